@@ -1,0 +1,193 @@
+/*
+ * mt3_hip.h -- C ABI of libmt3hip.so, the MI355X (gfx950) engine for the MT3
+ * audio -> notes inference path.
+ *
+ * The reference (magenta/mt3) has no FFI layer: its boundary is a Python class,
+ * `InferenceModel` (colab/music_transcription_with_transformers.ipynb, cell
+ * "Imports and Definitions"), plus the t5x write_fn in mt3/inference.py:34-138.
+ * Each entry point below replaces the *compiled work* behind one reference call;
+ * the Python mirror in mt3_amd/ keeps the reference's names on top of it
+ * (see INTEGRATION.md for the ctypes binding a reference maintainer would add).
+ *
+ * Conventions
+ *   - every function returns int: 0 = MT3_OK, negative = mt3_status;
+ *     mt3_last_error() gives a message for the calling thread.
+ *   - no exception crosses the ABI; no torch / C++ types in signatures.
+ *   - `d_*` pointers are DEVICE pointers owned by the caller (torch tensors in
+ *     the Python mirror); `h_*` are host pointers.  The library never frees or
+ *     reallocates caller memory.  Work is enqueued on `stream` (a hipStream_t
+ *     passed as void*) and the call returns without synchronising, except
+ *     mt3_engine_load_weight / mt3_engine_finalize (setup) and the pure-host
+ *     functions.
+ *   - one engine per (device, stream); an engine is not thread-safe, distinct
+ *     engines are independent.
+ */
+#ifndef MT3_HIP_H_
+#define MT3_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum mt3_status {
+  MT3_OK = 0,
+  MT3_ERR_INVALID = -1,   /* bad argument / shape / state                      */
+  MT3_ERR_HIP = -2,       /* a HIP runtime call failed (no GPU, OOM, launch)   */
+  MT3_ERR_CAPACITY = -3,  /* caller's output buffer too small; size returned   */
+  MT3_ERR_MISSING = -4    /* weight not loaded / unknown weight name           */
+} mt3_status;
+
+const char* mt3_last_error(void);
+int mt3_abi_version(void);
+
+/* ------------------------------------------------------------------ frontend
+ * Replaces spectrograms.compute_spectrogram -> spectral_ops.compute_logmel
+ * (mt3/spectrograms.py:64-73, mt3/spectral_ops.py:29-88) as called per segment by
+ * preprocessors.compute_spectrograms (mt3/preprocessors.py:613-618), plus the
+ * zero-fill of short segments done later by the feature converter
+ * (mt3/models.py:48-98): frames >= n_frames[s] are written as 0.0, not log(eps).
+ */
+typedef struct mt3_frontend_config {
+  int32_t sample_rate;   /* 16000  spectrograms.py:23 */
+  int32_t hop_width;     /* 128    spectrograms.py:24 */
+  int32_t num_mel_bins;  /* 512    spectrograms.py:25 */
+  int32_t fft_size;      /* 2048   spectrograms.py:28 */
+  float lo_hz;           /* 20.0   spectrograms.py:29 */
+  float hi_hz;           /* 7600.0 spectral_ops.py:79 */
+} mt3_frontend_config;
+
+typedef struct mt3_frontend mt3_frontend;
+
+int mt3_frontend_create(const mt3_frontend_config* cfg, mt3_frontend** out);
+void mt3_frontend_destroy(mt3_frontend* fe);
+/* number of non-zero mel weights and a copy of the dense [fft/2+1, mel] f32 matrix
+ * the kernel was built from (for parity tests) */
+int mt3_frontend_mel_matrix(const mt3_frontend* fe, float* h_out /*[(fft/2+1)*mel]*/, int64_t* nnz);
+/* d_audio  [n_segments, frames_per_segment*hop] f32 (segment s uses its first
+ *          h_n_frames[s]*hop samples; the rest is ignored)
+ * d_logmel [n_segments, frames_per_segment, num_mel_bins] f32 */
+int mt3_frontend_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segments,
+                        int32_t frames_per_segment, const int32_t* h_n_frames /* may be NULL = all full */,
+                        float* d_logmel, void* stream);
+
+/* -------------------------------------------------------------------- engine
+ * Replaces network.Transformer (mt3/network.py:265-409, layers in mt3/layers.py)
+ * as driven by t5x predict_batch_with_aux through
+ * models.ContinuousInputsEncoderDecoderModel (mt3/models.py:121-152):
+ * encode once, cross-K/V once, then up to `max_decode_len` cached decode steps.
+ */
+typedef enum mt3_dtype { MT3_BF16 = 0, MT3_F32 = 1 } mt3_dtype;
+
+typedef struct mt3_engine_config {   /* network.T5Config (network.py:25-41), model.gin:47-59 */
+  int32_t vocab_size;           /* 1536 (mt3) / 1664 (ismir2021): vocabularies.num_embeddings */
+  int32_t emb_dim;              /* 512  */
+  int32_t num_heads;            /* 6    */
+  int32_t head_dim;             /* 64 (only 64 is supported by the attention kernels) */
+  int32_t mlp_dim;              /* 1024 */
+  int32_t num_encoder_layers;   /* 8    */
+  int32_t num_decoder_layers;   /* 8    */
+  int32_t input_depth;          /* 512 = spectrograms.input_depth */
+  int32_t input_length;         /* T: 256 (mt3) / 512 (ismir2021) encoder frames */
+  int32_t max_decode_len;       /* L: 1024 */
+  int32_t max_batch;            /* segments per call the workspaces are sized for */
+  int32_t compute_dtype;        /* mt3_dtype: MFMA operand type; accumulation is always f32 */
+} mt3_engine_config;
+
+typedef struct mt3_engine mt3_engine;
+
+int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out);
+void mt3_engine_destroy(mt3_engine* e);
+/* Flax parameter names of the reference tree joined by '/', e.g.
+ * "encoder/layers_0/attention/query/kernel" (SURVEY.md A.3); h_data is f32,
+ * row-major, in the reference's own [in, out] orientation. */
+int mt3_engine_load_weight(mt3_engine* e, const char* name, const float* h_data,
+                           const int64_t* shape, int32_t ndim);
+/* folds norm scales, fuses QKV / gate matrices, converts to compute dtype, uploads */
+int mt3_engine_finalize(mt3_engine* e);
+int64_t mt3_engine_device_bytes(const mt3_engine* e);
+
+/* Transformer.encode (network.py:275-301) + cross-attention K/V of every decoder
+ * layer (layers.py:239-240, hoisted out of the decode loop).
+ * d_inputs [batch, T, input_depth] f32.  d_encoded_f32 [batch, T, emb] f32 or NULL. */
+int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch,
+                      float* d_encoded_f32, void* stream);
+
+/* Greedy autoregressive decode (BOS=0, EOS=1; ids after a row's EOS are 0).
+ * Runs `num_steps` (<= L) steps; each step is one hipGraph replay unless
+ * flags & MT3_DECODE_NO_GRAPH.  d_ids [batch, L] int32 (columns >= num_steps
+ * are zero-filled).  d_first_logits: [batch, vocab] f32 logits of step 0, or NULL.
+ * With MT3_DECODE_EARLY_EXIT the host polls a device flag every 32 steps and
+ * stops once every row has emitted EOS (this synchronises the stream). */
+enum { MT3_DECODE_NO_GRAPH = 1, MT3_DECODE_EARLY_EXIT = 2 };
+int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags,
+                      int32_t* d_ids, float* d_first_logits, int32_t* h_steps_run, void* stream);
+
+/* GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271): -1 from the
+ * first EOS(1) to the end of the row, id-3 for 3 <= id < 3+num_regular, else -2. */
+int mt3_ids_to_tokens(const int32_t* d_ids, int32_t batch, int32_t length, int32_t num_regular,
+                      int32_t* d_tokens, void* stream);
+
+/* ------------------------------------------------ kernel-level entry points
+ * The same kernels the engine launches, exposed one at a time so that parity
+ * tests can check each against the oracle.  dtype: mt3_dtype of A/W/out. */
+enum { MT3_EPI_STORE = 0, MT3_EPI_RESID = 1, MT3_EPI_GEGLU = 2, MT3_EPI_POS = 3, MT3_EPI_F32 = 4, MT3_EPI_HEADS = 5 };
+/* out = epilogue( [rms(A)] * A[M,K] @ Wt[N,K]^T );  a_is_f32: A is f32 (converted on load);
+ * norm: multiply rows by rsqrt(mean(A^2)+1e-6) (requires a_is_f32).  aux: pos table (EPI_POS, f32 [T,N]);
+ * seq_len: T for EPI_POS / EPI_HEADS; heads for EPI_HEADS = N/(2*64).  small: use the decode-sized tile. */
+int mt3_op_gemm(int32_t dtype, const void* d_A, int32_t a_is_f32, int32_t norm, const void* d_Wt,
+                void* d_out, int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* d_aux,
+                int32_t seq_len, int32_t small, void* stream);
+/* encoder self-attention over qkv [B, T, 3, H, 64] -> out [B, T, H*64]; unscaled logits, softmax f32 */
+int mt3_op_encoder_attention(int32_t dtype, const void* d_qkv, void* d_out, int32_t B, int32_t T, int32_t H,
+                             void* stream);
+/* single-query attention: q [B, H*64] (row stride q_stride elements) against cache K/V [B, H, cap, 64],
+ * attending positions 0..n_keys-1; if d_new_kv != NULL its [B, 2, H, 64]-strided K/V rows (row stride
+ * kv_stride, K at +0 and V at +H*64) are first appended at position n_keys-1.  n_keys read from *d_step+1
+ * when d_step != NULL. */
+int mt3_op_decode_attention(int32_t dtype, const void* d_q, int32_t q_stride, void* d_kcache, void* d_vcache,
+                            int32_t cap, const void* d_new_k, const void* d_new_v, int32_t kv_stride,
+                            const int32_t* d_step, int32_t n_keys, void* d_out, int32_t B, int32_t H, void* stream);
+
+/* --------------------------------------------------- symbolic stage (host CPU)
+ * Replaces metrics_utils.event_predictions_to_ns (mt3/metrics_utils.py:59-146) =
+ * decode_and_combine_predictions + run_length_encoding.decode_events
+ * (mt3/run_length_encoding.py:371-423) + the note state machine
+ * (mt3/note_sequences.py:262-446) + event_codec.Codec.decode_event_index
+ * (mt3/event_codec.py:103-112).  Integer results are bit-exact with the reference;
+ * times are computed in double with the reference's own expressions.
+ */
+enum { MT3_EV_SHIFT = 0, MT3_EV_PITCH = 1, MT3_EV_VELOCITY = 2, MT3_EV_TIE = 3, MT3_EV_PROGRAM = 4, MT3_EV_DRUM = 5 };
+enum { MT3_SPEC_ONSETS = 0, MT3_SPEC_NOTES = 1, MT3_SPEC_TIES = 2 };  /* note_sequences.py:416-446 */
+
+typedef struct mt3_event_range { int32_t type, min_value, max_value; } mt3_event_range;
+typedef struct mt3_codec {
+  double steps_per_second;
+  int32_t num_ranges;               /* ranges[0] must be MT3_EV_SHIFT with min 0 */
+  mt3_event_range ranges[8];
+} mt3_codec;
+typedef struct mt3_note {
+  double start_time, end_time;
+  int32_t pitch, velocity, program, is_drum, instrument, reserved;
+} mt3_note;
+
+/* vocabularies.build_codec (mt3/vocabularies.py:119-140) */
+int mt3_build_codec(int32_t steps_per_second, int32_t max_shift_seconds, int32_t num_velocity_bins,
+                    mt3_codec* out);
+int mt3_codec_num_classes(const mt3_codec* c);
+int mt3_codec_decode_event(const mt3_codec* c, int32_t index, int32_t* type, int32_t* value);  /* MT3_ERR_INVALID = ValueError */
+int mt3_codec_encode_event(const mt3_codec* c, int32_t type, int32_t value, int32_t* index);
+/* tokens: concatenated per-segment token rows (already trimmed at EOS); seg_offsets [n_segments+1];
+ * h_has_max_time==NULL -> the combiner rule (max_time = next segment's start, none for the last);
+ * otherwise explicit per-segment max_time (decode_events' own argument). */
+int mt3_notes_decode(const mt3_codec* c, int32_t spec, int32_t n_segments, const int32_t* h_tokens,
+                     const int64_t* h_seg_offsets, const double* h_start_times,
+                     const int32_t* h_has_max_time, const double* h_max_times,
+                     mt3_note* h_notes, int64_t notes_capacity, int64_t* n_notes,
+                     int64_t* invalid_events, int64_t* dropped_events, double* total_time);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MT3_HIP_H_ */

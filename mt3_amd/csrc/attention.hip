@@ -1,0 +1,385 @@
+// Attention kernels of the MT3 path on gfx950.
+//
+// Reference semantics (mt3/layers.py:85-157 `dot_product_attention`, called from
+// MultiHeadDotProductAttention, layers.py:164-355): logits = Q K^T with NO 1/sqrt(d)
+// scaling (layers.py:230-234), f32 softmax over keys, then P V.  The encoder mask is all ones
+// (network.py:283-289); the cached decoder attends positions 0..t (layers.py:297-305), which
+// here is a loop bound instead of a -1e10 bias.
+//
+// (1) enc_attn_kernel: one workgroup per (batch, head), T = 256/512 keys, head_dim 64.
+//     K [T][64] and V^T [64][T] of the head are staged into LDS ONCE (each K/V byte is read
+//     from HBM exactly once); every wave then owns 16-query tiles:
+//       S^T = K Q^T on the matrix pipe with K as the A operand, so that a lane ends up holding,
+//       for ITS query (lane & 15), the scores of keys kb*16 + (lane>>4)*4 + r -- the softmax
+//       row reduction is in-lane plus two cross-lane steps (xor 16, 32), and the probabilities
+//       are already laid out as the A operand of the P V product (two 16-key blocks = one
+//       32-wide K-group): no LDS round trip for P.
+//       V is consumed as V^T rows so the B operand is K-contiguous (8-byte LDS reads).
+// (2) dec_attn_kernel: single-query attention of one decode step -- pure HBM streaming of the
+//     K/V cache [B][H][cap][64]; LPK lanes share a key (16 bytes each), a wave covers 64/LPK
+//     consecutive keys per load (1 KiB contiguous), 4-deep unrolled so every lane keeps 8 loads
+//     in flight; online softmax per lane group, merged across groups by shuffles and across the
+//     4 waves through LDS.  With APPEND the step's new K/V row is written to the cache at
+//     position *step by the same kernel (the reference rewrites the WHOLE cache per step with a
+//     one-hot multiply-add: layers.py:272-292).
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "device.h"
+#include "kernels.h"
+
+namespace mt3k {
+
+// ------------------------------------------------------------------------ encoder attention
+template <typename CT, int T>
+__global__ __launch_bounds__(256) void enc_attn_kernel(const CT* __restrict__ qkv, CT* __restrict__ out, int H) {
+  constexpr int KPL = CTraits<CT>::KPL;
+  constexpr int KG = CTraits<CT>::KGROUP;       // head-dim / key elements per chunk-MFMA
+  constexpr int D = 64;
+  constexpr int ROWK = D + KPL;                 // K tile row (elements), one pad chunk
+  constexpr int ROWV = T + 8;                   // V^T row (elements): keeps 8/16-byte alignment
+  constexpr int CH = D / KPL;                   // chunks per K/V row
+  constexpr int NC = D / KG;                    // K-groups across the head dim
+
+  __shared__ __attribute__((aligned(16))) CT Ks[T * ROWK];
+  __shared__ __attribute__((aligned(16))) CT Vt[D * ROWV];
+
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int RS = 3 * H * D;                     // qkv row stride (elements)
+  const CT* base = qkv + static_cast<size_t>(b) * T * RS + h * D;
+
+  // ---- stage K (row-major) : chunk c -> row c / CH, piece c % CH
+  for (int c = tid; c < T * CH; c += 256) {
+    const int row = c / CH, ch = c % CH;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(base + static_cast<size_t>(row) * RS + H * D + ch * KPL);
+    *reinterpret_cast<u32x4*>(&Ks[row * ROWK + ch * KPL]) = v;
+  }
+  // ---- stage V transposed: work item = (key pair, piece); a wave takes 64 consecutive key pairs
+  for (int w = tid; w < (T / 2) * CH; w += 256) {
+    const int rp = w % (T / 2), ch = w / (T / 2);
+    const CT* src = base + static_cast<size_t>(2 * rp) * RS + 2 * H * D + ch * KPL;
+    const u32x4 v0 = *reinterpret_cast<const u32x4*>(src);
+    const u32x4 v1 = *reinterpret_cast<const u32x4*>(src + RS);
+    if constexpr (KPL == 8) {
+      const bf16x8 a = __builtin_bit_cast(bf16x8, v0), c = __builtin_bit_cast(bf16x8, v1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+        const bf16x2 pr = {a[j], c[j]};
+        *reinterpret_cast<bf16x2*>(&Vt[(ch * 8 + j) * ROWV + 2 * rp]) = pr;
+      }
+    } else {
+      const f32x4 a = __builtin_bit_cast(f32x4, v0), c = __builtin_bit_cast(f32x4, v1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<float2*>(&Vt[(ch * 4 + j) * ROWV + 2 * rp]) = make_float2(a[j], c[j]);
+    }
+  }
+  __syncthreads();
+
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int qt = wave; qt < T / 16; qt += 4) {
+    const int q0 = qt * 16;
+    // Q^T as the B operand: col n = query q0 + fr, K-group chunk c
+    u32x4 qf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+      qf[c] = *reinterpret_cast<const u32x4*>(base + static_cast<size_t>(q0 + fr) * RS + c * KG + fg * KPL);
+
+    // online softmax over 64-key chunks (4 blocks of 16 keys): keeps the live score registers at 16
+    // per lane instead of T/4, so T = 512 and the f32 path stay out of scratch.
+    float m = -3.0e38f, l = 0.f;                 // running max (uniform over the 4 lane groups), lane-partial sum
+    f32x4 o[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) o[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int k64 = 0; k64 < T / 64; ++k64) {
+      // S^T block j: rows = keys (k64*4 + j)*16 + fg*4 + r, col = query fr
+      f32x4 sc[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const u32x4 kf =
+              *reinterpret_cast<const u32x4*>(&Ks[((k64 * 4 + j) * 16 + fr) * ROWK + c * KG + fg * KPL]);
+          mfma_chunk<CT>(kf, qf[c], sc[j]);
+        }
+      }
+      float cm = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cm = fmaxf(cm, sc[j][r]);
+      cm = fmaxf(cm, __shfl_xor(cm, 16));
+      cm = fmaxf(cm, __shfl_xor(cm, 32));
+      const float mn = fmaxf(m, cm);
+      const float alpha = expf(m - mn);          // 0 on the first chunk
+      m = mn;
+      float ls = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = expf(sc[j][r] - mn);
+          sc[j][r] = p;
+          ls += p;
+        }
+      l = l * alpha + ls;
+      // rescale O: its rows are queries fg*4 + r, whose alpha lives in lane fg*4 + r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ar = __shfl(alpha, fg * 4 + r);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) o[nb][r] *= ar;
+      }
+      // O += P V : A = P (row = query fr, K-slots = this lane's keys), B = V^T rows (col = d)
+      if constexpr (KPL == 8) {
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+          const float pv[8] = {sc[2 * kc][0],     sc[2 * kc][1],     sc[2 * kc][2],     sc[2 * kc][3],
+                               sc[2 * kc + 1][0], sc[2 * kc + 1][1], sc[2 * kc + 1][2], sc[2 * kc + 1][3]};
+          const u32x4 pa = pack_bf16x8(pv);
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            const CT* vrow = &Vt[(nb * 16 + fr) * ROWV + k64 * 64 + fg * 4];
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (2 * kc) * 16);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (2 * kc + 1) * 16);
+            const u32x4 vb = u32x4{lo.x, lo.y, hi.x, hi.y};
+            mfma_chunk<CT>(pa, vb, o[nb]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32x4 pa = pack_f32x4(sc[j][0], sc[j][1], sc[j][2], sc[j][3]);
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            const u32x4 vb =
+                *reinterpret_cast<const u32x4*>(&Vt[(nb * 16 + fr) * ROWV + (k64 * 4 + j) * 16 + fg * 4]);
+            mfma_chunk<CT>(pa, vb, o[nb]);
+          }
+        }
+      }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float linv = 1.f / l;
+    // O fragment: row = query fg*4 + r, col = d = nb*16 + fr.  1/l of that query lives in lane fg*4 + r.
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float li = __shfl(linv, fg * 4 + r);
+      CT* dst = out + (static_cast<size_t>(b) * T + q0 + fg * 4 + r) * (H * D) + h * D + fr;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) dst[nb * 16] = to_ct<CT>(o[nb][r] * li);
+    }
+  }
+}
+
+int launch_encoder_attention(int dtype, const void* qkv, void* out, int B, int T, int H, hipStream_t s) {
+  if (!qkv || !out || B <= 0 || H <= 0) return mt3::fail(MT3_ERR_INVALID, "encoder_attention: bad arguments");
+  const dim3 grid(B * H), block(256);
+  if (dtype == MT3_BF16 && T == 256) {
+    hipLaunchKernelGGL((enc_attn_kernel<__bf16, 256>), grid, block, 0, s, static_cast<const __bf16*>(qkv),
+                       static_cast<__bf16*>(out), H);
+  } else if (dtype == MT3_BF16 && T == 512) {
+    hipLaunchKernelGGL((enc_attn_kernel<__bf16, 512>), grid, block, 0, s, static_cast<const __bf16*>(qkv),
+                       static_cast<__bf16*>(out), H);
+  } else if (dtype == MT3_F32 && T == 256) {
+    hipLaunchKernelGGL((enc_attn_kernel<float, 256>), grid, block, 0, s, static_cast<const float*>(qkv),
+                       static_cast<float*>(out), H);
+  } else {
+    return mt3::fail(MT3_ERR_INVALID,
+                     "encoder_attention: supported (dtype, T) are (bf16, 256), (bf16, 512), (f32, 256)");
+  }
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+
+// ------------------------------------------------------------------------- decode attention
+template <typename CT, bool APPEND>
+__global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs a) {
+  constexpr int KPL = CTraits<CT>::KPL;
+  constexpr int D = 64;
+  constexpr int LPK = D / KPL;            // lanes sharing one key (8 bf16 / 16 f32)
+  constexpr int KPW = 64 / LPK;           // keys per wave per load
+  constexpr int STRIDE = 4 * KPW;         // keys per block iteration
+  constexpr int UNROLL = 4;
+
+  __shared__ float s_m[4][LPK], s_l[4][LPK], s_acc[4][LPK][KPL];
+
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane % LPK, slot = lane / LPK;
+  const int n_keys = a.step ? (*a.step + 1) : a.n_keys;
+  const int pos = n_keys - 1;
+
+  const CT* kc = static_cast<const CT*>(a.kcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;
+  const CT* vc = static_cast<const CT*>(a.vcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;
+  const CT* nk = nullptr;
+  const CT* nv = nullptr;
+  if constexpr (APPEND) {
+    nk = static_cast<const CT*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D;
+    nv = static_cast<const CT*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D;
+    // persist this step's K/V row (read back by later steps; this step reads it from nk/nv)
+    if (tid < 2 * LPK) {
+      const int which = tid / LPK, piece = tid % LPK;
+      const CT* src = (which ? nv : nk) + piece * KPL;
+      CT* dst = (which ? static_cast<CT*>(a.vcache) : static_cast<CT*>(a.kcache)) +
+                ((static_cast<size_t>(b) * a.H + h) * a.cap + pos) * D + piece * KPL;
+      *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+    }
+  }
+
+  float qf[KPL];
+  {
+    const u32x4 qc = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.q) +
+                                                     static_cast<size_t>(b) * a.q_stride + h * D + sub * KPL);
+    unpack_chunk<CT>(qc, qf);
+  }
+
+  float m = -1.0e30f, l = 0.f, acc[KPL];
+#pragma unroll
+  for (int j = 0; j < KPL; ++j) acc[j] = 0.f;
+
+  for (int k0 = wave * KPW + slot; k0 < n_keys; k0 += STRIDE * UNROLL) {
+    u32x4 kv[UNROLL], vv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int key = k0 + u * STRIDE;
+      if (key < n_keys) {
+        const CT* kp = kc + static_cast<size_t>(key) * D + sub * KPL;
+        const CT* vp = vc + static_cast<size_t>(key) * D + sub * KPL;
+        if constexpr (APPEND) {
+          if (key == pos) {
+            kp = nk + sub * KPL;
+            vp = nv + sub * KPL;
+          }
+        }
+        kv[u] = *reinterpret_cast<const u32x4*>(kp);
+        vv[u] = *reinterpret_cast<const u32x4*>(vp);
+      } else {
+        kv[u] = u32x4{0u, 0u, 0u, 0u};
+        vv[u] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int key = k0 + u * STRIDE;
+      float kf[KPL], vf[KPL];
+      unpack_chunk<CT>(kv[u], kf);
+      unpack_chunk<CT>(vv[u], vf);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) s += qf[j] * kf[j];
+#pragma unroll
+      for (int o = LPK / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);      // the LPK lanes of this key
+      if (key < n_keys) {                                              // uniform within the key's lanes
+        const float mn = fmaxf(m, s);
+        const float sc = expf(m - mn), p = expf(s - mn);
+        l = l * sc + p;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) acc[j] = acc[j] * sc + p * vf[j];
+        m = mn;
+      }
+    }
+  }
+  // merge the key slots of this wave (lanes with equal `sub`)
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    const float mo = __shfl_xor(m, o), lo = __shfl_xor(l, o);
+    const float mn = fmaxf(m, mo);
+    const float ca = expf(m - mn), cb = expf(mo - mn);
+    l = l * ca + lo * cb;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) {
+      const float ao = __shfl_xor(acc[j], o);
+      acc[j] = acc[j] * ca + ao * cb;
+    }
+    m = mn;
+  }
+  if (lane < LPK) {
+    s_m[wave][lane] = m;
+    s_l[wave][lane] = l;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) s_acc[wave][lane][j] = acc[j];
+  }
+  __syncthreads();
+  if (tid < LPK) {
+    float M = s_m[0][tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, s_m[w][tid]);
+    float L = 0.f, o[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float c = expf(s_m[w][tid] - M);
+      L += s_l[w][tid] * c;
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) o[j] += s_acc[w][tid][j] * c;
+    }
+    const float inv = 1.f / L;
+    CT* dst = static_cast<CT*>(a.out) + static_cast<size_t>(b) * a.H * D + h * D + tid * KPL;
+    if constexpr (KPL == 8) {
+      float r[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = o[j] * inv;
+      *reinterpret_cast<u32x4*>(dst) = pack_bf16x8(r);
+    } else {
+      *reinterpret_cast<u32x4*>(dst) = pack_f32x4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv);
+    }
+  }
+}
+
+int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
+  if (!a.q || !a.kcache || !a.vcache || !a.out || a.B <= 0 || a.H <= 0 || a.cap <= 0)
+    return mt3::fail(MT3_ERR_INVALID, "decode_attention: bad arguments");
+  if (!a.step && (a.n_keys <= 0 || a.n_keys > a.cap)) return mt3::fail(MT3_ERR_INVALID, "decode_attention: n_keys");
+  const bool append = a.new_k != nullptr;
+  if (append && !a.new_v) return mt3::fail(MT3_ERR_INVALID, "decode_attention: new_k without new_v");
+  const dim3 grid(a.B * a.H), block(256);
+  if (dtype == MT3_BF16) {
+    if (append) hipLaunchKernelGGL((dec_attn_kernel<__bf16, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((dec_attn_kernel<__bf16, false>), grid, block, 0, s, a);
+  } else if (dtype == MT3_F32) {
+    if (append) hipLaunchKernelGGL((dec_attn_kernel<float, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((dec_attn_kernel<float, false>), grid, block, 0, s, a);
+  } else {
+    return mt3::fail(MT3_ERR_INVALID, "decode_attention: unknown dtype");
+  }
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+
+}  // namespace mt3k
+
+extern "C" {
+
+int mt3_op_encoder_attention(int32_t dtype, const void* d_qkv, void* d_out, int32_t B, int32_t T, int32_t H,
+                             void* stream) {
+  return mt3k::launch_encoder_attention(dtype, d_qkv, d_out, B, T, H, static_cast<hipStream_t>(stream));
+}
+
+int mt3_op_decode_attention(int32_t dtype, const void* d_q, int32_t q_stride, void* d_kcache, void* d_vcache,
+                            int32_t cap, const void* d_new_k, const void* d_new_v, int32_t kv_stride,
+                            const int32_t* d_step, int32_t n_keys, void* d_out, int32_t B, int32_t H, void* stream) {
+  mt3k::DecAttnArgs a{};
+  a.q = d_q;
+  a.q_stride = q_stride;
+  a.kcache = d_kcache;
+  a.vcache = d_vcache;
+  a.cap = cap;
+  a.new_k = d_new_k;
+  a.new_v = d_new_v;
+  a.kv_stride = kv_stride;
+  a.step = d_step;
+  a.n_keys = n_keys;
+  a.out = d_out;
+  a.B = B;
+  a.H = H;
+  return mt3k::launch_decode_attention(dtype, a, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,548 @@
+// The MT3 encoder-decoder engine behind mt3_engine_* (include/mt3_hip.h).
+//
+// Replaces network.Transformer (mt3/network.py:265-409) as t5x's predict_batch_with_aux drives it
+// (mt3/models.py:121-152): `encode` once, then a cached single-token `decode` per step.
+//
+// MI355X design notes
+//   * weights live on the device in the layouts the kernels want, built once at finalize():
+//       - every DenseGeneral kernel [in,out] (layers.py:373-418) is stored output-major Wt[out][in];
+//       - Q|K|V (layers.py:238-240) are fused into one [3*H*64][emb] matrix, wi_0|wi_1
+//         (layers.py:460-468) are interleaved in 16-row groups for the GEGLU epilogue;
+//       - every pre-norm scale (network.py:54-56,71,104-106,126-128,142,244) is folded into the
+//         rows of the matrix that consumes the normalised activations (the rsqrt part is computed
+//         inside that GEMM), so the only standalone norm left is `encoder_norm`.
+//   * cross-attention K/V (layers.py:239-240 via network.py:129-135) are computed ONCE per encode
+//     for all decoder layers, head-major for the streaming decode kernel; the reference recomputes
+//     them inside every decode step unless XLA hoists them.
+//   * the self-attention cache is [B][H][L][64] written in place at position t (the reference
+//     rewrites the whole [B,H,64,L] cache per step: layers.py:272-292).
+//   * one decode step = 8 x 8 + 4 kernels with the step index in DEVICE memory, captured once per
+//     batch size into a hipGraph and replayed L times.
+//   * sized for 288 GB HBM: all workspaces for max_batch are allocated up front
+//     (B=256: ~3.3 GB KV cache + ~0.9 GB cross K/V + ~0.5 GB activations in bf16).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+#include "mt3_hip.h"
+
+namespace {
+
+constexpr int kMaxPos = 2048;   // FixedEmbed.max_length, layers.py:565
+
+uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40);   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                                       // RNE
+  return static_cast<uint16_t>(u >> 16);
+}
+
+struct HostWeight {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+};
+
+struct LayerDev {
+  void* wqkv = nullptr;      // [3HD][emb]
+  void* wo = nullptr;        // [emb][HD]
+  void* wq_x = nullptr;      // decoder cross query [HD][emb]
+  void* wkv_x = nullptr;     // decoder cross key|value [2HD][emb]
+  void* wo_x = nullptr;      // decoder cross out [emb][HD]
+  void* wi = nullptr;        // [2*mlp][emb] interleaved gate/linear
+  void* wo_mlp = nullptr;    // [emb][mlp]
+  void* self_k = nullptr;    // decoder [Bm][H][L][64]
+  void* self_v = nullptr;
+  void* cross_kv = nullptr;  // decoder [2][B][H][T][64]
+};
+
+}  // namespace
+
+struct mt3_engine {
+  mt3_engine_config cfg{};
+  std::map<std::string, HostWeight> raw;
+  std::vector<void*> allocs;
+  int64_t device_bytes = 0;
+  bool finalized = false;
+  int esize = 2;
+
+  void* enc_in = nullptr;        // [emb][input_depth]
+  float* enc_norm = nullptr;     // [emb] f32
+  float* embedding = nullptr;    // [V][emb] f32
+  void* logits_w = nullptr;      // [V][emb] (decoder_norm folded)
+  float* pos_table = nullptr;    // [kMaxPos][emb] f32
+  std::vector<LayerDev> enc, dec;
+
+  // encoder workspaces
+  float* x = nullptr;
+  void* qkv = nullptr;
+  void* attn = nullptr;
+  void* hbuf = nullptr;
+  void* enc_out = nullptr;
+  // decode workspaces
+  float* y = nullptr;
+  void* qkv_d = nullptr;
+  void* attn_d = nullptr;
+  void* q_d = nullptr;
+  void* h_d = nullptr;
+  float* logits = nullptr;
+  int* ids = nullptr;
+  int* cur_tok = nullptr;
+  int* done = nullptr;
+  int* step = nullptr;
+  int* n_done = nullptr;
+  int* h_pinned = nullptr;
+
+  int cur_batch = 0;             // batch of the last encode
+  hipStream_t cap_stream = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  hipGraph_t graph = nullptr;
+  int graph_batch = 0;
+
+  int HD() const { return cfg.num_heads * cfg.head_dim; }
+};
+
+namespace {
+
+int dmalloc(mt3_engine* e, void** p, size_t bytes) {
+  MT3_HIP_CHECK(hipMalloc(p, bytes));
+  e->allocs.push_back(*p);
+  e->device_bytes += static_cast<int64_t>(bytes);
+  return MT3_OK;
+}
+
+// upload a host f32 matrix as the compute type
+int upload_ct(mt3_engine* e, const std::vector<float>& h, void** d) {
+  int rc = dmalloc(e, d, h.size() * e->esize);
+  if (rc) return rc;
+  if (e->cfg.compute_dtype == MT3_BF16) {
+    std::vector<uint16_t> t(h.size());
+    for (size_t i = 0; i < h.size(); ++i) t[i] = f32_to_bf16_bits(h[i]);
+    MT3_HIP_CHECK(hipMemcpy(*d, t.data(), t.size() * 2, hipMemcpyHostToDevice));
+  } else {
+    MT3_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  }
+  return MT3_OK;
+}
+
+int upload_f32(mt3_engine* e, const std::vector<float>& h, float** d) {
+  int rc = dmalloc(e, reinterpret_cast<void**>(d), h.size() * 4);
+  if (rc) return rc;
+  MT3_HIP_CHECK(hipMemcpy(*d, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  return MT3_OK;
+}
+
+const HostWeight* find(mt3_engine* e, const std::string& name, int64_t d0, int64_t d1) {
+  auto it = e->raw.find(name);
+  if (it == e->raw.end()) {
+    mt3::fail(MT3_ERR_MISSING, "weight not loaded: " + name);
+    return nullptr;
+  }
+  const HostWeight& w = it->second;
+  const bool ok = (d1 < 0) ? (w.shape.size() == 1 && w.shape[0] == d0)
+                           : (w.shape.size() == 2 && w.shape[0] == d0 && w.shape[1] == d1);
+  if (!ok) {
+    mt3::fail(MT3_ERR_INVALID, "weight has the wrong shape: " + name);
+    return nullptr;
+  }
+  return &w;
+}
+
+// dst rows [row0, row0+out) of an output-major matrix with `in` columns  <-  W[in][out] (* scale[in])
+void put_transposed(std::vector<float>& dst, int in, int row0, const HostWeight& w, const float* scale) {
+  const int out = static_cast<int>(w.shape[1]);
+  for (int k = 0; k < in; ++k) {
+    const float s = scale ? scale[k] : 1.f;
+    const float* src = w.data.data() + static_cast<size_t>(k) * out;
+    for (int n = 0; n < out; ++n) dst[static_cast<size_t>(row0 + n) * in + k] = src[n] * s;
+  }
+}
+
+int build_attention(mt3_engine* e, const std::string& prefix, const float* scale, bool cross, LayerDev* L) {
+  const int emb = e->cfg.emb_dim, hd = e->HD();
+  const HostWeight *q = find(e, prefix + "/query/kernel", emb, hd), *k = find(e, prefix + "/key/kernel", emb, hd),
+                   *v = find(e, prefix + "/value/kernel", emb, hd), *o = find(e, prefix + "/out/kernel", hd, emb);
+  if (!q || !k || !v || !o) return MT3_ERR_MISSING;
+  int rc;
+  std::vector<float> ot(static_cast<size_t>(emb) * hd);
+  put_transposed(ot, hd, 0, *o, nullptr);
+  if (!cross) {
+    std::vector<float> t(static_cast<size_t>(3) * hd * emb);
+    put_transposed(t, emb, 0, *q, scale);
+    put_transposed(t, emb, hd, *k, scale);
+    put_transposed(t, emb, 2 * hd, *v, scale);
+    if ((rc = upload_ct(e, t, &L->wqkv))) return rc;
+    if ((rc = upload_ct(e, ot, &L->wo))) return rc;
+  } else {
+    std::vector<float> tq(static_cast<size_t>(hd) * emb), tkv(static_cast<size_t>(2) * hd * emb);
+    put_transposed(tq, emb, 0, *q, scale);         // query side sees the pre_cross_attention norm
+    put_transposed(tkv, emb, 0, *k, nullptr);      // key/value side sees `encoded` (already normed)
+    put_transposed(tkv, emb, hd, *v, nullptr);
+    if ((rc = upload_ct(e, tq, &L->wq_x))) return rc;
+    if ((rc = upload_ct(e, tkv, &L->wkv_x))) return rc;
+    if ((rc = upload_ct(e, ot, &L->wo_x))) return rc;
+  }
+  return MT3_OK;
+}
+
+int build_mlp(mt3_engine* e, const std::string& prefix, const float* scale, LayerDev* L) {
+  const int emb = e->cfg.emb_dim, mlp = e->cfg.mlp_dim;
+  const HostWeight *w0 = find(e, prefix + "/wi_0/kernel", emb, mlp), *w1 = find(e, prefix + "/wi_1/kernel", emb, mlp),
+                   *wo = find(e, prefix + "/wo/kernel", mlp, emb);
+  if (!w0 || !w1 || !wo) return MT3_ERR_MISSING;
+  // rows [32q, 32q+16) = gate columns 16q.., rows [32q+16, 32q+32) = linear columns 16q..
+  std::vector<float> t(static_cast<size_t>(2) * mlp * emb);
+  for (int k = 0; k < emb; ++k) {
+    const float s = scale[k];
+    for (int n = 0; n < mlp; ++n) {
+      const int q = n >> 4, r = n & 15;
+      t[static_cast<size_t>(32 * q + r) * emb + k] = w0->data[static_cast<size_t>(k) * mlp + n] * s;
+      t[static_cast<size_t>(32 * q + 16 + r) * emb + k] = w1->data[static_cast<size_t>(k) * mlp + n] * s;
+    }
+  }
+  std::vector<float> ot(static_cast<size_t>(emb) * mlp);
+  put_transposed(ot, mlp, 0, *wo, nullptr);
+  int rc;
+  if ((rc = upload_ct(e, t, &L->wi))) return rc;
+  return upload_ct(e, ot, &L->wo_mlp);
+}
+
+const float* scale_of(mt3_engine* e, const std::string& name) {
+  const HostWeight* w = find(e, name, e->cfg.emb_dim, -1);
+  return w ? w->data.data() : nullptr;
+}
+
+mt3k::GemmArgs gemm_args(const void* A, const void* Wt, void* out, int M, int N, int K, int ldo) {
+  mt3k::GemmArgs g{};
+  g.A = A;
+  g.Wt = Wt;
+  g.out = out;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = K;
+  g.ldo = ldo;
+  return g;
+}
+
+#define MT3_TRY(expr)           \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != MT3_OK) return _rc; \
+  } while (0)
+
+int enqueue_decode_step(mt3_engine* e, int B, hipStream_t s) {
+  const mt3_engine_config& c = e->cfg;
+  const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), H = c.num_heads, T = c.input_length;
+  const bool small = true;
+  char* qkv_b = static_cast<char*>(e->qkv_d);
+  MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y, B, emb, s));
+  for (int l = 0; l < c.num_decoder_layers; ++l) {
+    LayerDev& L = e->dec[l];
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, L.wqkv, e->qkv_d, B, 3 * hd, emb, 3 * hd), true, true,
+                              MT3_EPI_STORE, small, s));
+    mt3k::DecAttnArgs a{};
+    a.q = e->qkv_d;
+    a.q_stride = 3 * hd;
+    a.kcache = L.self_k;
+    a.vcache = L.self_v;
+    a.cap = c.max_decode_len;
+    a.new_k = qkv_b + static_cast<size_t>(hd) * e->esize;
+    a.new_v = qkv_b + static_cast<size_t>(2 * hd) * e->esize;
+    a.kv_stride = 3 * hd;
+    a.step = e->step;
+    a.out = e->attn_d;
+    a.B = B;
+    a.H = H;
+    MT3_TRY(mt3k::launch_decode_attention(dt, a, s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->attn_d, L.wo, e->y, B, emb, hd, emb), false, false, MT3_EPI_RESID,
+                              small, s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, L.wq_x, e->q_d, B, hd, emb, hd), true, true, MT3_EPI_STORE, small,
+                              s));
+    mt3k::DecAttnArgs x{};
+    x.q = e->q_d;
+    x.q_stride = hd;
+    x.kcache = L.cross_kv;
+    x.vcache = static_cast<char*>(L.cross_kv) + static_cast<size_t>(B) * H * T * 64 * e->esize;
+    x.cap = T;
+    x.n_keys = T;
+    x.out = e->attn_d;
+    x.B = B;
+    x.H = H;
+    MT3_TRY(mt3k::launch_decode_attention(dt, x, s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->attn_d, L.wo_x, e->y, B, emb, hd, emb), false, false, MT3_EPI_RESID,
+                              small, s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, L.wi, e->h_d, B, 2 * c.mlp_dim, emb, c.mlp_dim), true, true,
+                              MT3_EPI_GEGLU, small, s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->h_d, L.wo_mlp, e->y, B, emb, c.mlp_dim, emb), false, false,
+                              MT3_EPI_RESID, small, s));
+  }
+  MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, e->logits_w, e->logits, B, c.vocab_size, emb, c.vocab_size), true,
+                            true, MT3_EPI_F32, small, s));
+  MT3_TRY(mt3k::launch_argmax_step(e->logits, c.vocab_size, e->ids, c.max_decode_len, e->cur_tok, e->done, e->n_done,
+                                   e->step, B, s));
+  MT3_TRY(mt3k::launch_advance_step(e->step, s));
+  return MT3_OK;
+}
+
+void drop_graph(mt3_engine* e) {
+  if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+  if (e->graph) (void)hipGraphDestroy(e->graph);
+  e->graph_exec = nullptr;
+  e->graph = nullptr;
+  e->graph_batch = 0;
+}
+
+// capture one decode step for batch B (on the engine's private stream: the caller's stream may be
+// the legacy default stream, which cannot be captured)
+int ensure_graph(mt3_engine* e, int B) {
+  if (e->graph_exec && e->graph_batch == B) return MT3_OK;
+  drop_graph(e);
+  if (!e->cap_stream) MT3_HIP_CHECK(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+  MT3_HIP_CHECK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+  const int rc = enqueue_decode_step(e, B, e->cap_stream);
+  hipGraph_t g = nullptr;
+  const hipError_t end = hipStreamEndCapture(e->cap_stream, &g);
+  if (rc != MT3_OK) {
+    if (g) (void)hipGraphDestroy(g);
+    return rc;
+  }
+  if (end != hipSuccess) return mt3::fail(MT3_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(end));
+  e->graph = g;
+  MT3_HIP_CHECK(hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0));
+  e->graph_batch = B;
+  return MT3_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
+  if (!cfg || !out) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: null argument");
+  if (cfg->head_dim != 64) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: head_dim must be 64");
+  if (cfg->compute_dtype != MT3_BF16 && cfg->compute_dtype != MT3_F32)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: compute_dtype must be MT3_BF16 or MT3_F32");
+  if (cfg->input_length != 256 && cfg->input_length != 512)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: input_length must be 256 (mt3) or 512 (ismir2021)");
+  if (cfg->compute_dtype == MT3_F32 && cfg->input_length != 256)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the f32 parity path supports input_length 256 only");
+  if (cfg->emb_dim % 128 || cfg->mlp_dim % 128 || cfg->vocab_size % 128 || cfg->input_depth % 64 ||
+      (cfg->num_heads * 64) % 128)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: emb/mlp/vocab/heads*64 must be multiples of 128");
+  if (cfg->max_batch <= 0 || cfg->max_decode_len <= 0 || cfg->max_decode_len > kMaxPos ||
+      cfg->num_encoder_layers <= 0 || cfg->num_decoder_layers <= 0)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: bad sizes");
+  mt3_engine* e = new (std::nothrow) mt3_engine();
+  if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
+  e->cfg = *cfg;
+  e->esize = cfg->compute_dtype == MT3_BF16 ? 2 : 4;
+  *out = e;
+  return MT3_OK;
+}
+
+void mt3_engine_destroy(mt3_engine* e) {
+  if (!e) return;
+  drop_graph(e);
+  if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+  if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+  for (void* p : e->allocs) (void)hipFree(p);
+  delete e;
+}
+
+int mt3_engine_load_weight(mt3_engine* e, const char* name, const float* h_data, const int64_t* shape, int32_t ndim) {
+  if (!e || !name || !h_data || !shape || ndim < 1 || ndim > 2)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_load_weight: bad arguments");
+  if (e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_load_weight: engine already finalized");
+  HostWeight w;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) {
+    if (shape[i] <= 0) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_load_weight: bad shape");
+    w.shape.push_back(shape[i]);
+    n *= static_cast<size_t>(shape[i]);
+  }
+  w.data.assign(h_data, h_data + n);
+  e->raw[name] = std::move(w);
+  return MT3_OK;
+}
+
+int64_t mt3_engine_device_bytes(const mt3_engine* e) { return e ? e->device_bytes : 0; }
+
+int mt3_engine_finalize(mt3_engine* e) {
+  if (!e) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_finalize: null engine");
+  if (e->finalized) return MT3_OK;
+  const mt3_engine_config& c = e->cfg;
+  const int emb = c.emb_dim, hd = e->HD(), Bm = c.max_batch, T = c.input_length, L = c.max_decode_len;
+  int rc;
+
+  // ---- encoder
+  {
+    const HostWeight* w = find(e, "encoder/continuous_inputs_projection/kernel", c.input_depth, emb);
+    if (!w) return MT3_ERR_MISSING;
+    std::vector<float> t(static_cast<size_t>(emb) * c.input_depth);
+    put_transposed(t, c.input_depth, 0, *w, nullptr);
+    if ((rc = upload_ct(e, t, &e->enc_in))) return rc;
+  }
+  e->enc.resize(c.num_encoder_layers);
+  for (int l = 0; l < c.num_encoder_layers; ++l) {
+    const std::string P = "encoder/layers_" + std::to_string(l);
+    const float* s1 = scale_of(e, P + "/pre_attention_layer_norm/scale");
+    const float* s2 = scale_of(e, P + "/pre_mlp_layer_norm/scale");
+    if (!s1 || !s2) return MT3_ERR_MISSING;
+    if ((rc = build_attention(e, P + "/attention", s1, false, &e->enc[l]))) return rc;
+    if ((rc = build_mlp(e, P + "/mlp", s2, &e->enc[l]))) return rc;
+  }
+  {
+    const HostWeight* w = find(e, "encoder/encoder_norm/scale", emb, -1);
+    if (!w) return MT3_ERR_MISSING;
+    if ((rc = upload_f32(e, w->data, &e->enc_norm))) return rc;
+  }
+  // ---- decoder
+  {
+    const HostWeight* w = find(e, "decoder/token_embedder/embedding", c.vocab_size, emb);
+    if (!w) return MT3_ERR_MISSING;
+    if ((rc = upload_f32(e, w->data, &e->embedding))) return rc;
+  }
+  e->dec.resize(c.num_decoder_layers);
+  for (int l = 0; l < c.num_decoder_layers; ++l) {
+    const std::string P = "decoder/layers_" + std::to_string(l);
+    const float* s1 = scale_of(e, P + "/pre_self_attention_layer_norm/scale");
+    const float* s2 = scale_of(e, P + "/pre_cross_attention_layer_norm/scale");
+    const float* s3 = scale_of(e, P + "/pre_mlp_layer_norm/scale");
+    if (!s1 || !s2 || !s3) return MT3_ERR_MISSING;
+    if ((rc = build_attention(e, P + "/self_attention", s1, false, &e->dec[l]))) return rc;
+    if ((rc = build_attention(e, P + "/encoder_decoder_attention", s2, true, &e->dec[l]))) return rc;
+    if ((rc = build_mlp(e, P + "/mlp", s3, &e->dec[l]))) return rc;
+    const size_t kvb = static_cast<size_t>(Bm) * c.num_heads * L * 64 * e->esize;
+    if ((rc = dmalloc(e, &e->dec[l].self_k, kvb))) return rc;
+    if ((rc = dmalloc(e, &e->dec[l].self_v, kvb))) return rc;
+    if ((rc = dmalloc(e, &e->dec[l].cross_kv, static_cast<size_t>(2) * Bm * c.num_heads * T * 64 * e->esize)))
+      return rc;
+  }
+  {
+    const float* sn = scale_of(e, "decoder/decoder_norm/scale");
+    const HostWeight* w = find(e, "decoder/logits_dense/kernel", emb, c.vocab_size);
+    if (!sn || !w) return MT3_ERR_MISSING;
+    std::vector<float> t(static_cast<size_t>(c.vocab_size) * emb);
+    put_transposed(t, emb, 0, *w, sn);
+    if ((rc = upload_ct(e, t, &e->logits_w))) return rc;
+  }
+  // ---- sinusoidal table (layers.py:51-82): [sin | cos] halves, scale = -ln(10000)/(emb/2 - 1)
+  {
+    std::vector<float> pe(static_cast<size_t>(kMaxPos) * emb);
+    const int half = emb / 2;
+    const double sf = -std::log(10000.0) / (half - 1);
+    for (int p = 0; p < kMaxPos; ++p)
+      for (int j = 0; j < half; ++j) {
+        const double div = std::exp(j * sf);
+        pe[static_cast<size_t>(p) * emb + j] = static_cast<float>(std::sin(p * div));
+        pe[static_cast<size_t>(p) * emb + half + j] = static_cast<float>(std::cos(p * div));
+      }
+    if ((rc = upload_f32(e, pe, &e->pos_table))) return rc;
+  }
+  // ---- workspaces
+  const size_t M = static_cast<size_t>(Bm) * T;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x), M * emb * 4))) return rc;
+  if ((rc = dmalloc(e, &e->qkv, M * 3 * hd * e->esize))) return rc;
+  if ((rc = dmalloc(e, &e->attn, M * hd * e->esize))) return rc;
+  if ((rc = dmalloc(e, &e->hbuf, M * c.mlp_dim * e->esize))) return rc;
+  if ((rc = dmalloc(e, &e->enc_out, M * emb * e->esize))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y), static_cast<size_t>(Bm) * emb * 4))) return rc;
+  if ((rc = dmalloc(e, &e->qkv_d, static_cast<size_t>(Bm) * 3 * hd * e->esize))) return rc;
+  if ((rc = dmalloc(e, &e->attn_d, static_cast<size_t>(Bm) * hd * e->esize))) return rc;
+  if ((rc = dmalloc(e, &e->q_d, static_cast<size_t>(Bm) * hd * e->esize))) return rc;
+  if ((rc = dmalloc(e, &e->h_d, static_cast<size_t>(Bm) * c.mlp_dim * e->esize))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->logits), static_cast<size_t>(Bm) * c.vocab_size * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->ids), static_cast<size_t>(Bm) * L * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->cur_tok), static_cast<size_t>(Bm) * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->done), static_cast<size_t>(Bm) * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->step), 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->n_done), 4))) return rc;
+  MT3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned), 64, hipHostMallocDefault));
+  e->raw.clear();
+  e->finalized = true;
+  return MT3_OK;
+}
+
+int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float* d_encoded_f32, void* stream) {
+  if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: engine not finalized");
+  if (!d_inputs || batch <= 0 || batch > e->cfg.max_batch)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: batch out of range");
+  const mt3_engine_config& c = e->cfg;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), T = c.input_length;
+  const int M = batch * T;
+  const bool small = M < 2048;
+  {
+    mt3k::GemmArgs g = gemm_args(d_inputs, e->enc_in, e->x, M, emb, c.input_depth, emb);
+    g.aux = e->pos_table;
+    g.seq_len = T;
+    MT3_TRY(mt3k::launch_gemm(dt, g, true, false, MT3_EPI_POS, small, s));
+  }
+  for (int l = 0; l < c.num_encoder_layers; ++l) {
+    LayerDev& L = e->enc[l];
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->x, L.wqkv, e->qkv, M, 3 * hd, emb, 3 * hd), true, true, MT3_EPI_STORE,
+                              small, s));
+    MT3_TRY(mt3k::launch_encoder_attention(dt, e->qkv, e->attn, batch, T, c.num_heads, s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->attn, L.wo, e->x, M, emb, hd, emb), false, false, MT3_EPI_RESID, small,
+                              s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->x, L.wi, e->hbuf, M, 2 * c.mlp_dim, emb, c.mlp_dim), true, true,
+                              MT3_EPI_GEGLU, small, s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->hbuf, L.wo_mlp, e->x, M, emb, c.mlp_dim, emb), false, false,
+                              MT3_EPI_RESID, small, s));
+  }
+  MT3_TRY(mt3k::launch_rmsnorm(dt, e->x, e->enc_norm, e->enc_out, d_encoded_f32, M, emb, s));
+  for (int l = 0; l < c.num_decoder_layers; ++l) {
+    mt3k::GemmArgs g = gemm_args(e->enc_out, e->dec[l].wkv_x, e->dec[l].cross_kv, M, 2 * hd, emb, 2 * hd);
+    g.seq_len = T;
+    MT3_TRY(mt3k::launch_gemm(dt, g, false, false, MT3_EPI_HEADS, small, s));
+  }
+  e->cur_batch = batch;
+  return MT3_OK;
+}
+
+int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t* d_ids,
+                      float* d_first_logits, int32_t* h_steps_run, void* stream) {
+  if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: engine not finalized");
+  if (batch <= 0 || batch != e->cur_batch)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: batch must equal the batch of the preceding encode");
+  const mt3_engine_config& c = e->cfg;
+  if (num_steps <= 0 || num_steps > c.max_decode_len || !d_ids)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: num_steps out of range or null ids");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int L = c.max_decode_len;
+  MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->n_done, 0, 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->done, 0, static_cast<size_t>(batch) * 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->cur_tok, 0, static_cast<size_t>(batch) * 4, s));     // BOS = 0
+  MT3_HIP_CHECK(hipMemsetAsync(e->ids, 0, static_cast<size_t>(batch) * L * 4, s));
+
+  bool use_graph = !(flags & MT3_DECODE_NO_GRAPH);
+  if (use_graph && ensure_graph(e, batch) != MT3_OK) use_graph = false;   // fall back to direct launches
+  int ran = 0;
+  for (int t = 0; t < num_steps; ++t) {
+    if (use_graph) MT3_HIP_CHECK(hipGraphLaunch(e->graph_exec, s));
+    else MT3_TRY(enqueue_decode_step(e, batch, s));
+    ++ran;
+    if (t == 0 && d_first_logits)
+      MT3_HIP_CHECK(hipMemcpyAsync(d_first_logits, e->logits, static_cast<size_t>(batch) * c.vocab_size * 4,
+                                   hipMemcpyDeviceToDevice, s));
+    if ((flags & MT3_DECODE_EARLY_EXIT) && (t % 32 == 31)) {
+      MT3_HIP_CHECK(hipMemcpyAsync(e->h_pinned, e->n_done, 4, hipMemcpyDeviceToHost, s));
+      MT3_HIP_CHECK(hipStreamSynchronize(s));
+      if (e->h_pinned[0] >= batch) break;
+    }
+  }
+  MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
+  if (h_steps_run) *h_steps_run = ran;
+  return MT3_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Host-side construction of the frontend's constant tables (window, twiddles,
+// HTK mel filterbank in dense and band-sparse form).  Plain C++ (no HIP), shared
+// by frontend.hip and the CPU emulation test.
+//
+// Mel matrix: tf.signal.linear_to_mel_weight_matrix(512, 1025, 16000, 20.0, 7600.0)
+// as called at mt3/spectral_ops.py:69-70 [TF op restated from its documentation]:
+// HTK mel m(f) = 1127 ln(1 + f/700); 514 band edges linspace'd in mel between
+// m(lo) and m(hi); weight[k][j] = max(0, min(lower slope, upper slope)) for linear
+// bins k >= 1, DC row zero.  Evaluated in double, stored as float.
+#ifndef MT3_FRONTEND_TABLES_H_
+#define MT3_FRONTEND_TABLES_H_
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace mt3fe {
+
+struct HostTables {
+  int fft = 2048, bins = 1025, mel = 512;
+  std::vector<float> hann;        // [fft] periodic Hann
+  std::vector<float> tw1024;      // [1024][2]  exp(-2 pi i j/1024)
+  std::vector<float> tw2048;      // [1025][2]  exp(-2 pi i j/2048)
+  std::vector<float> mel_dense;   // [bins][mel]
+  std::vector<int32_t> k0, cnt, off;   // per mel bin: first spectrum bin, count, offset into w
+  std::vector<float> w;           // band weights, concatenated per mel bin
+  int64_t nnz = 0;
+  int max_cnt = 0;
+};
+
+inline double hz_to_mel(double f) { return 1127.0 * std::log1p(f / 700.0); }
+
+inline HostTables build_tables(int sample_rate, int fft, int mel_bins, double lo_hz, double hi_hz) {
+  HostTables t;
+  t.fft = fft;
+  t.bins = fft / 2 + 1;
+  t.mel = mel_bins;
+  const double pi = 3.14159265358979323846;
+  t.hann.resize(fft);
+  for (int i = 0; i < fft; ++i) t.hann[i] = static_cast<float>(0.5 - 0.5 * std::cos(2.0 * pi * i / fft));
+  const int half = fft / 2;
+  t.tw1024.resize(2 * half);
+  for (int j = 0; j < half; ++j) {
+    t.tw1024[2 * j] = static_cast<float>(std::cos(2.0 * pi * j / half));
+    t.tw1024[2 * j + 1] = static_cast<float>(-std::sin(2.0 * pi * j / half));
+  }
+  t.tw2048.resize(2 * (half + 1));
+  for (int j = 0; j <= half; ++j) {
+    t.tw2048[2 * j] = static_cast<float>(std::cos(2.0 * pi * j / fft));
+    t.tw2048[2 * j + 1] = static_cast<float>(-std::sin(2.0 * pi * j / fft));
+  }
+  // dense mel matrix
+  const double nyquist = sample_rate / 2.0;
+  std::vector<double> edges(mel_bins + 2);
+  const double m_lo = hz_to_mel(lo_hz), m_hi = hz_to_mel(hi_hz);
+  for (int i = 0; i < mel_bins + 2; ++i) edges[i] = m_lo + (m_hi - m_lo) * i / (mel_bins + 1);
+  t.mel_dense.assign(static_cast<size_t>(t.bins) * mel_bins, 0.f);
+  for (int k = 1; k < t.bins; ++k) {
+    const double f = nyquist * k / (t.bins - 1);
+    const double m = hz_to_mel(f);
+    for (int j = 0; j < mel_bins; ++j) {
+      const double lower = (m - edges[j]) / (edges[j + 1] - edges[j]);
+      const double upper = (edges[j + 2] - m) / (edges[j + 2] - edges[j + 1]);
+      const double v = std::fmax(0.0, std::fmin(lower, upper));
+      t.mel_dense[static_cast<size_t>(k) * mel_bins + j] = static_cast<float>(v);
+    }
+  }
+  // band-sparse form: for each mel bin the contiguous run of spectrum bins with weight > 0
+  t.k0.assign(mel_bins, 0);
+  t.cnt.assign(mel_bins, 0);
+  t.off.assign(mel_bins, 0);
+  for (int j = 0; j < mel_bins; ++j) {
+    int first = -1, last = -1;
+    for (int k = 0; k < t.bins; ++k)
+      if (t.mel_dense[static_cast<size_t>(k) * mel_bins + j] != 0.f) {
+        if (first < 0) first = k;
+        last = k;
+      }
+    t.off[j] = static_cast<int32_t>(t.w.size());
+    if (first >= 0) {
+      t.k0[j] = first;
+      t.cnt[j] = last - first + 1;
+      for (int k = first; k <= last; ++k) {
+        const float v = t.mel_dense[static_cast<size_t>(k) * mel_bins + j];
+        t.w.push_back(v);
+        if (v != 0.f) ++t.nnz;
+      }
+      if (t.cnt[j] > t.max_cnt) t.max_cnt = t.cnt[j];
+    }
+  }
+  return t;
+}
+
+}  // namespace mt3fe
+#endif  // MT3_FRONTEND_TABLES_H_

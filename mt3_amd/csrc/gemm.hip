@@ -1,0 +1,279 @@
+// MFMA GEMM for the T5 blocks of the MT3 path on gfx950:  out = epilogue(rs(A) * (A @ Wt^T)).
+//
+// One kernel template covers every dense layer of mt3/network.py / mt3/layers.py
+// (`DenseGeneral`, layers.py:373-418, all bias-free):
+//   * A [M,K]: either the f32 residual stream (converted to the compute type while it is staged
+//     into LDS) or a compute-type activation;  Wt [N,K]: weight stored output-major so that both
+//     MFMA operands are K-contiguous 16-byte chunks.
+//   * NORM fuses T5 LayerNorm (layers.py:604-621 = RMSNorm, eps 1e-6) into the GEMM that consumes
+//     it: the learned scale is folded into Wt's columns at load time, and the per-row
+//     rsqrt(mean(x^2) + eps) is accumulated from the f32 A values as they stream through the
+//     K loop and applied in the epilogue -- no separate normalisation pass over HBM.
+//   * epilogues: STORE (compute type), RESID (f32 out += acc, the residual add of
+//     network.py:66,83,120,136,150), GEGLU (gelu(wi_0 x) * wi_1 x of layers.py:460-473 with the
+//     two weight matrices interleaved in 16-column groups so gate and linear land in the same
+//     lane), POS (+ sinusoidal table row, network.py:174-180), F32 (logits, network.py:256-261),
+//     HEADS (cross-attention K/V written head-major [2][B][H][T][64] for the decode kernel).
+// Tiling: workgroup tile BMxBN, WMxWN waves, each wave FMxFN 16x16 MFMA fragments, K step BK;
+// global -> register prefetch of tile t+1 overlaps the MFMAs of tile t; LDS rows padded by one
+// 16-byte chunk (conflict-free 16-lane fragment reads); XCD-aware block remap so that the
+// column tiles of one row panel share an L2.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "device.h"
+#include "kernels.h"
+
+namespace mt3k {
+
+// stage one K-slice of A (optionally f32 -> compute type, accumulating sum of squares for the fused
+// RMSNorm) and of Wt from global memory into registers
+template <typename CT, bool A_F32, bool NORM, int A_PASSES, int B_PASSES, int ROWS_PER_PASS>
+__device__ __forceinline__ void gemm_load_tiles(u32x4 (&a_reg)[A_PASSES], u32x4 (&b_reg)[B_PASSES],
+                                                float (&ss)[A_PASSES], const void* gA, const void* gW, int m0,
+                                                int n0, int ld_row, int ld_chunk, int gM, int gLda, int gK, int k0) {
+  constexpr int KPL = CTraits<CT>::KPL;
+#pragma unroll
+  for (int p = 0; p < A_PASSES; ++p) {
+    int row = m0 + ld_row + p * ROWS_PER_PASS;
+    row = row < gM ? row : gM - 1;                       // clamp: out-of-range rows are never stored
+    const size_t e = static_cast<size_t>(row) * gLda + k0 + ld_chunk * KPL;
+    if constexpr (A_F32) {
+      const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(gA) + e);
+      if constexpr (KPL == 8) {
+        const float4 u = src[0], v = src[1];
+        const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        if constexpr (NORM) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ss[p] += f[i] * f[i];
+        }
+        a_reg[p] = pack_bf16x8(f);
+      } else {
+        const float4 u = src[0];
+        if constexpr (NORM) ss[p] += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+        a_reg[p] = pack_f32x4(u.x, u.y, u.z, u.w);
+      }
+    } else {
+      a_reg[p] = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(gA) + e);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < B_PASSES; ++p) {
+    const int row = n0 + ld_row + p * ROWS_PER_PASS;       // N is a multiple of BN: always in range
+    const size_t e = static_cast<size_t>(row) * gK + k0 + ld_chunk * KPL;
+    b_reg[p] = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(gW) + e);
+  }
+}
+
+template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int KPL = CTraits<CT>::KPL;
+  constexpr int KG = CTraits<CT>::KGROUP;
+  constexpr int CPR = BK / KPL;          // 16-byte chunks per tile row
+  constexpr int ROWE = BK + KPL;         // LDS row length in elements (one pad chunk)
+  constexpr int FM = BM / (WM * 16), FN = BN / (WN * 16);
+  constexpr int A_PASSES = BM * CPR / NT, B_PASSES = BN * CPR / NT;
+  constexpr int ROWS_PER_PASS = NT / CPR;
+  static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile/threads mismatch");
+  static_assert(NT % CPR == 0 && (CPR & (CPR - 1)) == 0, "CPR must be a power of two dividing NT");
+  static_assert(BK % KG == 0, "BK must be a multiple of the MFMA K-group");
+  static_assert(!NORM || A_F32, "NORM needs the f32 A operand");
+  static_assert(EPI != MT3_EPI_GEGLU || (FN % 2 == 0), "GEGLU pairs fragments");
+
+  __shared__ __attribute__((aligned(16))) CT As[BM * ROWE];
+  __shared__ __attribute__((aligned(16))) CT Bs[BN * ROWE];
+  __shared__ float rs_s[BM];
+
+  // scalars out of the by-value argument struct (never take its address: that forces a private copy)
+  const void* const gA = g.A;
+  const void* const gW = g.Wt;
+  void* const gO = g.out;
+  const float* const gAux = g.aux;
+  const int gM = g.M, gN = g.N, gK = g.K, gLda = g.lda, gLdo = g.ldo, gSeq = g.seq_len;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = gN / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+
+  const int ld_row = tid / CPR, ld_chunk = tid % CPR;
+
+  u32x4 a_reg[A_PASSES], b_reg[B_PASSES];
+  float ss[A_PASSES];
+#pragma unroll
+  for (int p = 0; p < A_PASSES; ++p) ss[p] = 0.f;
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frag_row = lane & 15, frag_g = lane >> 4;
+  const CT* a_base = &As[(wm * FM * 16 + frag_row) * ROWE + frag_g * KPL];
+  const CT* b_base = &Bs[(wn * FN * 16 + frag_row) * ROWE + frag_g * KPL];
+
+  gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, ROWS_PER_PASS>(a_reg, b_reg, ss, gA, gW, m0, n0, ld_row, ld_chunk,
+                                                                      gM, gLda, gK, 0);
+  for (int k0 = 0; k0 < gK; k0 += BK) {
+    __syncthreads();                    // every wave is done reading the previous tile
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p)
+      *reinterpret_cast<u32x4*>(&As[(ld_row + p * ROWS_PER_PASS) * ROWE + ld_chunk * KPL]) = a_reg[p];
+#pragma unroll
+    for (int p = 0; p < B_PASSES; ++p)
+      *reinterpret_cast<u32x4*>(&Bs[(ld_row + p * ROWS_PER_PASS) * ROWE + ld_chunk * KPL]) = b_reg[p];
+    __syncthreads();
+    if (k0 + BK < gK)                   // next slice in flight while the MFMAs below run
+      gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, ROWS_PER_PASS>(a_reg, b_reg, ss, gA, gW, m0, n0, ld_row,
+                                                                          ld_chunk, gM, gLda, gK, k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / KG; ++kk) {
+      u32x4 af[FM], bf[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(a_base + i * 16 * ROWE + kk * KG);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(b_base + j * 16 * ROWE + kk * KG);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) mfma_chunk<CT>(af[i], bf[j], acc[i][j]);
+    }
+  }
+
+  if constexpr (NORM) {
+    // each tile row was streamed by CPR consecutive lanes: finish mean(x^2) and publish rsqrt
+#pragma unroll
+    for (int p = 0; p < A_PASSES; ++p) {
+      float s = ss[p];
+#pragma unroll
+      for (int o = CPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (ld_chunk == 0) rs_s[ld_row + p * ROWS_PER_PASS] = rsqrtf(s / static_cast<float>(gK) + 1e-6f);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C fragment (i, j): rows (lane>>4)*4 + r, col lane & 15
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int lrow = wm * FM * 16 + i * 16 + frag_g * 4 + r;
+      const int row = m0 + lrow;
+      if (row >= gM) continue;
+      const float rs = NORM ? rs_s[lrow] : 1.f;
+      if constexpr (EPI == MT3_EPI_GEGLU) {
+        CT* out = static_cast<CT*>(gO);
+#pragma unroll
+        for (int j = 0; j < FN; j += 2) {
+          const int col = n0 + wn * FN * 16 + j * 16;                  // multiple of 32
+          const float gate = acc[i][j][r] * rs, lin = acc[i][j + 1][r] * rs;
+          out[static_cast<size_t>(row) * gLdo + (col >> 1) + frag_row] = to_ct<CT>(gelu_tanh(gate) * lin);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int col = n0 + wn * FN * 16 + j * 16 + frag_row;
+          const float v = acc[i][j][r] * rs;
+          if constexpr (EPI == MT3_EPI_STORE) {
+            static_cast<CT*>(gO)[static_cast<size_t>(row) * gLdo + col] = to_ct<CT>(v);
+          } else if constexpr (EPI == MT3_EPI_RESID) {
+            float* o = static_cast<float*>(gO) + static_cast<size_t>(row) * gLdo + col;
+            *o = *o + v;
+          } else if constexpr (EPI == MT3_EPI_POS) {
+            static_cast<float*>(gO)[static_cast<size_t>(row) * gLdo + col] =
+                v + gAux[static_cast<size_t>(row % gSeq) * gN + col];
+          } else if constexpr (EPI == MT3_EPI_F32) {
+            static_cast<float*>(gO)[static_cast<size_t>(row) * gLdo + col] = v;
+          } else {  // MT3_EPI_HEADS: col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
+            const int hd = gN >> 1;                       // H * 64
+            const int kv = col / hd, h = (col % hd) >> 6, d = col & 63;
+            const int b = row / gSeq, t = row % gSeq, H = hd >> 6, B = gM / gSeq;
+            const size_t dst = ((((static_cast<size_t>(kv) * B + b) * H + h) * gSeq) + t) * 64 + d;
+            static_cast<CT*>(gO)[dst] = to_ct<CT>(v);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ dispatch
+template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI>
+static int launch_cfg(const GemmArgs& g, hipStream_t s) {
+  if (g.N % BN != 0 || g.K % BK != 0) return mt3::fail(MT3_ERR_INVALID, "gemm: N/K not a multiple of the tile");
+  const int grid = ((g.M + BM - 1) / BM) * (g.N / BN);
+  hipLaunchKernelGGL((gemm_kernel<CT, BM, BN, BK, WM, WN, A_F32, NORM, EPI>), dim3(grid), dim3(WM * WN * 64), 0, s,
+                     g);
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+
+template <typename CT, bool A_F32, bool NORM, int EPI>
+static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
+  constexpr int KG = CTraits<CT>::KGROUP;
+  if (small) return launch_cfg<CT, 64, 64, 2 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
+  return launch_cfg<CT, 128, 128, KG, 2, 2, A_F32, NORM, EPI>(g, s);
+}
+
+template <typename CT>
+static int launch_typed(const GemmArgs& g, bool a_f32, bool norm, int epi, bool small, hipStream_t s) {
+  // Only the combinations the engine uses are instantiated.
+  if (norm) {
+    if (!a_f32) return mt3::fail(MT3_ERR_INVALID, "gemm: norm requires an f32 A operand");
+    switch (epi) {
+      case MT3_EPI_STORE: return launch_tile<CT, true, true, MT3_EPI_STORE>(g, small, s);
+      case MT3_EPI_GEGLU: return launch_tile<CT, true, true, MT3_EPI_GEGLU>(g, small, s);
+      case MT3_EPI_F32: return launch_tile<CT, true, true, MT3_EPI_F32>(g, small, s);
+      default: break;
+    }
+  } else if (a_f32) {
+    switch (epi) {
+      case MT3_EPI_POS: return launch_tile<CT, true, false, MT3_EPI_POS>(g, small, s);
+      case MT3_EPI_F32: return launch_tile<CT, true, false, MT3_EPI_F32>(g, small, s);
+      case MT3_EPI_STORE: return launch_tile<CT, true, false, MT3_EPI_STORE>(g, small, s);
+      default: break;
+    }
+  } else {
+    switch (epi) {
+      case MT3_EPI_RESID: return launch_tile<CT, false, false, MT3_EPI_RESID>(g, small, s);
+      case MT3_EPI_HEADS: return launch_tile<CT, false, false, MT3_EPI_HEADS>(g, small, s);
+      case MT3_EPI_STORE: return launch_tile<CT, false, false, MT3_EPI_STORE>(g, small, s);
+      case MT3_EPI_F32: return launch_tile<CT, false, false, MT3_EPI_F32>(g, small, s);
+      default: break;
+    }
+  }
+  return mt3::fail(MT3_ERR_INVALID, "gemm: unsupported (a_is_f32, norm, epilogue) combination");
+}
+
+int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, bool norm, int epi, bool small, hipStream_t s) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.Wt || !g.out)
+    return mt3::fail(MT3_ERR_INVALID, "gemm: bad shape or null pointer");
+  if (epi == MT3_EPI_POS && (!g.aux || g.seq_len <= 0)) return mt3::fail(MT3_ERR_INVALID, "gemm: POS needs aux/seq_len");
+  if (epi == MT3_EPI_HEADS && (g.seq_len <= 0 || g.M % g.seq_len != 0 || g.N % 128 != 0))
+    return mt3::fail(MT3_ERR_INVALID, "gemm: HEADS needs M = B*T and N = 2*H*64");
+  if (dtype == MT3_BF16) return launch_typed<__bf16>(g, a_f32, norm, epi, small, s);
+  if (dtype == MT3_F32) return launch_typed<float>(g, a_f32, norm, epi, small, s);
+  return mt3::fail(MT3_ERR_INVALID, "gemm: unknown dtype");
+}
+
+}  // namespace mt3k
+
+extern "C" int mt3_op_gemm(int32_t dtype, const void* d_A, int32_t a_is_f32, int32_t norm, const void* d_Wt,
+                           void* d_out, int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* d_aux,
+                           int32_t seq_len, int32_t small, void* stream) {
+  mt3k::GemmArgs g{};
+  g.A = d_A;
+  g.Wt = d_Wt;
+  g.out = d_out;
+  g.aux = d_aux;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = K;
+  g.ldo = epilogue == MT3_EPI_GEGLU ? N / 2 : N;
+  g.seq_len = seq_len;
+  return mt3k::launch_gemm(dtype, g, a_is_f32 != 0, norm != 0, epilogue, small != 0, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,56 @@
+// Internal launcher interface between the engine (engine.hip) and the kernel files.
+#ifndef MT3_KERNELS_H_
+#define MT3_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mt3_hip.h"
+
+namespace mt3k {
+
+struct GemmArgs {
+  const void* A;      // [M, lda]  f32 or compute type
+  const void* Wt;     // [N, K]    compute type
+  void* out;          // see epilogue
+  const float* aux;   // EPI_POS: positional table [seq_len, N]
+  int M, N, K;
+  int lda, ldo;
+  int seq_len;        // EPI_POS / EPI_HEADS: rows per batch item
+};
+
+int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, bool norm, int epi, bool small, hipStream_t s);
+
+// encoder self-attention, qkv [B, T, 3, H, 64] -> out [B, T, H*64]
+int launch_encoder_attention(int dtype, const void* qkv, void* out, int B, int T, int H, hipStream_t s);
+
+struct DecAttnArgs {
+  const void* q;        // [B, q_stride] compute type; head h at +h*64
+  int q_stride;
+  void* kcache;         // [B, H, cap, 64]
+  void* vcache;
+  int cap;
+  const void* new_k;    // [B, kv_stride] rows; head h at +h*64 (NULL: no append)
+  const void* new_v;
+  int kv_stride;
+  const int* step;      // device: n_keys = *step + 1 (NULL: use n_keys)
+  int n_keys;
+  void* out;            // [B, H*64] compute type
+  int B, H;
+};
+int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s);
+
+// out_ct[row] = x[row] * rsqrt(mean(x^2)+eps) * scale ; optional f32 copy
+int launch_rmsnorm(int dtype, const float* x, const float* scale, void* out_ct, float* out_f32, int rows, int dim,
+                   hipStream_t s);
+// y[b] = table[tok[b]] + pos[*step]
+int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, int B, int dim,
+                 hipStream_t s);
+// greedy pick + bookkeeping for one decode step (see decode_ops.hip)
+int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
+                       int* n_done, const int* step, int B, hipStream_t s);
+int launch_advance_step(int* step, hipStream_t s);
+int launch_ids_to_tokens(const int* ids, int B, int L, int num_regular, int* out, hipStream_t s);
+
+}  // namespace mt3k
+#endif  // MT3_KERNELS_H_
