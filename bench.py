@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- audio-seconds transcribed per second on MI355X (BASELINE.json's metric).
+
+One "step" = one full pass of the hot path over one batch of synthetic 16 kHz segments that are
+already resident in HBM:  log-mel frontend -> T5 encoder -> cross-K/V -> 1024-step greedy decode
+(hipGraph replay per step, NO early exit: random weights never emit EOS reliably)
+-> ids->tokens kernel -> (N>1: RCCL all-gather of the int32 token rows) -> host run-length /
+note decoding of every row (C++ in libmt3hip.so).
+
+Workload at N=1: BASELINE.json configs[2] ("MT3-base full encoder-decoder greedy decode, batch=256
+synthetic segments, 1xMI355X with hipGraph") -- the largest single-GPU configuration and the only
+one that *transcribes* (configs[1] is encoder-only and would leave the decoder out of the timed
+region).  Scaling is weak: every rank processes `--batch` segments.
+
+Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
+         python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+                --master-port P bench.py --gpus N --steps K --warmup W
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+SEG_SECONDS = 2.048          # 256 frames * 128 hop / 16 kHz  (mt3.gin:4, spectrograms.py:23-24)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(n_segments: int, decode_steps: int):
+    """The oracle (CPU restatement of the reference path: numpy frontend + torch-CPU f32 network +
+    pure-Python note decoding) timed on this box's host cores on a bounded sample."""
+    import numpy as np
+    import torch
+    from mt3_amd import network
+    from oracle import frontend as OF, network as ON, symbolic as OS
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = network.T5Config(dtype="float32")
+    params = network.init_random_params(cfg, seed=0)
+    audio = OF.synth_audio(n_segments, seed=0)
+    orc = ON.Oracle(params, ON.T5Config())
+    t0 = time.perf_counter()
+    lm = np.stack([OF.compute_logmel(a, np.float32) for a in audio])
+    enc = orc.encode(lm)
+    ids = orc.greedy_decode(enc, decode_steps)
+    vocab = OS.GenericTokenVocabulary(1388, extra_ids=100)
+    toks = vocab.decode_tf(ids)
+    codec = OS.build_codec(OS.VocabularyConfig(num_velocity_bins=1))
+    preds = [{"est_tokens": OS.trim_eos(t), "start_time": OS.floor_start_time(i * SEG_SECONDS, 100)}
+             for i, t in enumerate(toks)]
+    OS.event_predictions_to_ns(preds, codec, "ties")
+    dt = time.perf_counter() - t0
+    return {"value": n_segments * SEG_SECONDS / dt, "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": "%d segments (%.1f s of audio), same path: log-mel + encoder + %d greedy steps + note "
+                      "decoding; oracle restatement (numpy/torch-CPU f32), not JAX; %.1f s wall"
+                      % (n_segments, n_segments * SEG_SECONDS, decode_steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="segments per GPU per step (c3: 256)")
+    ap.add_argument("--decode-steps", type=int, default=1024)
+    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-segments", type=int, default=4)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from mt3_amd import metrics_utils, network, note_sequences, spectrograms, synthetic, vocabularies
+
+    B, L = args.batch, 1024
+    cfg = network.T5Config(dtype=args.dtype)
+    eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B)
+    eng.load_params(network.init_random_params(cfg, seed=0))
+    codec = vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1))
+    vocab = vocabularies.vocabulary_from_codec(codec)
+    audio = synthetic.synth_audio(B, seed=1000 + rank)                    # [B, 32768] f32 in HBM
+    stream = torch.cuda.Stream()                                          # a real (capturable) stream
+    start_times = [s * SEG_SECONDS - (s * SEG_SECONDS) % 0.01 for s in range(B * world)]
+
+    def step():
+        with torch.cuda.stream(stream):
+            logmel = spectrograms.compute_spectrogram_batch(audio, None)
+            eng.encode(logmel)
+            ids = eng.decode(num_steps=args.decode_steps)
+            tokens = vocab.decode_tf(ids)                                  # CUDA int32 [B, L]
+            if world > 1:
+                gathered = torch.empty((world * B, L), device="cuda", dtype=torch.int32)
+                dist.all_gather_into_tensor(gathered, tokens)
+                tokens = gathered
+            if rank == 0:
+                host = tokens.cpu().numpy()                                # syncs the stream
+                rows = []
+                for r in host:
+                    hit = np.flatnonzero(r == vocabularies.DECODED_EOS_ID)
+                    rows.append(r[: hit[0]] if hit.size else r)
+                ns, inv, drop = metrics_utils._run(codec, note_sequences.NoteEncodingWithTiesSpec.spec_id, rows,
+                                                   start_times)
+                return len(ns.notes)
+        return 0
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_notes = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- roofline of the dominant kernel (decode self-attention, HBM streaming of the K/V cache):
+    # HIP events around every launch of that kernel inside a real decode pass of the same workload
+    roof = None
+    if rank == 0:
+        with torch.cuda.stream(stream):
+            logmel = spectrograms.compute_spectrogram_batch(audio, None)
+            eng.encode(logmel)
+            eng.decode(num_steps=args.decode_steps, profile=True)
+        torch.cuda.synchronize()
+        p = eng.decode_profile()
+        ach = p["self_bytes"] / (p["self_ms"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "dec_attn_kernel<bf16,APPEND> (decode self-attention over the K/V cache)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_us": p["self_ms"] * 1e3 / max(p["self_launches"], 1),
+                "algorithmic_bytes_per_launch": p["self_bytes"] / max(p["self_launches"], 1),
+                "launches": int(p["self_launches"]),
+                "cross_attn": {"achieved": p["cross_bytes"] / (p["cross_ms"] * 1e-3) / 1e9,
+                               "avg_launch_us": p["cross_ms"] * 1e3 / max(p["cross_launches"], 1)},
+                "decode_direct_launch_ms": p["decode_ms"]}
+
+    if rank == 0:
+        segs = B * world * args.steps
+        value = segs * SEG_SECONDS / dt
+        out = {
+            "metric": "audio-seconds transcribed/sec (whole node), MT3-base, 1/2/4/8 MI355X",
+            "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: MT3 (model.gin) random-init, full encoder-decoder greedy "
+                                   "decode, batch=%d synthetic 2.048 s segments per GPU, %d decode steps (no early "
+                                   "exit), hipGraph step replay, ids->tokens + host note decoding included"
+                                   % (B, args.decode_steps),
+                       "segments_per_gpu": B, "decode_steps": args.decode_steps, "segment_seconds": SEG_SECONDS,
+                       "parallelism": "dp%d (segments sharded, weights replicated, RCCL all-gather of token rows)"
+                                      % world if world > 1 else "single GPU",
+                       "notes_decoded_last_step": n_notes},
+            "segments_per_s": segs / dt,
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_segments, args.decode_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

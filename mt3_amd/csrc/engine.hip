@@ -100,6 +100,14 @@ struct mt3_engine {
   int* n_done = nullptr;
   int* h_pinned = nullptr;
 
+  // MT3_DECODE_PROFILE: HIP events around every decode-attention launch (direct launches, one sync per step)
+  std::vector<hipEvent_t> prof_ev;   // [2 kinds][layers][start, stop]
+  bool prof_on = false;
+  double prof_ms[2] = {0.0, 0.0};
+  double prof_bytes[2] = {0.0, 0.0};
+  double prof_launches[2] = {0.0, 0.0};
+  double prof_total_ms = 0.0;
+
   int cur_batch = 0;             // batch of the last encode
   hipStream_t cap_stream = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -261,7 +269,9 @@ int enqueue_decode_step(mt3_engine* e, int B, hipStream_t s) {
     a.out = e->attn_d;
     a.B = B;
     a.H = H;
+    if (e->prof_on) MT3_HIP_CHECK(hipEventRecord(e->prof_ev[(0 * c.num_decoder_layers + l) * 2], s));
     MT3_TRY(mt3k::launch_decode_attention(dt, a, s));
+    if (e->prof_on) MT3_HIP_CHECK(hipEventRecord(e->prof_ev[(0 * c.num_decoder_layers + l) * 2 + 1], s));
     MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->attn_d, L.wo, e->y, B, emb, hd, emb), false, false, MT3_EPI_RESID,
                               small, s));
     MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, L.wq_x, e->q_d, B, hd, emb, hd), true, true, MT3_EPI_STORE, small,
@@ -276,7 +286,9 @@ int enqueue_decode_step(mt3_engine* e, int B, hipStream_t s) {
     x.out = e->attn_d;
     x.B = B;
     x.H = H;
+    if (e->prof_on) MT3_HIP_CHECK(hipEventRecord(e->prof_ev[(1 * c.num_decoder_layers + l) * 2], s));
     MT3_TRY(mt3k::launch_decode_attention(dt, x, s));
+    if (e->prof_on) MT3_HIP_CHECK(hipEventRecord(e->prof_ev[(1 * c.num_decoder_layers + l) * 2 + 1], s));
     MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->attn_d, L.wo_x, e->y, B, emb, hd, emb), false, false, MT3_EPI_RESID,
                               small, s));
     MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, L.wi, e->h_d, B, 2 * c.mlp_dim, emb, c.mlp_dim), true, true,
@@ -352,6 +364,7 @@ void mt3_engine_destroy(mt3_engine* e) {
   if (!e) return;
   drop_graph(e);
   if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+  for (auto& ev : e->prof_ev) (void)hipEventDestroy(ev);
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
@@ -374,6 +387,17 @@ int mt3_engine_load_weight(mt3_engine* e, const char* name, const float* h_data,
 }
 
 int64_t mt3_engine_device_bytes(const mt3_engine* e) { return e ? e->device_bytes : 0; }
+
+int mt3_engine_profile(const mt3_engine* e, double* out7) {
+  if (!e || !out7) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_profile: null argument");
+  for (int k = 0; k < 2; ++k) {
+    out7[3 * k] = e->prof_ms[k];
+    out7[3 * k + 1] = e->prof_launches[k];
+    out7[3 * k + 2] = e->prof_bytes[k];
+  }
+  out7[6] = e->prof_total_ms;
+  return MT3_OK;
+}
 
 int mt3_engine_finalize(mt3_engine* e) {
   if (!e) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_finalize: null engine");
@@ -524,13 +548,44 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
   MT3_HIP_CHECK(hipMemsetAsync(e->cur_tok, 0, static_cast<size_t>(batch) * 4, s));     // BOS = 0
   MT3_HIP_CHECK(hipMemsetAsync(e->ids, 0, static_cast<size_t>(batch) * L * 4, s));
 
-  bool use_graph = !(flags & MT3_DECODE_NO_GRAPH);
+  const bool profile = (flags & MT3_DECODE_PROFILE) != 0;
+  bool use_graph = !(flags & MT3_DECODE_NO_GRAPH) && !profile;
   if (use_graph && ensure_graph(e, batch) != MT3_OK) use_graph = false;   // fall back to direct launches
+  const int nl = c.num_decoder_layers;
+  hipEvent_t ev_all[2] = {nullptr, nullptr};
+  if (profile) {
+    if (e->prof_ev.empty()) {
+      e->prof_ev.resize(static_cast<size_t>(2) * nl * 2);
+      for (auto& ev : e->prof_ev) MT3_HIP_CHECK(hipEventCreate(&ev));
+    }
+    for (int k = 0; k < 2; ++k) e->prof_ms[k] = e->prof_bytes[k] = e->prof_launches[k] = 0.0;
+    MT3_HIP_CHECK(hipEventCreate(&ev_all[0]));
+    MT3_HIP_CHECK(hipEventCreate(&ev_all[1]));
+    MT3_HIP_CHECK(hipEventRecord(ev_all[0], s));
+    e->prof_on = true;
+  }
   int ran = 0;
   for (int t = 0; t < num_steps; ++t) {
     if (use_graph) MT3_HIP_CHECK(hipGraphLaunch(e->graph_exec, s));
-    else MT3_TRY(enqueue_decode_step(e, batch, s));
+    else {
+      const int rc = enqueue_decode_step(e, batch, s);
+      if (rc != MT3_OK) { e->prof_on = false; return rc; }
+    }
     ++ran;
+    if (profile) {
+      MT3_HIP_CHECK(hipStreamSynchronize(s));
+      const double kv = 2.0 * batch * c.num_heads * 64 * e->esize;          // K+V bytes per key position
+      for (int k = 0; k < 2; ++k)
+        for (int l = 0; l < nl; ++l) {
+          float ms = 0.f;
+          MT3_HIP_CHECK(hipEventElapsedTime(&ms, e->prof_ev[(k * nl + l) * 2], e->prof_ev[(k * nl + l) * 2 + 1]));
+          e->prof_ms[k] += ms;
+          e->prof_launches[k] += 1.0;
+          // algorithmic bytes of the launch: the K/V rows it must read (+ q in, out; new row write for self)
+          e->prof_bytes[k] += kv * (k == 0 ? (t + 1) : c.input_length) + 2.0 * batch * c.num_heads * 64 * e->esize +
+                              (k == 0 ? kv : 0.0);
+        }
+    }
     if (t == 0 && d_first_logits)
       MT3_HIP_CHECK(hipMemcpyAsync(d_first_logits, e->logits, static_cast<size_t>(batch) * c.vocab_size * 4,
                                    hipMemcpyDeviceToDevice, s));
@@ -539,6 +594,16 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
       MT3_HIP_CHECK(hipStreamSynchronize(s));
       if (e->h_pinned[0] >= batch) break;
     }
+  }
+  if (profile) {
+    e->prof_on = false;
+    MT3_HIP_CHECK(hipEventRecord(ev_all[1], s));
+    MT3_HIP_CHECK(hipEventSynchronize(ev_all[1]));
+    float ms = 0.f;
+    MT3_HIP_CHECK(hipEventElapsedTime(&ms, ev_all[0], ev_all[1]));
+    e->prof_total_ms = ms;
+    (void)hipEventDestroy(ev_all[0]);
+    (void)hipEventDestroy(ev_all[1]);
   }
   MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
   if (h_steps_run) *h_steps_run = ran;

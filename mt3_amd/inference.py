@@ -1,0 +1,215 @@
+"""Drop-in inference surface of MT3 on the MI355X engine.
+
+`InferenceModel` mirrors the class the reference defines in its Colab notebook
+(mt3/colab/music_transcription_with_transformers.ipynb, cell "Imports and
+Definitions"): same constructor arguments, attributes (`inputs_length`,
+`outputs_length`, `batch_size`, `sequence_length`, `encoding_spec`,
+`spectrogram_config`, `codec`, `vocabulary`, `input_shapes`) and methods
+(`restore_from_checkpoint`, `predict_tokens`, `__call__`, `audio_to_dataset`,
+`preprocess`, `postprocess`, `_trim_eos`).  `write_inferences_to_file` mirrors
+mt3/inference.py:34-138 (the t5x `infer` write_fn).
+
+Differences that are deliberate: the t5x/gin/tf.data plumbing is gone -- segments
+are cut and padded on the host exactly as the reference's preprocessors do
+(`_audio_to_frames`, split into `inputs_length`-frame chunks, zero rows after the
+log for a short last segment), everything numeric runs in libmt3hip.so, and decode
+is greedy-until-EOS (the reference runs t5x beam search with beam size 1).
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Any, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import metrics_utils
+from . import network
+from . import note_sequences
+from . import spectrograms
+from . import vocabularies
+
+SAMPLE_RATE = 16000
+
+
+def trim_eos(tokens: Sequence[int]) -> np.ndarray:
+    """tasks.trim_eos (mt3/tasks.py:58-63) == InferenceModel._trim_eos."""
+    tokens = np.array(tokens, np.int32)
+    if vocabularies.DECODED_EOS_ID in tokens:
+        tokens = tokens[: np.argmax(tokens == vocabularies.DECODED_EOS_ID)]
+    return tokens
+
+
+class InferenceModel(object):
+    """Wrapper of the MI355X engine for music transcription."""
+
+    def __init__(self, checkpoint_path, model_type="mt3", *, config: Optional[network.T5Config] = None,
+                 dtype: str = "bfloat16", batch_size: int = 8, early_exit: bool = True):
+        if model_type == "ismir2021":
+            num_velocity_bins = 127
+            self.encoding_spec = note_sequences.NoteEncodingSpec
+            self.inputs_length = 512
+        elif model_type == "mt3":
+            num_velocity_bins = 1
+            self.encoding_spec = note_sequences.NoteEncodingWithTiesSpec
+            self.inputs_length = 256
+        else:
+            raise ValueError("unknown model_type: %s" % model_type)
+
+        self.batch_size = batch_size             # reference default 8; bigger batches fill the GPU
+        self.outputs_length = 1024
+        self.sequence_length = {"inputs": self.inputs_length, "targets": self.outputs_length}
+        self.early_exit = early_exit
+
+        self.spectrogram_config = spectrograms.SpectrogramConfig()
+        self.codec = vocabularies.build_codec(
+            vocab_config=vocabularies.VocabularyConfig(num_velocity_bins=num_velocity_bins))
+        self.vocabulary = vocabularies.vocabulary_from_codec(self.codec)
+        self.output_features = {"inputs": None, "targets": self.vocabulary}
+
+        base = config or network.T5Config()
+        self.model_config = network.T5Config(**{
+            **{f: getattr(base, f) for f in base.__dataclass_fields__},
+            "vocab_size": vocabularies.num_embeddings(self.vocabulary), "dtype": dtype,
+            "input_depth": spectrograms.input_depth(self.spectrogram_config)})
+        self.model = network.Transformer(self.model_config, input_length=self.inputs_length,
+                                         max_decode_length=self.outputs_length, max_batch=self.batch_size)
+        self.restore_from_checkpoint(checkpoint_path)
+
+    @property
+    def input_shapes(self):
+        return {"encoder_input_tokens": (self.batch_size, self.inputs_length),
+                "decoder_input_tokens": (self.batch_size, self.outputs_length)}
+
+    def restore_from_checkpoint(self, checkpoint_path):
+        """Weights: a flat `.npz` (names = the reference's Flax tree joined by '/'), a dict of arrays,
+        or 'random:<seed>' / None for the reference's initialisers (no checkpoint ships with the
+        repo; reading t5x's native TensorStore format is the N1 follow-up in DESIGN.md)."""
+        if isinstance(checkpoint_path, dict):
+            params = checkpoint_path
+        elif checkpoint_path is None or str(checkpoint_path).startswith("random"):
+            seed = int(str(checkpoint_path).split(":")[1]) if checkpoint_path and ":" in str(checkpoint_path) else 0
+            params = network.init_random_params(self.model_config, seed=seed)
+        elif str(checkpoint_path).endswith(".npz") and os.path.exists(str(checkpoint_path)):
+            with np.load(str(checkpoint_path)) as z:
+                params = {k: z[k] for k in z.files}
+        else:
+            raise ValueError("unsupported checkpoint %r: pass a flat .npz, a dict, or 'random:<seed>'"
+                             % (checkpoint_path,))
+        self.model.load_params(params)
+
+    # ------------------------------------------------------------------ model call
+    def predict_tokens(self, batch: Dict[str, Any], seed: int = 0) -> np.ndarray:
+        """batch['encoder_input_tokens']: f32 [B, T, 512] (numpy or CUDA tensor) -> int32 [B, 1024]
+        with -1 from EOS on and -2 for invalid ids (vocabulary.decode_tf)."""
+        import torch
+        x = batch["encoder_input_tokens"]
+        x = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x, np.float32))
+        out = []
+        for s in range(0, x.shape[0], self.batch_size):
+            self.model.encode(x[s:s + self.batch_size].cuda())
+            ids = self.model.decode(early_exit=self.early_exit)
+            out.append(self.vocabulary.decode_tf(ids))
+        return torch.cat(out, 0).cpu().numpy()
+
+    def __call__(self, audio):
+        """1-d numpy array of 16 kHz samples -> NoteSequence."""
+        ds = self.audio_to_dataset(audio)
+        examples = self.preprocess(ds)
+        T = self.inputs_length
+        feats = np.zeros((len(examples), T, self.spectrogram_config.num_mel_bins), np.float32)
+        for i, ex in enumerate(examples):              # feature converter: pad/trim to [T, 512]
+            feats[i, : ex["inputs"].shape[0]] = ex["inputs"][:T]
+        tokens = self.predict_tokens({"encoder_input_tokens": feats})
+        predictions = [self.postprocess(t, ex) for t, ex in zip(tokens, examples)]
+        result = metrics_utils.event_predictions_to_ns(predictions, codec=self.codec,
+                                                       encoding_spec=self.encoding_spec)
+        return result["est_ns"]
+
+    # ------------------------------------------------------------------ host preprocessing
+    def audio_to_dataset(self, audio):
+        frames, frame_times = self._audio_to_frames(audio)
+        return {"inputs": frames, "input_times": frame_times}
+
+    def _audio_to_frames(self, audio):
+        frame_size = self.spectrogram_config.hop_width
+        audio = np.asarray(audio)
+        padding = [0, frame_size - len(audio) % frame_size]      # always pads (a full hop if aligned)
+        audio = np.pad(audio, padding, mode="constant")
+        frames = spectrograms.split_audio(audio, self.spectrogram_config)
+        num_frames = len(audio) // frame_size
+        times = np.arange(num_frames) / self.spectrogram_config.frames_per_second
+        return frames, times
+
+    def preprocess(self, ds) -> List[Dict[str, Any]]:
+        """split_tokens_to_inputs_length + add_dummy_targets + compute_spectrograms
+        (preprocessors.py:53-57,613-618), batched over all segments in one kernel launch."""
+        import torch
+        frames, times = ds["inputs"], ds["input_times"]
+        T, hop = self.inputs_length, self.spectrogram_config.hop_width
+        n_seg = -(-len(frames) // T)
+        audio = np.zeros((n_seg, T * hop), np.float32)
+        counts = []
+        for s in range(n_seg):
+            chunk = frames[s * T:(s + 1) * T]
+            audio[s, : chunk.size] = chunk.reshape(-1)
+            counts.append(len(chunk))
+        logmel = spectrograms.compute_spectrogram_batch(torch.from_numpy(audio).cuda(), counts,
+                                                        self.spectrogram_config).cpu().numpy()
+        return [{"inputs": logmel[s, : counts[s]], "input_times": times[s * T:(s + 1) * T],
+                 "raw_inputs": audio[s, : counts[s] * hop], "targets": np.zeros((0,), np.int32)}
+                for s in range(n_seg)]
+
+    def postprocess(self, tokens, example):
+        tokens = self._trim_eos(tokens)
+        start_time = example["input_times"][0]
+        start_time -= start_time % (1 / self.codec.steps_per_second)   # float64, as in the notebook
+        return {"est_tokens": tokens, "start_time": start_time, "raw_inputs": []}
+
+    @staticmethod
+    def _trim_eos(tokens):
+        return trim_eos(tokens)
+
+
+def write_inferences_to_file(path: str, inferences: Sequence[Any], task_ds, mode: str, vocabulary=None,
+                             vocab_config=None, onsets_only=None, use_ties=None) -> None:
+    """mt3/inference.py:34-138: one JSON line {"id", "est_notes": [...]} per track.
+    `task_ds`: iterable of dicts with 'input_times', 'unique_id' (and optionally 'raw_inputs');
+    `inferences`: one int32 id row per example (model ids, before decode_tf)."""
+    if mode == "score":
+        raise ValueError("`score` mode currently not supported in MT3")
+    if not vocabulary:
+        raise ValueError("`vocabulary` parameter required in `predict` mode")
+    if vocab_config is None or onsets_only is None or use_ties is None:
+        raise ValueError("vocab_config, onsets_only and use_ties are required")
+    if onsets_only and use_ties:
+        raise ValueError("ties not compatible with onset-only transcription")
+    if onsets_only:
+        encoding_spec = note_sequences.NoteOnsetEncodingSpec
+    elif not use_ties:
+        encoding_spec = note_sequences.NoteEncodingSpec
+    else:
+        encoding_spec = note_sequences.NoteEncodingWithTiesSpec
+    codec = vocabularies.build_codec(vocab_config)
+
+    def first(x):
+        x = np.asarray(x)
+        return x.reshape(-1)[0] if x.ndim else x[()]
+
+    predictions = []
+    for inp, output in zip(task_ds, inferences):
+        tokens = trim_eos(vocabulary.decode_tf(np.asarray(output, np.int32)))
+        start_time = float(first(inp["input_times"]))
+        start_time -= start_time % (1 / codec.steps_per_second)
+        uid = first(inp["unique_id"])
+        predictions.append({"unique_id": uid.decode() if isinstance(uid, bytes) else str(uid),
+                            "est_tokens": tokens, "start_time": start_time,
+                            "raw_inputs": inp.get("raw_inputs", [])})
+    full = metrics_utils.combine_predictions_by_id(
+        predictions, lambda preds: metrics_utils.event_predictions_to_ns(preds, codec=codec,
+                                                                         encoding_spec=encoding_spec))
+    with open(path, "w") as f:
+        for uid in sorted(full.keys()):
+            notes = [{"start_time": n.start_time, "end_time": n.end_time, "pitch": n.pitch, "velocity": n.velocity,
+                      "program": n.program, "is_drum": n.is_drum} for n in full[uid]["est_ns"].notes]
+            f.write(json.dumps({"id": uid, "est_notes": notes}) + "\n")

@@ -1,0 +1,185 @@
+"""Encoder-decoder engine wrapper (mirror of mt3/network.py's public surface).
+
+`T5Config` keeps the reference's field names (network.py:25-41; values of
+mt3/gin/model.gin:47-59 as defaults).  `Transformer` owns one `mt3_engine` of
+libmt3hip.so: `encode()` = network.Transformer.encode (network.py:275-301) plus the
+hoisted cross-attention K/V; `decode()` = the cached greedy loop that t5x runs
+around network.Transformer.decode (network.py:303-361).  Device memory for inputs
+and outputs is plain torch CUDA tensors; all compute is in the library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+import math
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+@dataclasses.dataclass(frozen=True)
+class T5Config:
+    vocab_size: int = 1536
+    dtype: str = "bfloat16"          # MFMA operand type: 'bfloat16' (product) or 'float32' (parity path)
+    emb_dim: int = 512
+    num_heads: int = 6
+    num_encoder_layers: int = 8
+    num_decoder_layers: int = 8
+    head_dim: int = 64
+    mlp_dim: int = 1024
+    mlp_activations: Sequence[str] = ("gelu", "linear")
+    dropout_rate: float = 0.1        # unused at inference
+    logits_via_embedding: bool = False
+    input_depth: int = 512           # spectrograms.input_depth
+
+
+MT3_SMALL = T5Config()                                           # model.gin / ismir2022/small.gin
+MT3_BASE = T5Config(emb_dim=768, num_heads=12, num_encoder_layers=12, num_decoder_layers=12,
+                    mlp_dim=2048)                                # ismir2022/base.gin:4-10
+
+
+def param_shapes(cfg: T5Config) -> Dict[str, tuple]:
+    """Flax parameter tree of network.Transformer flattened with '/' (SURVEY.md A.3)."""
+    e, hd, f, v = cfg.emb_dim, cfg.num_heads * cfg.head_dim, cfg.mlp_dim, cfg.vocab_size
+    s = {"encoder/continuous_inputs_projection/kernel": (cfg.input_depth, e),
+         "encoder/encoder_norm/scale": (e,),
+         "decoder/token_embedder/embedding": (v, e),
+         "decoder/decoder_norm/scale": (e,),
+         "decoder/logits_dense/kernel": (e, v)}
+
+    def attn(p):
+        for n in ("query", "key", "value"):
+            s[f"{p}/{n}/kernel"] = (e, hd)
+        s[f"{p}/out/kernel"] = (hd, e)
+
+    def mlp(p):
+        s[f"{p}/wi_0/kernel"] = (e, f)
+        s[f"{p}/wi_1/kernel"] = (e, f)
+        s[f"{p}/wo/kernel"] = (f, e)
+
+    for i in range(cfg.num_encoder_layers):
+        p = f"encoder/layers_{i}"
+        s[f"{p}/pre_attention_layer_norm/scale"] = (e,)
+        attn(f"{p}/attention")
+        s[f"{p}/pre_mlp_layer_norm/scale"] = (e,)
+        mlp(f"{p}/mlp")
+    for i in range(cfg.num_decoder_layers):
+        p = f"decoder/layers_{i}"
+        s[f"{p}/pre_self_attention_layer_norm/scale"] = (e,)
+        attn(f"{p}/self_attention")
+        s[f"{p}/pre_cross_attention_layer_norm/scale"] = (e,)
+        attn(f"{p}/encoder_decoder_attention")
+        s[f"{p}/pre_mlp_layer_norm/scale"] = (e,)
+        mlp(f"{p}/mlp")
+    return s
+
+
+def init_random_params(cfg: T5Config, seed: int = 0, norm_scale_jitter: float = 0.0) -> Dict[str, np.ndarray]:
+    """Random-init weights with the reference's initialisers:
+    embedding N(0,1) (network.py:221); attention kernels N(0, 1/fan_in), query / sqrt(head_dim)
+    (layers.py:177-178,230-234); MLP / logits / input projection truncated-normal fan-in
+    (layers.py:384-385, flax lecun_normal); norm scales 1 (optionally jittered for tests so that
+    the scale-folding is exercised)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, shape in param_shapes(cfg).items():
+        if name.endswith("/scale"):
+            w = torch.ones(shape)
+            if norm_scale_jitter:
+                w = w + norm_scale_jitter * torch.randn(shape, generator=g)
+        elif name.endswith("/embedding"):
+            w = torch.randn(shape, generator=g)
+        else:
+            fan_in = shape[0]
+            std = math.sqrt(1.0 / fan_in)
+            if "/attention/" in name or "_attention/" in name:
+                w = torch.randn(shape, generator=g) * std
+                if name.endswith("query/kernel"):
+                    w = w / math.sqrt(cfg.head_dim)
+            else:
+                w = torch.empty(shape)
+                torch.nn.init.trunc_normal_(w, mean=0.0, std=1.0, a=-2.0, b=2.0, generator=g)
+                w = w * (std / 0.87962566103423978)
+        out[name] = w.numpy().astype(np.float32)
+    return out
+
+
+class Transformer:
+    """One engine per (device, stream)."""
+
+    def __init__(self, config: T5Config, input_length: int = 256, max_decode_length: int = 1024,
+                 max_batch: int = 8):
+        self.config = config
+        self.input_length, self.max_decode_length, self.max_batch = input_length, max_decode_length, max_batch
+        if config.dtype not in ("bfloat16", "float32"):
+            raise ValueError("T5Config.dtype must be 'bfloat16' or 'float32'")
+        self._lib = _lib.load()
+        ec = _lib.EngineConfig(config.vocab_size, config.emb_dim, config.num_heads, config.head_dim, config.mlp_dim,
+                               config.num_encoder_layers, config.num_decoder_layers, config.input_depth,
+                               input_length, max_decode_length, max_batch,
+                               _lib.MT3_BF16 if config.dtype == "bfloat16" else _lib.MT3_F32)
+        h = C.c_void_p()
+        _lib.check(self._lib.mt3_engine_create(C.byref(ec), C.byref(h)))
+        self._h = h
+        self._loaded = False
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.mt3_engine_destroy(h)
+
+    def load_params(self, params: Dict[str, np.ndarray]):
+        """`params`: flat dict in the reference's names/orientation (f32)."""
+        for name, arr in params.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            _lib.check(self._lib.mt3_engine_load_weight(self._h, name.encode(), a.ctypes.data, shape, a.ndim))
+        _lib.check(self._lib.mt3_engine_finalize(self._h))
+        self._loaded = True
+
+    @property
+    def device_bytes(self) -> int:
+        return int(self._lib.mt3_engine_device_bytes(self._h))
+
+    def encode(self, encoder_input_tokens, return_encoded: bool = False):
+        """encoder_input_tokens: CUDA f32 tensor [B, T, input_depth]."""
+        import torch
+        x = encoder_input_tokens
+        if x.dim() != 3 or x.shape[1] != self.input_length or x.shape[2] != self.config.input_depth:
+            raise ValueError(f"expected [B, {self.input_length}, {self.config.input_depth}], got {tuple(x.shape)}")
+        x = x.to(device="cuda", dtype=torch.float32).contiguous()
+        enc = torch.empty((x.shape[0], x.shape[1], self.config.emb_dim), device="cuda", dtype=torch.float32) \
+            if return_encoded else None
+        _lib.check(self._lib.mt3_engine_encode(self._h, x.data_ptr(), x.shape[0], enc.data_ptr() if enc is not None
+                                               else None, torch.cuda.current_stream().cuda_stream))
+        self._batch = x.shape[0]
+        return enc
+
+    def decode(self, num_steps: Optional[int] = None, use_graph: bool = True, early_exit: bool = False,
+               return_first_logits: bool = False, profile: bool = False):
+        """Greedy decode for the batch of the last `encode`.  Returns int32 CUDA [B, L] ids
+        (and the step-0 logits [B, V] if asked)."""
+        import torch
+        B, L = self._batch, self.max_decode_length
+        ids = torch.empty((B, L), device="cuda", dtype=torch.int32)
+        logits = torch.empty((B, self.config.vocab_size), device="cuda", dtype=torch.float32) \
+            if return_first_logits else None
+        flags = (0 if use_graph else _lib.DECODE_NO_GRAPH) | (_lib.DECODE_EARLY_EXIT if early_exit else 0) | \
+            (_lib.DECODE_PROFILE if profile else 0)
+        ran = C.c_int32()
+        _lib.check(self._lib.mt3_engine_decode(self._h, B, num_steps or L, flags, ids.data_ptr(),
+                                               logits.data_ptr() if logits is not None else None, C.byref(ran),
+                                               torch.cuda.current_stream().cuda_stream))
+        self.steps_run = ran.value
+        return (ids, logits) if return_first_logits else ids
+
+    def decode_profile(self) -> Dict[str, float]:
+        """Timers of the last `decode(profile=True)`: per decode-attention kind the summed HIP-event
+        time, launch count and algorithmic bytes; plus the whole (direct-launch) decode time."""
+        out = (C.c_double * 7)()
+        _lib.check(self._lib.mt3_engine_profile(self._h, out))
+        return {"self_ms": out[0], "self_launches": out[1], "self_bytes": out[2], "cross_ms": out[3],
+                "cross_launches": out[4], "cross_bytes": out[5], "decode_ms": out[6]}

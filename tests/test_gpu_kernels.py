@@ -1,0 +1,275 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (libmt3hip.so).
+
+Each HIP kernel is compared with a float64 evaluation of the same operation on the
+same (already rounded) inputs; tolerances are stated next to each check.  Integer
+kernels are bit-exact against the oracle.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from mt3_amd import _lib  # noqa: E402
+
+BF16, F32 = _lib.MT3_BF16, _lib.MT3_F32
+
+
+def lib():
+    return _lib.load()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def tdt(dtype):
+    return torch.bfloat16 if dtype == BF16 else torch.float32
+
+
+def rel_err(got, ref):
+    got, ref = got.double(), ref.double()
+    return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+
+def gelu_tanh(x):
+    return 0.5 * x * (1 + torch.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3)))
+
+
+# ----------------------------------------------------------------------------- GEMM
+def run_gemm(dtype, A, a_f32, norm, Wt, out, M, N, K, epi, aux=None, seq_len=0, small=False):
+    _lib.check(lib().mt3_op_gemm(dtype, A.data_ptr(), int(a_f32), int(norm), Wt.data_ptr(), out.data_ptr(), M, N, K,
+                                 epi, aux.data_ptr() if aux is not None else None, seq_len, int(small), stream()))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("small", [False, True])
+@pytest.mark.parametrize("M,N,K", [(256, 384, 512), (200, 1152, 512), (777, 512, 1024), (3, 128, 384)])
+def test_gemm_store_and_resid(dtype, small, M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    ct = tdt(dtype)
+    A = torch.randn(M, K, device="cuda", generator=g).to(ct)
+    Wt = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(ct)
+    ref = A.double() @ Wt.double().T
+    out = torch.zeros(M, N, device="cuda", dtype=ct)
+    run_gemm(dtype, A, False, False, Wt, out, M, N, K, _lib.EPI_STORE, small=small)
+    tol = 6e-3 if dtype == BF16 else 2e-5          # bf16: output rounding 2^-9; f32: accumulation order
+    assert rel_err(out, ref) < tol, f"STORE rel err {rel_err(out, ref)}"
+    # asymmetric inputs make a transposed C-write fail loudly:
+    assert (out.double() - ref).abs().max() < 0.05 * ref.abs().max() + 1e-3
+    res0 = torch.randn(M, N, device="cuda", generator=g)
+    res = res0.clone()
+    run_gemm(dtype, A, False, False, Wt, res, M, N, K, _lib.EPI_RESID, small=small)
+    assert rel_err(res, res0.double() + ref) < 2e-5, "RESID"
+    o32 = torch.zeros(M, N, device="cuda")
+    run_gemm(dtype, A, False, False, Wt, o32, M, N, K, _lib.EPI_F32, small=small)
+    assert rel_err(o32, ref) < 2e-5, "F32"
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("small", [False, True])
+def test_gemm_norm_fused(dtype, small):
+    M, N, K = 300, 1152, 512
+    g = torch.Generator(device="cuda").manual_seed(5)
+    ct = tdt(dtype)
+    x = torch.randn(M, K, device="cuda", generator=g) * (1 + 3 * torch.rand(M, 1, device="cuda", generator=g))
+    Wt = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(ct)
+    rs = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-6)
+    ref = (x.to(ct).double() @ Wt.double().T) * rs            # the kernel rounds x to CT, then scales in f32
+    out = torch.zeros(M, N, device="cuda", dtype=ct)
+    run_gemm(dtype, x, True, True, Wt, out, M, N, K, _lib.EPI_STORE, small=small)
+    assert rel_err(out, ref) < (6e-3 if dtype == BF16 else 2e-5)
+    o32 = torch.zeros(M, N, device="cuda")
+    run_gemm(dtype, x, True, True, Wt, o32, M, N, K, _lib.EPI_F32, small=small)
+    assert rel_err(o32, ref) < 2e-5
+    # and against the un-rounded math (what the reference computes in f32): bf16 input rounding only
+    true = (x.double() @ Wt.double().T) * rs
+    assert rel_err(o32, true) < (8e-3 if dtype == BF16 else 2e-5)
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("small", [False, True])
+def test_gemm_geglu(dtype, small):
+    M, K, F = 130, 512, 1024
+    g = torch.Generator(device="cuda").manual_seed(9)
+    ct = tdt(dtype)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w0 = (torch.randn(K, F, device="cuda", generator=g) / math.sqrt(K)).to(ct)
+    w1 = (torch.randn(K, F, device="cuda", generator=g) / math.sqrt(K)).to(ct)
+    # interleave in 16-row groups: rows [32q,32q+16) = gate cols 16q.., rows [32q+16,32q+32) = linear cols 16q..
+    Wt = torch.empty(2 * F, K, device="cuda", dtype=ct)
+    Wt.view(F // 16, 2, 16, K)[:, 0] = w0.T.reshape(F // 16, 16, K)
+    Wt.view(F // 16, 2, 16, K)[:, 1] = w1.T.reshape(F // 16, 16, K)
+    rs = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-6)
+    xr = x.to(ct).double()
+    ref = gelu_tanh((xr @ w0.double()) * rs) * ((xr @ w1.double()) * rs)
+    out = torch.zeros(M, F, device="cuda", dtype=ct)
+    run_gemm(dtype, x, True, True, Wt, out, M, 2 * F, K, _lib.EPI_GEGLU, small=small)
+    assert rel_err(out, ref) < (8e-3 if dtype == BF16 else 3e-5), f"GEGLU rel err {rel_err(out, ref)}"
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_gemm_pos_and_heads(dtype):
+    B, T, K, N = 3, 256, 512, 512
+    M = B * T
+    g = torch.Generator(device="cuda").manual_seed(11)
+    ct = tdt(dtype)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    Wt = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(ct)
+    pos = torch.randn(T, N, device="cuda", generator=g)
+    out = torch.zeros(M, N, device="cuda")
+    run_gemm(dtype, x, True, False, Wt, out, M, N, K, _lib.EPI_POS, aux=pos, seq_len=T)
+    ref = x.to(ct).double() @ Wt.double().T + pos.double().repeat(B, 1)
+    assert rel_err(out, ref) < 2e-5
+    # HEADS: N = 2*H*64 -> [2][B][H][T][64]
+    H = 6
+    N2 = 2 * H * 64
+    A = torch.randn(M, K, device="cuda", generator=g).to(ct)
+    W2 = (torch.randn(N2, K, device="cuda", generator=g) / math.sqrt(K)).to(ct)
+    o2 = torch.zeros(2, B, H, T, 64, device="cuda", dtype=ct)
+    run_gemm(dtype, A, False, False, W2, o2, M, N2, K, _lib.EPI_HEADS, seq_len=T)
+    r2 = (A.double() @ W2.double().T).view(B, T, 2, H, 64).permute(2, 0, 3, 1, 4)
+    assert rel_err(o2, r2) < (6e-3 if dtype == BF16 else 2e-5)
+
+
+# ------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("dtype,T", [(BF16, 256), (BF16, 512), (F32, 256)])
+def test_encoder_attention(dtype, T):
+    B, H = 2, 6
+    g = torch.Generator(device="cuda").manual_seed(T)
+    ct = tdt(dtype)
+    qkv = torch.randn(B, T, 3, H, 64, device="cuda", generator=g)
+    qkv[:, :, 0] *= 0.35                                   # unscaled logits: keep softmax non-degenerate
+    qkv = qkv.to(ct)
+    out = torch.zeros(B, T, H * 64, device="cuda", dtype=ct)
+    _lib.check(lib().mt3_op_encoder_attention(dtype, qkv.data_ptr(), out.data_ptr(), B, T, H, stream()))
+    torch.cuda.synchronize()
+    q, k, v = (qkv[:, :, i].double() for i in range(3))
+    w = torch.softmax(torch.einsum("bqhd,bkhd->bhqk", q, k), -1)        # no 1/sqrt(d): layers.py:230-234
+    ref = torch.einsum("bhqk,bkhd->bqhd", w, v).reshape(B, T, H * 64)
+    # bf16: P is rounded to bf16 before P.V (rel 2^-9) and the output is stored in bf16
+    assert rel_err(out, ref) < (1e-2 if dtype == BF16 else 3e-5), f"rel err {rel_err(out, ref)}"
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+@pytest.mark.parametrize("n_keys", [1, 2, 31, 257, 1024])
+def test_decode_attention_append(dtype, n_keys):
+    B, H, cap = 5, 6, 1024
+    g = torch.Generator(device="cuda").manual_seed(n_keys)
+    ct = tdt(dtype)
+    kc = torch.randn(B, H, cap, 64, device="cuda", generator=g).to(ct)
+    vc = torch.randn(B, H, cap, 64, device="cuda", generator=g).to(ct)
+    qkv = torch.randn(B, 3 * H * 64, device="cuda", generator=g)
+    qkv[:, : H * 64] *= 0.35
+    qkv = qkv.to(ct)
+    step = torch.tensor([n_keys - 1], device="cuda", dtype=torch.int32)
+    out = torch.zeros(B, H * 64, device="cuda", dtype=ct)
+    kc0, vc0 = kc.clone(), vc.clone()
+    es = qkv.element_size()
+    _lib.check(lib().mt3_op_decode_attention(dtype, qkv.data_ptr(), 3 * H * 64, kc.data_ptr(), vc.data_ptr(), cap,
+                                             qkv.data_ptr() + H * 64 * es, qkv.data_ptr() + 2 * H * 64 * es,
+                                             3 * H * 64, step.data_ptr(), 0, out.data_ptr(), B, H, stream()))
+    torch.cuda.synchronize()
+    q = qkv[:, : H * 64].view(B, H, 64).double()
+    kn = qkv[:, H * 64: 2 * H * 64].view(B, H, 64)
+    vn = qkv[:, 2 * H * 64:].view(B, H, 64)
+    K = kc0.clone()
+    V = vc0.clone()
+    K[:, :, n_keys - 1] = kn
+    V[:, :, n_keys - 1] = vn
+    # the cache must now hold the new row, everything else untouched (bit-exact)
+    assert torch.equal(kc, K) and torch.equal(vc, V)
+    w = torch.softmax(torch.einsum("bhd,bhkd->bhk", q, K[:, :, :n_keys].double()), -1)
+    ref = torch.einsum("bhk,bhkd->bhd", w, V[:, :, :n_keys].double()).reshape(B, H * 64)
+    assert rel_err(out, ref) < (5e-3 if dtype == BF16 else 2e-5), f"rel err {rel_err(out, ref)}"
+
+
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_decode_attention_cross(dtype):
+    B, H, T = 4, 6, 256
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ct = tdt(dtype)
+    kv = torch.randn(2, B, H, T, 64, device="cuda", generator=g).to(ct)
+    q = (torch.randn(B, H * 64, device="cuda", generator=g) * 0.35).to(ct)
+    out = torch.zeros(B, H * 64, device="cuda", dtype=ct)
+    _lib.check(lib().mt3_op_decode_attention(dtype, q.data_ptr(), H * 64, kv[0].data_ptr(), kv[1].data_ptr(), T,
+                                             None, None, 0, None, T, out.data_ptr(), B, H, stream()))
+    torch.cuda.synchronize()
+    w = torch.softmax(torch.einsum("bhd,bhkd->bhk", q.view(B, H, 64).double(), kv[0].double()), -1)
+    ref = torch.einsum("bhk,bhkd->bhd", w, kv[1].double()).reshape(B, H * 64)
+    assert rel_err(out, ref) < (5e-3 if dtype == BF16 else 2e-5)
+
+
+# ------------------------------------------------------------------ ids -> tokens
+def test_ids_to_tokens_bit_exact():
+    from oracle import symbolic as S
+    rng = np.random.default_rng(0)
+    L = 1024
+    rows = [rng.integers(0, 1536, L), np.zeros(L), np.ones(L), rng.integers(3, 1391, L), rng.integers(0, 3000, L)]
+    r = rng.integers(3, 1391, L)
+    r[1023] = 1
+    rows.append(r)
+    r = rng.integers(3, 1391, L)
+    r[0] = 1
+    rows.append(r)
+    ids = np.stack(rows).astype(np.int32)
+    vocab = S.GenericTokenVocabulary(1388, extra_ids=100)
+    ref = vocab.decode_tf(ids)
+    d = torch.from_numpy(ids).cuda()
+    out = torch.empty_like(d)
+    _lib.check(lib().mt3_ids_to_tokens(d.data_ptr(), ids.shape[0], L, 1388, out.data_ptr(), stream()))
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    # reference literals (vocabularies_test.py:64-83) through the Python mirror
+    from mt3_amd import vocabularies as V
+    v4 = V.GenericTokenVocabulary(32, extra_ids=4)
+    np.testing.assert_array_equal(v4.decode_tf(np.array([0, 2, 3, 4, 34, 35])), [-2, -2, 0, 1, 31, -2])
+    v = V.GenericTokenVocabulary(32)
+    np.testing.assert_array_equal(v.decode_tf(np.array([0, 2, 3, 4, 1, 0, 1, 0])), [-2, -2, 0, 1, -1, -1, -1, -1])
+    assert v.decode([0, 2, 3, 4, 1, 0, 1, 0]) == [-2, -2, 0, 1, -1]
+    assert v.decode_tf(np.array([3, 4], np.int64)).dtype == np.int64
+
+
+# ----------------------------------------------------------------------- frontend
+def test_frontend_vs_oracle():
+    from oracle import frontend as F
+    from mt3_amd import spectrograms as SP
+    audio = F.synth_audio(6, seed=0)
+    rng = np.random.default_rng(1)
+    audio[4] = rng.uniform(-1, 1, 32768).astype(np.float32)      # white noise: no empty-energy bins
+    audio[5] = 0.0                                               # silence: every bin must be log(1e-5)
+    n_frames = [256, 256, 100, 1, 256, 256]
+    out = SP.compute_spectrogram_batch(torch.from_numpy(audio).cuda(), n_frames).cpu().numpy()
+    # mel matrix the kernel was built from == oracle's (f64 -> f32)
+    np.testing.assert_array_equal(SP.mel_matrix(), F.mel_weight_matrix().astype(np.float32))
+    for s, n in enumerate(n_frames):
+        ref = F.compute_logmel(audio[s][: n * 128], np.float64)             # [n, 512]
+        assert ref.shape == (n, 512)
+        got = out[s]
+        assert np.all(got[n:] == 0.0), "pad rows must be exactly 0.0 (not log(eps))"
+        frames = F.frame_signal(audio[s][: n * 128].astype(np.float64)) * F.hann_periodic()
+        peak = np.abs(np.fft.rfft(frames, axis=-1)).max(1)                   # per-frame spectral peak
+        mel_ref, mel_got = np.exp(ref), np.exp(got[:n].astype(np.float64))
+        # f32 FFT noise floor scales with the frame's peak magnitude: linear-domain bound
+        lin = np.abs(mel_got - mel_ref)
+        assert np.all(lin <= 4e-6 * peak[:, None] + 1.1e-5 * 1e-5 + 1e-12), f"seg {s}: lin err {lin.max()}"
+        # where a bin carries signal (>= 1e-3 of the frame peak) the log itself is tight
+        sig = mel_ref >= 1e-3 * np.maximum(peak[:, None], 1e-30)
+        if sig.any():
+            assert np.abs(got[:n] - ref)[sig].max() < 1e-3
+        # the two structurally empty mel columns are exactly log(1e-5)
+        assert np.all(got[:n, [1, 10]] == np.float32(np.log(np.float32(1e-5))))
+    assert np.all(out[5] == np.float32(np.log(np.float32(1e-5))))
+    # linearity property at full size: scaling the audio by 2 adds log 2 to every signal-carrying bin
+    big = F.synth_audio(8, seed=3)
+    a = SP.compute_spectrogram_batch(torch.from_numpy(big).cuda(), None)
+    b = SP.compute_spectrogram_batch(torch.from_numpy(big * 2).cuda(), None)
+    mask = a > -4.0
+    assert float(((b - a)[mask] - math.log(2.0)).abs().max()) < 2e-3
+    # single-segment reference-signature entry point
+    one = SP.compute_spectrogram(audio[0][: 100 * 128])
+    np.testing.assert_array_equal(one, SP.compute_spectrogram_batch(torch.from_numpy(audio[:1]).cuda(), [100])
+                                  .cpu().numpy()[0, :100])
