@@ -87,7 +87,7 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from mt3_amd import metrics_utils, network, note_sequences, spectrograms, synthetic, vocabularies
+    from mt3_amd import distributed, metrics_utils, network, note_sequences, spectrograms, synthetic, vocabularies
 
     B, L = args.batch, 1024
     cfg = network.T5Config(dtype=args.dtype)
@@ -105,10 +105,7 @@ def main():
             eng.encode(logmel)
             ids = eng.decode(num_steps=args.decode_steps)
             tokens = vocab.decode_tf(ids)                                  # CUDA int32 [B, L]
-            if world > 1:
-                gathered = torch.empty((world * B, L), device="cuda", dtype=torch.int32)
-                dist.all_gather_into_tensor(gathered, tokens)
-                tokens = gathered
+            tokens = distributed.gather_token_rows(tokens, world * B)   # RCCL all-gather (identity at N=1)
             if rank == 0:
                 host = tokens.cpu().numpy()                                # syncs the stream
                 rows = []

@@ -1,0 +1,50 @@
+"""Multi-GPU sharding of the MT3 path: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" on CPU for tests).
+
+Segments are independent units (the reference itself only shards the batch axis:
+PartitionSpec('data',) in the notebook's `_get_predict_fn`), so weights are replicated, each rank
+takes a contiguous slice of the global segment list, and the ONLY collective is one all-gather of
+the decoded int32 token rows before host run-length decoding.  The payload is tiny
+(B x 1024 x 4 bytes per rank), i.e. latency-bound, so a single flat all-gather is used.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) slice of rank `rank`; sizes differ by at most one."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_token_rows(tokens, n_items: int = None):
+    """All-gather per-rank token rows [n_local, L] (int32 tensor, CUDA or CPU) into the global
+    [n_items, L] tensor ordered by `shard_range`.  Ragged shards are padded to the largest shard for
+    the collective and trimmed afterwards.  Without an initialised process group: identity."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return tokens
+    world = dist.get_world_size()
+    n_local = torch.tensor([tokens.shape[0]], device=tokens.device, dtype=torch.int64)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    if tokens.shape[0] < m:
+        pad = torch.zeros((m - tokens.shape[0], tokens.shape[1]), device=tokens.device, dtype=tokens.dtype)
+        tokens = torch.cat([tokens, pad], 0)
+    out = torch.empty((world * m, tokens.shape[1]), device=tokens.device, dtype=tokens.dtype)
+    if tokens.is_cuda:
+        dist.all_gather_into_tensor(out, tokens.contiguous())
+    else:
+        parts = [torch.empty_like(tokens) for _ in range(world)]
+        dist.all_gather(parts, tokens.contiguous())
+        out = torch.cat(parts, 0)
+    rows = [out[r * m: r * m + counts[r]] for r in range(world)]
+    res = torch.cat(rows, 0)
+    if n_items is not None and res.shape[0] != n_items:
+        raise RuntimeError("gathered %d rows, expected %d" % (res.shape[0], n_items))
+    return res

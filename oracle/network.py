@@ -70,6 +70,16 @@ def attention(q, k, v, bias=None):
     return torch.einsum("bhqk,bkhd->bqhd", w, v)
 
 
+def mlp_block(x: torch.Tensor, wi: List[torch.Tensor], wo: torch.Tensor, activations=("gelu", "linear")):
+    """layers.py:435-486 MlpBlock: product over `activations` of act_i(x @ wi_i), then @ wo."""
+    acts = {"relu": torch.relu, "linear": lambda t: t, "gelu": lambda t: F.gelu(t, approximate="tanh")}
+    h = None
+    for name, w in zip(activations, wi):
+        t = acts[name](x @ w)
+        h = t if h is None else h * t
+    return h @ wo
+
+
 class Oracle:
     def __init__(self, params: Dict[str, np.ndarray], cfg: T5Config, dtype=torch.float32):
         self.cfg = cfg

@@ -1,0 +1,67 @@
+"""The C-ABI library on a box without a GPU: it loads, exports every symbol include/mt3_hip.h
+declares, reports errors through return codes (never a CPU fallback), and the package layout keeps
+the oracle out of the product."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from mt3_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported_and_typed():
+    header = open(os.path.join(ROOT, "include", "mt3_hip.h")).read()
+    declared = set(re.findall(r"\b(mt3_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mt3_status"}
+    lib = _lib.load()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in mt3_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert lib.mt3_abi_version() == 1
+
+
+def test_argument_errors_are_reported_not_swallowed():
+    lib = _lib.load()
+    h = C.c_void_p()
+    bad = _lib.FrontendConfig(16000, 160, 512, 2048, 20.0, 7600.0)            # unsupported hop
+    assert lib.mt3_frontend_create(C.byref(bad), C.byref(h)) == _lib.MT3_ERR_INVALID
+    assert b"hop_width" in lib.mt3_last_error()
+    cfg = _lib.EngineConfig(1536, 512, 6, 32, 1024, 8, 8, 512, 256, 1024, 8, _lib.MT3_BF16)   # head_dim 32
+    assert lib.mt3_engine_create(C.byref(cfg), C.byref(h)) == _lib.MT3_ERR_INVALID
+    with pytest.raises(_lib.Mt3Error):
+        _lib.check(lib.mt3_ids_to_tokens(None, 1, 1, 1, None, None))
+
+
+@pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure_not_cpu_fallback():
+    """Without a device the engine cannot finalize: MT3_ERR_HIP, never a silent CPU path."""
+    import numpy as np
+    from mt3_amd import network
+    cfg = network.T5Config(num_encoder_layers=1, num_decoder_layers=1)
+    eng = network.Transformer(cfg, max_batch=1)
+    with pytest.raises(_lib.Mt3Error) as ei:
+        eng.load_params(network.init_random_params(cfg))
+    assert ei.value.code == _lib.MT3_ERR_HIP
+
+
+def test_missing_weight_is_an_error():
+    lib = _lib.load()
+    cfg = _lib.EngineConfig(1536, 512, 6, 64, 1024, 1, 1, 512, 256, 1024, 1, _lib.MT3_BF16)
+    h = C.c_void_p()
+    assert lib.mt3_engine_create(C.byref(cfg), C.byref(h)) == 0
+    rc = lib.mt3_engine_finalize(h)
+    assert rc in (_lib.MT3_ERR_MISSING, _lib.MT3_ERR_HIP)
+    lib.mt3_engine_destroy(h)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "mt3_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+                assert "oracle/" not in src or f.endswith(".py") is False or "oracle/" not in src.split('"""')[0]
