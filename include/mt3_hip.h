@@ -120,14 +120,17 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch,
  * are zero-filled).  d_first_logits: [batch, vocab] f32 logits of step 0, or NULL.
  * With MT3_DECODE_EARLY_EXIT the host polls a device flag every 32 steps and
  * stops once every row has emitted EOS (this synchronises the stream). */
-enum { MT3_DECODE_NO_GRAPH = 1, MT3_DECODE_EARLY_EXIT = 2, MT3_DECODE_PROFILE = 4 };
+enum {
+  MT3_DECODE_NO_GRAPH = 1,
+  MT3_DECODE_EARLY_EXIT = 2,
+  /* profiling only: drop the self / cross decode-attention launches from every step (output invalid);
+   * (full decode time) - (time without the kernel) = in-situ time of that kernel, measured with two
+   * HIP events around the whole graph-replayed decode instead of 8192 per-launch event pairs */
+  MT3_DECODE_SKIP_SELF_ATTN = 8,
+  MT3_DECODE_SKIP_CROSS_ATTN = 16
+};
 int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags,
                       int32_t* d_ids, float* d_first_logits, int32_t* h_steps_run, void* stream);
-
-/* After a decode with MT3_DECODE_PROFILE (direct launches, HIP events around every decode-attention
- * launch on `stream`, one sync per step): out7 = {self_attn_ms, self_attn_launches, self_attn_algorithmic_bytes,
- * cross_attn_ms, cross_attn_launches, cross_attn_algorithmic_bytes, whole_decode_ms}. */
-int mt3_engine_profile(const mt3_engine* e, double* out7);
 
 /* GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271): -1 from the
  * first EOS(1) to the end of the row, id-3 for 3 <= id < 3+num_regular, else -2. */

@@ -7,7 +7,8 @@
 //                       + FixedEmbed decode slice pos[t] (layers.py:589-596).
 //   argmax_step_kernel  greedy pick of the step (lowest id on ties), EOS bookkeeping, writes
 //                       ids[b][t]; rows that already emitted EOS get 0 (pad).
-//   advance_step_kernel t += 1 in device memory, so ONE captured hipGraph serves every step.
+//                       The last block to arrive also does t += 1 in device memory, so ONE captured
+//                       hipGraph serves every step.
 //   ids_to_tokens_kernel GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271), bit-exact.
 #include <hip/hip_runtime.h>
 
@@ -84,7 +85,7 @@ int launch_embed(const float* table, const float* pos, const int* tok, const int
 __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restrict__ logits, int vocab,
                                                            int* __restrict__ ids, int ids_stride,
                                                            int* __restrict__ cur_tok, int* __restrict__ done,
-                                                           int* __restrict__ n_done, const int* __restrict__ step) {
+                                                           int* __restrict__ n_done, int* step, int* arrive) {
   __shared__ float s_v[4];
   __shared__ int s_i[4];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,21 +128,19 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
       done[b] = 1;
       atomicAdd(n_done, 1);
     }
+    // every row has consumed *step once its block arrives here; the last arriver advances the step
+    // (device-memory step counter: the SAME captured graph serves every decode step)
+    if (atomicAdd(arrive, 1) == static_cast<int>(gridDim.x) - 1) {
+      *arrive = 0;
+      *step = *step + 1;
+    }
   }
 }
 
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
-                       int* n_done, const int* step, int B, hipStream_t s) {
+                       int* n_done, int* step, int* arrive, int B, hipStream_t s) {
   hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok, done,
-                     n_done, step);
-  MT3_HIP_CHECK(hipGetLastError());
-  return MT3_OK;
-}
-
-__global__ void advance_step_kernel(int* step) { *step = *step + 1; }
-
-int launch_advance_step(int* step, hipStream_t s) {
-  hipLaunchKernelGGL(advance_step_kernel, dim3(1), dim3(1), 0, s, step);
+                     n_done, step, arrive);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

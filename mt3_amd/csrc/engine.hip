@@ -16,7 +16,7 @@
 //     them inside every decode step unless XLA hoists them.
 //   * the self-attention cache is [B][H][L][64] written in place at position t (the reference
 //     rewrites the whole [B,H,64,L] cache per step: layers.py:272-292).
-//   * one decode step = 8 x 8 + 4 kernels with the step index in DEVICE memory, captured once per
+//   * one decode step = 8 x 8 + 3 kernels with the step index in DEVICE memory, captured once per
 //     batch size into a hipGraph and replayed L times.
 //   * sized for 288 GB HBM: all workspaces for max_batch are allocated up front
 //     (B=256: ~3.3 GB KV cache + ~0.9 GB cross K/V + ~0.5 GB activations in bf16).
@@ -98,20 +98,14 @@ struct mt3_engine {
   int* done = nullptr;
   int* step = nullptr;
   int* n_done = nullptr;
+  int* arrive = nullptr;
   int* h_pinned = nullptr;
-
-  // MT3_DECODE_PROFILE: HIP events around every decode-attention launch (direct launches, one sync per step)
-  std::vector<hipEvent_t> prof_ev;   // [2 kinds][layers][start, stop]
-  bool prof_on = false;
-  double prof_ms[2] = {0.0, 0.0};
-  double prof_bytes[2] = {0.0, 0.0};
-  double prof_launches[2] = {0.0, 0.0};
-  double prof_total_ms = 0.0;
 
   int cur_batch = 0;             // batch of the last encode
   hipStream_t cap_stream = nullptr;
-  hipGraphExec_t graph_exec = nullptr;
-  hipGraph_t graph = nullptr;
+  // one captured decode step per (batch, skip-mask); skip-mask != 0 only for differential profiling
+  hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
   int graph_batch = 0;
 
   int HD() const { return cfg.num_heads * cfg.head_dim; }
@@ -246,7 +240,7 @@ mt3k::GemmArgs gemm_args(const void* A, const void* Wt, void* out, int M, int N,
     if (_rc != MT3_OK) return _rc; \
   } while (0)
 
-int enqueue_decode_step(mt3_engine* e, int B, hipStream_t s) {
+int enqueue_decode_step(mt3_engine* e, int B, int skip, hipStream_t s) {
   const mt3_engine_config& c = e->cfg;
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), H = c.num_heads, T = c.input_length;
   const bool small = true;
@@ -269,9 +263,7 @@ int enqueue_decode_step(mt3_engine* e, int B, hipStream_t s) {
     a.out = e->attn_d;
     a.B = B;
     a.H = H;
-    if (e->prof_on) MT3_HIP_CHECK(hipEventRecord(e->prof_ev[(0 * c.num_decoder_layers + l) * 2], s));
-    MT3_TRY(mt3k::launch_decode_attention(dt, a, s));
-    if (e->prof_on) MT3_HIP_CHECK(hipEventRecord(e->prof_ev[(0 * c.num_decoder_layers + l) * 2 + 1], s));
+    if (!(skip & 1)) MT3_TRY(mt3k::launch_decode_attention(dt, a, s));
     MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->attn_d, L.wo, e->y, B, emb, hd, emb), false, false, MT3_EPI_RESID,
                               small, s));
     MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, L.wq_x, e->q_d, B, hd, emb, hd), true, true, MT3_EPI_STORE, small,
@@ -286,9 +278,7 @@ int enqueue_decode_step(mt3_engine* e, int B, hipStream_t s) {
     x.out = e->attn_d;
     x.B = B;
     x.H = H;
-    if (e->prof_on) MT3_HIP_CHECK(hipEventRecord(e->prof_ev[(1 * c.num_decoder_layers + l) * 2], s));
-    MT3_TRY(mt3k::launch_decode_attention(dt, x, s));
-    if (e->prof_on) MT3_HIP_CHECK(hipEventRecord(e->prof_ev[(1 * c.num_decoder_layers + l) * 2 + 1], s));
+    if (!(skip & 2)) MT3_TRY(mt3k::launch_decode_attention(dt, x, s));
     MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->attn_d, L.wo_x, e->y, B, emb, hd, emb), false, false, MT3_EPI_RESID,
                               small, s));
     MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, L.wi, e->h_d, B, 2 * c.mlp_dim, emb, c.mlp_dim), true, true,
@@ -299,27 +289,28 @@ int enqueue_decode_step(mt3_engine* e, int B, hipStream_t s) {
   MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, e->logits_w, e->logits, B, c.vocab_size, emb, c.vocab_size), true,
                             true, MT3_EPI_F32, small, s));
   MT3_TRY(mt3k::launch_argmax_step(e->logits, c.vocab_size, e->ids, c.max_decode_len, e->cur_tok, e->done, e->n_done,
-                                   e->step, B, s));
-  MT3_TRY(mt3k::launch_advance_step(e->step, s));
+                                   e->step, e->arrive, B, s));
   return MT3_OK;
 }
 
 void drop_graph(mt3_engine* e) {
-  if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
-  if (e->graph) (void)hipGraphDestroy(e->graph);
-  e->graph_exec = nullptr;
-  e->graph = nullptr;
+  for (int v = 0; v < 4; ++v) {
+    if (e->graph_exec[v]) (void)hipGraphExecDestroy(e->graph_exec[v]);
+    if (e->graph[v]) (void)hipGraphDestroy(e->graph[v]);
+    e->graph_exec[v] = nullptr;
+    e->graph[v] = nullptr;
+  }
   e->graph_batch = 0;
 }
 
 // capture one decode step for batch B (on the engine's private stream: the caller's stream may be
 // the legacy default stream, which cannot be captured)
-int ensure_graph(mt3_engine* e, int B) {
-  if (e->graph_exec && e->graph_batch == B) return MT3_OK;
-  drop_graph(e);
+int ensure_graph(mt3_engine* e, int B, int skip) {
+  if (e->graph_batch != B) drop_graph(e);
+  if (e->graph_exec[skip]) return MT3_OK;
   if (!e->cap_stream) MT3_HIP_CHECK(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
   MT3_HIP_CHECK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
-  const int rc = enqueue_decode_step(e, B, e->cap_stream);
+  const int rc = enqueue_decode_step(e, B, skip, e->cap_stream);
   hipGraph_t g = nullptr;
   const hipError_t end = hipStreamEndCapture(e->cap_stream, &g);
   if (rc != MT3_OK) {
@@ -327,8 +318,8 @@ int ensure_graph(mt3_engine* e, int B) {
     return rc;
   }
   if (end != hipSuccess) return mt3::fail(MT3_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(end));
-  e->graph = g;
-  MT3_HIP_CHECK(hipGraphInstantiate(&e->graph_exec, g, nullptr, nullptr, 0));
+  e->graph[skip] = g;
+  MT3_HIP_CHECK(hipGraphInstantiate(&e->graph_exec[skip], g, nullptr, nullptr, 0));
   e->graph_batch = B;
   return MT3_OK;
 }
@@ -364,7 +355,6 @@ void mt3_engine_destroy(mt3_engine* e) {
   if (!e) return;
   drop_graph(e);
   if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
-  for (auto& ev : e->prof_ev) (void)hipEventDestroy(ev);
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
@@ -387,17 +377,6 @@ int mt3_engine_load_weight(mt3_engine* e, const char* name, const float* h_data,
 }
 
 int64_t mt3_engine_device_bytes(const mt3_engine* e) { return e ? e->device_bytes : 0; }
-
-int mt3_engine_profile(const mt3_engine* e, double* out7) {
-  if (!e || !out7) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_profile: null argument");
-  for (int k = 0; k < 2; ++k) {
-    out7[3 * k] = e->prof_ms[k];
-    out7[3 * k + 1] = e->prof_launches[k];
-    out7[3 * k + 2] = e->prof_bytes[k];
-  }
-  out7[6] = e->prof_total_ms;
-  return MT3_OK;
-}
 
 int mt3_engine_finalize(mt3_engine* e) {
   if (!e) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_finalize: null engine");
@@ -489,6 +468,7 @@ int mt3_engine_finalize(mt3_engine* e) {
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->done), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->step), 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->n_done), 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->arrive), 4))) return rc;
   MT3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned), 64, hipHostMallocDefault));
   e->raw.clear();
   e->finalized = true;
@@ -544,48 +524,21 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
   const int L = c.max_decode_len;
   MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, 4, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->n_done, 0, 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->arrive, 0, 4, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->done, 0, static_cast<size_t>(batch) * 4, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->cur_tok, 0, static_cast<size_t>(batch) * 4, s));     // BOS = 0
   MT3_HIP_CHECK(hipMemsetAsync(e->ids, 0, static_cast<size_t>(batch) * L * 4, s));
 
-  const bool profile = (flags & MT3_DECODE_PROFILE) != 0;
-  bool use_graph = !(flags & MT3_DECODE_NO_GRAPH) && !profile;
-  if (use_graph && ensure_graph(e, batch) != MT3_OK) use_graph = false;   // fall back to direct launches
-  const int nl = c.num_decoder_layers;
-  hipEvent_t ev_all[2] = {nullptr, nullptr};
-  if (profile) {
-    if (e->prof_ev.empty()) {
-      e->prof_ev.resize(static_cast<size_t>(2) * nl * 2);
-      for (auto& ev : e->prof_ev) MT3_HIP_CHECK(hipEventCreate(&ev));
-    }
-    for (int k = 0; k < 2; ++k) e->prof_ms[k] = e->prof_bytes[k] = e->prof_launches[k] = 0.0;
-    MT3_HIP_CHECK(hipEventCreate(&ev_all[0]));
-    MT3_HIP_CHECK(hipEventCreate(&ev_all[1]));
-    MT3_HIP_CHECK(hipEventRecord(ev_all[0], s));
-    e->prof_on = true;
-  }
+  // profiling-only variants: leave the self (1) / cross (2) attention launches out of the step, so that
+  // their in-situ cost can be read as a DIFFERENCE of whole-decode times (results are garbage)
+  const int skip = ((flags & MT3_DECODE_SKIP_SELF_ATTN) ? 1 : 0) | ((flags & MT3_DECODE_SKIP_CROSS_ATTN) ? 2 : 0);
+  bool use_graph = !(flags & MT3_DECODE_NO_GRAPH);
+  if (use_graph && ensure_graph(e, batch, skip) != MT3_OK) use_graph = false;   // fall back to direct launches
   int ran = 0;
   for (int t = 0; t < num_steps; ++t) {
-    if (use_graph) MT3_HIP_CHECK(hipGraphLaunch(e->graph_exec, s));
-    else {
-      const int rc = enqueue_decode_step(e, batch, s);
-      if (rc != MT3_OK) { e->prof_on = false; return rc; }
-    }
+    if (use_graph) MT3_HIP_CHECK(hipGraphLaunch(e->graph_exec[skip], s));
+    else MT3_TRY(enqueue_decode_step(e, batch, skip, s));
     ++ran;
-    if (profile) {
-      MT3_HIP_CHECK(hipStreamSynchronize(s));
-      const double kv = 2.0 * batch * c.num_heads * 64 * e->esize;          // K+V bytes per key position
-      for (int k = 0; k < 2; ++k)
-        for (int l = 0; l < nl; ++l) {
-          float ms = 0.f;
-          MT3_HIP_CHECK(hipEventElapsedTime(&ms, e->prof_ev[(k * nl + l) * 2], e->prof_ev[(k * nl + l) * 2 + 1]));
-          e->prof_ms[k] += ms;
-          e->prof_launches[k] += 1.0;
-          // algorithmic bytes of the launch: the K/V rows it must read (+ q in, out; new row write for self)
-          e->prof_bytes[k] += kv * (k == 0 ? (t + 1) : c.input_length) + 2.0 * batch * c.num_heads * 64 * e->esize +
-                              (k == 0 ? kv : 0.0);
-        }
-    }
     if (t == 0 && d_first_logits)
       MT3_HIP_CHECK(hipMemcpyAsync(d_first_logits, e->logits, static_cast<size_t>(batch) * c.vocab_size * 4,
                                    hipMemcpyDeviceToDevice, s));
@@ -594,16 +547,6 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
       MT3_HIP_CHECK(hipStreamSynchronize(s));
       if (e->h_pinned[0] >= batch) break;
     }
-  }
-  if (profile) {
-    e->prof_on = false;
-    MT3_HIP_CHECK(hipEventRecord(ev_all[1], s));
-    MT3_HIP_CHECK(hipEventSynchronize(ev_all[1]));
-    float ms = 0.f;
-    MT3_HIP_CHECK(hipEventElapsedTime(&ms, ev_all[0], ev_all[1]));
-    e->prof_total_ms = ms;
-    (void)hipEventDestroy(ev_all[0]);
-    (void)hipEventDestroy(ev_all[1]);
   }
   MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
   if (h_steps_run) *h_steps_run = ran;

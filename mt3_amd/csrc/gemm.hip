@@ -76,7 +76,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   constexpr int A_PASSES = BM * CPR / NT, B_PASSES = BN * CPR / NT;
   constexpr int ROWS_PER_PASS = NT / CPR;
   static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile/threads mismatch");
-  static_assert(NT % CPR == 0 && (CPR & (CPR - 1)) == 0, "CPR must be a power of two dividing NT");
+  static_assert(NT % CPR == 0 && (CPR & (CPR - 1)) == 0 && CPR <= 64, "CPR: power of two, <= one wave, divides NT");
   static_assert(BK % KG == 0, "BK must be a multiple of the MFMA K-group");
   static_assert(!NORM || A_F32, "NORM needs the f32 A operand");
   static_assert(EPI != MT3_EPI_GEGLU || (FN % 2 == 0), "GEGLU pairs fragments");
@@ -211,10 +211,26 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   return MT3_OK;
 }
 
+// Tile choice.
+//   big   (encoder, M = B*T >= 2048): 128x128 tile, K step = one MFMA K-group, 2x2 waves of 64x64.
+//   small (decode, M = B <= a few hundred): the GEMM is latency-bound (weights are L2/MALL resident,
+//         ~1 MB), so the tile is 32x32 (64x32 for GEGLU, which pairs fragments inside a wave) to put
+//         >= 100 workgroups on the chip, and the K step is as deep as LDS allows (16 K-groups = 512 bf16
+//         elements: K = 512 in ONE slice) so that every global load of the block is in flight at once
+//         instead of 8-16 dependent load->barrier->MFMA rounds.
 template <typename CT, bool A_F32, bool NORM, int EPI>
 static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
   constexpr int KG = CTraits<CT>::KGROUP;
-  if (small) return launch_cfg<CT, 64, 64, 2 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
+  if (small) {
+    const bool deep = g.K % (16 * KG) == 0;
+    if constexpr (EPI == MT3_EPI_GEGLU) {
+      if (deep) return launch_cfg<CT, 64, 32, 16 * KG, 4, 1, A_F32, NORM, EPI>(g, s);
+      return launch_cfg<CT, 64, 32, 4 * KG, 4, 1, A_F32, NORM, EPI>(g, s);
+    } else {
+      if (deep) return launch_cfg<CT, 32, 32, 16 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
+      return launch_cfg<CT, 32, 32, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
+    }
+  }
   return launch_cfg<CT, 128, 128, KG, 2, 2, A_F32, NORM, EPI>(g, s);
 }
 

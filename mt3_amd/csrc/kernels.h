@@ -48,8 +48,7 @@ int launch_embed(const float* table, const float* pos, const int* tok, const int
                  hipStream_t s);
 // greedy pick + bookkeeping for one decode step (see decode_ops.hip)
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
-                       int* n_done, const int* step, int B, hipStream_t s);
-int launch_advance_step(int* step, hipStream_t s);
+                       int* n_done, int* step, int* arrive, int B, hipStream_t s);
 int launch_ids_to_tokens(const int* ids, int B, int L, int num_regular, int* out, hipStream_t s);
 
 }  // namespace mt3k

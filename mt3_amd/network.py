@@ -159,7 +159,8 @@ class Transformer:
         return enc
 
     def decode(self, num_steps: Optional[int] = None, use_graph: bool = True, early_exit: bool = False,
-               return_first_logits: bool = False, profile: bool = False):
+               return_first_logits: bool = False, skip_self_attn: bool = False,
+               skip_cross_attn: bool = False):
         """Greedy decode for the batch of the last `encode`.  Returns int32 CUDA [B, L] ids
         (and the step-0 logits [B, V] if asked)."""
         import torch
@@ -168,18 +169,11 @@ class Transformer:
         logits = torch.empty((B, self.config.vocab_size), device="cuda", dtype=torch.float32) \
             if return_first_logits else None
         flags = (0 if use_graph else _lib.DECODE_NO_GRAPH) | (_lib.DECODE_EARLY_EXIT if early_exit else 0) | \
-            (_lib.DECODE_PROFILE if profile else 0)
+            (_lib.DECODE_SKIP_SELF_ATTN if skip_self_attn else 0) | \
+            (_lib.DECODE_SKIP_CROSS_ATTN if skip_cross_attn else 0)       # skip_*: profiling only
         ran = C.c_int32()
         _lib.check(self._lib.mt3_engine_decode(self._h, B, num_steps or L, flags, ids.data_ptr(),
                                                logits.data_ptr() if logits is not None else None, C.byref(ran),
                                                torch.cuda.current_stream().cuda_stream))
         self.steps_run = ran.value
         return (ids, logits) if return_first_logits else ids
-
-    def decode_profile(self) -> Dict[str, float]:
-        """Timers of the last `decode(profile=True)`: per decode-attention kind the summed HIP-event
-        time, launch count and algorithmic bytes; plus the whole (direct-launch) decode time."""
-        out = (C.c_double * 7)()
-        _lib.check(self._lib.mt3_engine_profile(self._h, out))
-        return {"self_ms": out[0], "self_launches": out[1], "self_bytes": out[2], "cross_ms": out[3],
-                "cross_launches": out[4], "cross_bytes": out[5], "decode_ms": out[6]}
