@@ -93,6 +93,8 @@ typedef struct mt3_engine_config {   /* network.T5Config (network.py:25-41), mod
   int32_t max_decode_len;       /* L: 1024 */
   int32_t max_batch;            /* segments per call the workspaces are sized for */
   int32_t compute_dtype;        /* mt3_dtype: MFMA operand type; accumulation is always f32 */
+  int32_t decode_chains;        /* 0/1: one chain; n <= 8: the decode batch is dealt to n independent row groups
+                                   that run as parallel branches of the step graph (same results, bit for bit) */
 } mt3_engine_config;
 
 typedef struct mt3_engine mt3_engine;
@@ -128,7 +130,9 @@ enum {
    * HIP events around the whole graph-replayed decode instead of 8192 per-launch event pairs */
   MT3_DECODE_SKIP_SELF_ATTN = 8,
   MT3_DECODE_SKIP_CROSS_ATTN = 16
+  /* bits 8..11: number of decode chains for this call (1..8); 0 = the engine's configured default */
 };
+#define MT3_DECODE_CHAINS(n) (((n) & 0xF) << 8)
 int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags,
                       int32_t* d_ids, float* d_first_logits, int32_t* h_steps_run, void* stream);
 

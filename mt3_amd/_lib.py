@@ -36,7 +36,8 @@ class FrontendConfig(C.Structure):
 class EngineConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "vocab_size", "emb_dim", "num_heads", "head_dim", "mlp_dim", "num_encoder_layers",
-        "num_decoder_layers", "input_depth", "input_length", "max_decode_len", "max_batch", "compute_dtype")]
+        "num_decoder_layers", "input_depth", "input_length", "max_decode_len", "max_batch", "compute_dtype",
+        "decode_chains")]
 
 
 class EventRange(C.Structure):

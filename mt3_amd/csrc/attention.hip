@@ -257,8 +257,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs a) {
             vp = nv + sub * KPL;
           }
         }
-        kv[u] = *reinterpret_cast<const u32x4*>(kp);
-        vv[u] = *reinterpret_cast<const u32x4*>(vp);
+        // streamed once per step by exactly one CU: non-temporal, so the K/V stream (up to 3.2 GB per
+        // step) does not evict the decoder weights / activations the GEMMs re-read from L2 / MALL
+        kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kp));
+        vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vp));
       } else {
         kv[u] = u32x4{0u, 0u, 0u, 0u};
         vv[u] = u32x4{0u, 0u, 0u, 0u};

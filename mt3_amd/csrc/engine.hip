@@ -17,7 +17,10 @@
 //   * the self-attention cache is [B][H][L][64] written in place at position t (the reference
 //     rewrites the whole [B,H,64,L] cache per step: layers.py:272-292).
 //   * one decode step = 8 x 8 + 3 kernels with the step index in DEVICE memory, captured once per
-//     batch size into a hipGraph and replayed L times.
+//     batch size into a hipGraph and replayed L times.  The batch is dealt to `decode_chains`
+//     independent row groups, one graph BRANCH each (fork/join capture over several streams): the
+//     small-M GEMMs are latency-bound and the attention kernels HBM-bound, so concurrent branches
+//     overlap one chain's launch/latency floors with another chain's K/V streaming.
 //   * sized for 288 GB HBM: all workspaces for max_batch are allocated up front
 //     (B=256: ~3.3 GB KV cache + ~0.9 GB cross K/V + ~0.5 GB activations in bf16).
 #include <hip/hip_runtime.h>
@@ -36,6 +39,7 @@
 namespace {
 
 constexpr int kMaxPos = 2048;   // FixedEmbed.max_length, layers.py:565
+constexpr int kMaxChains = 8;
 
 uint16_t f32_to_bf16_bits(float f) {
   uint32_t u;
@@ -102,10 +106,11 @@ struct mt3_engine {
   int* h_pinned = nullptr;
 
   int cur_batch = 0;             // batch of the last encode
-  hipStream_t cap_stream = nullptr;
+  hipStream_t cap_stream[8] = {};     // one capture stream per chain (kMaxChains)
+  hipEvent_t cap_event[8] = {};
   // one captured decode step per (batch, skip-mask); skip-mask != 0 only for differential profiling
-  hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
-  hipGraph_t graph[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipGraphExec_t graph_exec[4][9] = {};   // [skip-mask][chains]
+  hipGraph_t graph[4][9] = {};
   int graph_batch = 0;
 
   int HD() const { return cfg.num_heads * cfg.head_dim; }
@@ -240,86 +245,142 @@ mt3k::GemmArgs gemm_args(const void* A, const void* Wt, void* out, int M, int N,
     if (_rc != MT3_OK) return _rc; \
   } while (0)
 
-int enqueue_decode_step(mt3_engine* e, int B, int skip, hipStream_t s) {
+// One decode step of rows [row0, row0 + rows) -- a "chain".  The batch of a decode call is split into
+// `e->chains` such chains; they are data-independent (a segment never looks at another segment), so
+// the step graph has one branch per chain and the GPU overlaps one chain's latency-bound GEMMs with
+// another chain's HBM-bound attention streams.  Every row-indexed workspace is simply offset.
+int enqueue_chain_step(mt3_engine* e, int row0, int rows, int chain, int B_total, int skip, hipStream_t s) {
   const mt3_engine_config& c = e->cfg;
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), H = c.num_heads, T = c.input_length;
+  const int Lmax = c.max_decode_len;
+  const size_t es = e->esize;
   const bool small = true;
-  char* qkv_b = static_cast<char*>(e->qkv_d);
-  MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y, B, emb, s));
+  float* y = e->y + static_cast<size_t>(row0) * emb;
+  char* qkv_d = static_cast<char*>(e->qkv_d) + static_cast<size_t>(row0) * 3 * hd * es;
+  char* attn_d = static_cast<char*>(e->attn_d) + static_cast<size_t>(row0) * hd * es;
+  char* q_d = static_cast<char*>(e->q_d) + static_cast<size_t>(row0) * hd * es;
+  char* h_d = static_cast<char*>(e->h_d) + static_cast<size_t>(row0) * c.mlp_dim * es;
+  float* logits = e->logits + static_cast<size_t>(row0) * c.vocab_size;
+  int* step = e->step + chain;
+  int* arrive = e->arrive + chain;
+  MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok + row0, step, y, rows, emb, s));
   for (int l = 0; l < c.num_decoder_layers; ++l) {
     LayerDev& L = e->dec[l];
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, L.wqkv, e->qkv_d, B, 3 * hd, emb, 3 * hd), true, true,
-                              MT3_EPI_STORE, small, s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(y, L.wqkv, qkv_d, rows, 3 * hd, emb, 3 * hd), true, true, MT3_EPI_STORE,
+                              small, s));
     mt3k::DecAttnArgs a{};
-    a.q = e->qkv_d;
+    a.q = qkv_d;
     a.q_stride = 3 * hd;
-    a.kcache = L.self_k;
-    a.vcache = L.self_v;
-    a.cap = c.max_decode_len;
-    a.new_k = qkv_b + static_cast<size_t>(hd) * e->esize;
-    a.new_v = qkv_b + static_cast<size_t>(2 * hd) * e->esize;
+    a.kcache = static_cast<char*>(L.self_k) + static_cast<size_t>(row0) * H * Lmax * 64 * es;
+    a.vcache = static_cast<char*>(L.self_v) + static_cast<size_t>(row0) * H * Lmax * 64 * es;
+    a.cap = Lmax;
+    a.new_k = qkv_d + static_cast<size_t>(hd) * es;
+    a.new_v = qkv_d + static_cast<size_t>(2 * hd) * es;
     a.kv_stride = 3 * hd;
-    a.step = e->step;
-    a.out = e->attn_d;
-    a.B = B;
+    a.step = step;
+    a.out = attn_d;
+    a.B = rows;
     a.H = H;
     if (!(skip & 1)) MT3_TRY(mt3k::launch_decode_attention(dt, a, s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->attn_d, L.wo, e->y, B, emb, hd, emb), false, false, MT3_EPI_RESID,
-                              small, s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, L.wq_x, e->q_d, B, hd, emb, hd), true, true, MT3_EPI_STORE, small,
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(attn_d, L.wo, y, rows, emb, hd, emb), false, false, MT3_EPI_RESID, small,
                               s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(y, L.wq_x, q_d, rows, hd, emb, hd), true, true, MT3_EPI_STORE, small, s));
     mt3k::DecAttnArgs x{};
-    x.q = e->q_d;
+    x.q = q_d;
     x.q_stride = hd;
-    x.kcache = L.cross_kv;
-    x.vcache = static_cast<char*>(L.cross_kv) + static_cast<size_t>(B) * H * T * 64 * e->esize;
+    x.kcache = static_cast<char*>(L.cross_kv) + static_cast<size_t>(row0) * H * T * 64 * es;
+    x.vcache = static_cast<char*>(L.cross_kv) + (static_cast<size_t>(B_total) + row0) * H * T * 64 * es;
     x.cap = T;
     x.n_keys = T;
-    x.out = e->attn_d;
-    x.B = B;
+    x.out = attn_d;
+    x.B = rows;
     x.H = H;
     if (!(skip & 2)) MT3_TRY(mt3k::launch_decode_attention(dt, x, s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->attn_d, L.wo_x, e->y, B, emb, hd, emb), false, false, MT3_EPI_RESID,
-                              small, s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, L.wi, e->h_d, B, 2 * c.mlp_dim, emb, c.mlp_dim), true, true,
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(attn_d, L.wo_x, y, rows, emb, hd, emb), false, false, MT3_EPI_RESID, small,
+                              s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(y, L.wi, h_d, rows, 2 * c.mlp_dim, emb, c.mlp_dim), true, true,
                               MT3_EPI_GEGLU, small, s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->h_d, L.wo_mlp, e->y, B, emb, c.mlp_dim, emb), false, false,
-                              MT3_EPI_RESID, small, s));
+    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(h_d, L.wo_mlp, y, rows, emb, c.mlp_dim, emb), false, false, MT3_EPI_RESID,
+                              small, s));
   }
-  MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->y, e->logits_w, e->logits, B, c.vocab_size, emb, c.vocab_size), true,
-                            true, MT3_EPI_F32, small, s));
-  MT3_TRY(mt3k::launch_argmax_step(e->logits, c.vocab_size, e->ids, c.max_decode_len, e->cur_tok, e->done, e->n_done,
-                                   e->step, e->arrive, B, s));
+  MT3_TRY(mt3k::launch_gemm(dt, gemm_args(y, e->logits_w, logits, rows, c.vocab_size, emb, c.vocab_size), true, true,
+                            MT3_EPI_F32, small, s));
+  MT3_TRY(mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
+                                   e->cur_tok + row0, e->done + row0, e->n_done, step, arrive, rows, s));
+  return MT3_OK;
+}
+
+// rows of chain k when `B` rows are dealt to `n` chains
+inline void chain_rows(int B, int n, int k, int* row0, int* rows) {
+  const int q = B / n, r = B % n;
+  *row0 = k * q + (k < r ? k : r);
+  *rows = q + (k < r ? 1 : 0);
+}
+
+int chains_for(const mt3_engine* e, int B, int requested) {
+  int n = requested > 0 ? requested : (e->cfg.decode_chains > 0 ? e->cfg.decode_chains : 1);
+  if (n > kMaxChains) n = kMaxChains;
+  while (n > 1 && B / n < 16) --n;          // keep at least one MFMA row-fragment per chain
+  return n;
+}
+
+// direct (un-captured) launch of one whole step on one stream: chains back to back
+int enqueue_decode_step(mt3_engine* e, int B, int skip, int n, hipStream_t s) {
+  for (int k = 0; k < n; ++k) {
+    int row0, rows;
+    chain_rows(B, n, k, &row0, &rows);
+    MT3_TRY(enqueue_chain_step(e, row0, rows, k, B, skip, s));
+  }
   return MT3_OK;
 }
 
 void drop_graph(mt3_engine* e) {
-  for (int v = 0; v < 4; ++v) {
-    if (e->graph_exec[v]) (void)hipGraphExecDestroy(e->graph_exec[v]);
-    if (e->graph[v]) (void)hipGraphDestroy(e->graph[v]);
-    e->graph_exec[v] = nullptr;
-    e->graph[v] = nullptr;
-  }
+  for (int v = 0; v < 4; ++v)
+    for (int n = 0; n < 9; ++n) {
+      if (e->graph_exec[v][n]) (void)hipGraphExecDestroy(e->graph_exec[v][n]);
+      if (e->graph[v][n]) (void)hipGraphDestroy(e->graph[v][n]);
+      e->graph_exec[v][n] = nullptr;
+      e->graph[v][n] = nullptr;
+    }
   e->graph_batch = 0;
 }
 
 // capture one decode step for batch B (on the engine's private stream: the caller's stream may be
 // the legacy default stream, which cannot be captured)
-int ensure_graph(mt3_engine* e, int B, int skip) {
+int ensure_graph(mt3_engine* e, int B, int skip, int n) {
   if (e->graph_batch != B) drop_graph(e);
-  if (e->graph_exec[skip]) return MT3_OK;
-  if (!e->cap_stream) MT3_HIP_CHECK(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
-  MT3_HIP_CHECK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
-  const int rc = enqueue_decode_step(e, B, skip, e->cap_stream);
-  hipGraph_t g = nullptr;
-  const hipError_t end = hipStreamEndCapture(e->cap_stream, &g);
-  if (rc != MT3_OK) {
-    if (g) (void)hipGraphDestroy(g);
-    return rc;
+  if (e->graph_exec[skip][n]) return MT3_OK;
+  for (int k = 0; k < n; ++k) {
+    if (!e->cap_stream[k]) MT3_HIP_CHECK(hipStreamCreateWithFlags(&e->cap_stream[k], hipStreamNonBlocking));
+    if (!e->cap_event[k]) MT3_HIP_CHECK(hipEventCreateWithFlags(&e->cap_event[k], hipEventDisableTiming));
   }
-  if (end != hipSuccess) return mt3::fail(MT3_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(end));
-  e->graph[skip] = g;
-  MT3_HIP_CHECK(hipGraphInstantiate(&e->graph_exec[skip], g, nullptr, nullptr, 0));
+  hipStream_t origin = e->cap_stream[0];
+  MT3_HIP_CHECK(hipStreamBeginCapture(origin, hipStreamCaptureModeThreadLocal));
+  int rc = MT3_OK;
+  hipError_t he = hipSuccess;
+  // fork: every other chain's stream joins the capture by waiting on an event of the origin
+  if (n > 1) he = hipEventRecord(e->cap_event[0], origin);
+  for (int k = 1; k < n && he == hipSuccess; ++k) he = hipStreamWaitEvent(e->cap_stream[k], e->cap_event[0], 0);
+  for (int k = 0; k < n && he == hipSuccess && rc == MT3_OK; ++k) {
+    int row0, rows;
+    chain_rows(B, n, k, &row0, &rows);
+    rc = enqueue_chain_step(e, row0, rows, k, B, skip, e->cap_stream[k]);
+  }
+  // join
+  for (int k = 1; k < n && he == hipSuccess && rc == MT3_OK; ++k) {
+    he = hipEventRecord(e->cap_event[k], e->cap_stream[k]);
+    if (he == hipSuccess) he = hipStreamWaitEvent(origin, e->cap_event[k], 0);
+  }
+  hipGraph_t g = nullptr;
+  const hipError_t end = hipStreamEndCapture(origin, &g);
+  if (rc != MT3_OK || he != hipSuccess || end != hipSuccess) {
+    if (g) (void)hipGraphDestroy(g);
+    if (rc != MT3_OK) return rc;
+    return mt3::fail(MT3_ERR_HIP, std::string("decode graph capture: ") +
+                                      hipGetErrorString(he != hipSuccess ? he : end));
+  }
+  e->graph[skip][n] = g;
+  MT3_HIP_CHECK(hipGraphInstantiate(&e->graph_exec[skip][n], g, nullptr, nullptr, 0));
   e->graph_batch = B;
   return MT3_OK;
 }
@@ -340,6 +401,8 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->emb_dim % 128 || cfg->mlp_dim % 128 || cfg->vocab_size % 128 || cfg->input_depth % 64 ||
       (cfg->num_heads * 64) % 128)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: emb/mlp/vocab/heads*64 must be multiples of 128");
+  if (cfg->decode_chains < 0 || cfg->decode_chains > kMaxChains)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: decode_chains must be in [0, 8]");
   if (cfg->max_batch <= 0 || cfg->max_decode_len <= 0 || cfg->max_decode_len > kMaxPos ||
       cfg->num_encoder_layers <= 0 || cfg->num_decoder_layers <= 0)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: bad sizes");
@@ -354,7 +417,10 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
 void mt3_engine_destroy(mt3_engine* e) {
   if (!e) return;
   drop_graph(e);
-  if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+  for (int k = 0; k < kMaxChains; ++k) {
+    if (e->cap_stream[k]) (void)hipStreamDestroy(e->cap_stream[k]);
+    if (e->cap_event[k]) (void)hipEventDestroy(e->cap_event[k]);
+  }
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
@@ -466,9 +532,9 @@ int mt3_engine_finalize(mt3_engine* e) {
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->ids), static_cast<size_t>(Bm) * L * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->cur_tok), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->done), static_cast<size_t>(Bm) * 4))) return rc;
-  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->step), 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->step), 4 * kMaxChains))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->n_done), 4))) return rc;
-  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->arrive), 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->arrive), 4 * kMaxChains))) return rc;
   MT3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned), 64, hipHostMallocDefault));
   e->raw.clear();
   e->finalized = true;
@@ -522,9 +588,9 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: num_steps out of range or null ids");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = c.max_decode_len;
-  MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, 4 * kMaxChains, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->n_done, 0, 4, s));
-  MT3_HIP_CHECK(hipMemsetAsync(e->arrive, 0, 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->arrive, 0, 4 * kMaxChains, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->done, 0, static_cast<size_t>(batch) * 4, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->cur_tok, 0, static_cast<size_t>(batch) * 4, s));     // BOS = 0
   MT3_HIP_CHECK(hipMemsetAsync(e->ids, 0, static_cast<size_t>(batch) * L * 4, s));
@@ -533,11 +599,12 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
   // their in-situ cost can be read as a DIFFERENCE of whole-decode times (results are garbage)
   const int skip = ((flags & MT3_DECODE_SKIP_SELF_ATTN) ? 1 : 0) | ((flags & MT3_DECODE_SKIP_CROSS_ATTN) ? 2 : 0);
   bool use_graph = !(flags & MT3_DECODE_NO_GRAPH);
-  if (use_graph && ensure_graph(e, batch, skip) != MT3_OK) use_graph = false;   // fall back to direct launches
+  const int chains = chains_for(e, batch, (flags >> 8) & 0xF);
+  if (use_graph && ensure_graph(e, batch, skip, chains) != MT3_OK) use_graph = false;   // fall back to direct launches
   int ran = 0;
   for (int t = 0; t < num_steps; ++t) {
-    if (use_graph) MT3_HIP_CHECK(hipGraphLaunch(e->graph_exec[skip], s));
-    else MT3_TRY(enqueue_decode_step(e, batch, skip, s));
+    if (use_graph) MT3_HIP_CHECK(hipGraphLaunch(e->graph_exec[skip][chains], s));
+    else MT3_TRY(enqueue_decode_step(e, batch, skip, chains, s));
     ++ran;
     if (t == 0 && d_first_logits)
       MT3_HIP_CHECK(hipMemcpyAsync(d_first_logits, e->logits, static_cast<size_t>(batch) * c.vocab_size * 4,

@@ -214,7 +214,7 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
 // Tile choice.
 //   big   (encoder, M = B*T >= 2048): 128x128 tile, K step = one MFMA K-group, 2x2 waves of 64x64.
 //   small (decode, M = B <= a few hundred): the GEMM is latency-bound (weights are L2/MALL resident,
-//         ~1 MB), so the tile is 32x32 (64x32 for GEGLU, which pairs fragments inside a wave) to put
+//         ~1 MB), so the tile is 32x32 (32x64 for GEGLU, which pairs fragments inside a wave) to put
 //         >= 100 workgroups on the chip, and the K step is as deep as LDS allows (16 K-groups = 512 bf16
 //         elements: K = 512 in ONE slice) so that every global load of the block is in flight at once
 //         instead of 8-16 dependent load->barrier->MFMA rounds.
@@ -224,8 +224,8 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
   if (small) {
     const bool deep = g.K % (16 * KG) == 0;
     if constexpr (EPI == MT3_EPI_GEGLU) {
-      if (deep) return launch_cfg<CT, 64, 32, 16 * KG, 4, 1, A_F32, NORM, EPI>(g, s);
-      return launch_cfg<CT, 64, 32, 4 * KG, 4, 1, A_F32, NORM, EPI>(g, s);
+      if (deep) return launch_cfg<CT, 32, 64, 16 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
+      return launch_cfg<CT, 32, 64, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
     } else {
       if (deep) return launch_cfg<CT, 32, 32, 16 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 32, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);

@@ -111,7 +111,7 @@ class Transformer:
     """One engine per (device, stream)."""
 
     def __init__(self, config: T5Config, input_length: int = 256, max_decode_length: int = 1024,
-                 max_batch: int = 8):
+                 max_batch: int = 8, decode_chains: int = 1):
         self.config = config
         self.input_length, self.max_decode_length, self.max_batch = input_length, max_decode_length, max_batch
         if config.dtype not in ("bfloat16", "float32"):
@@ -120,7 +120,7 @@ class Transformer:
         ec = _lib.EngineConfig(config.vocab_size, config.emb_dim, config.num_heads, config.head_dim, config.mlp_dim,
                                config.num_encoder_layers, config.num_decoder_layers, config.input_depth,
                                input_length, max_decode_length, max_batch,
-                               _lib.MT3_BF16 if config.dtype == "bfloat16" else _lib.MT3_F32)
+                               _lib.MT3_BF16 if config.dtype == "bfloat16" else _lib.MT3_F32, decode_chains)
         h = C.c_void_p()
         _lib.check(self._lib.mt3_engine_create(C.byref(ec), C.byref(h)))
         self._h = h
@@ -160,7 +160,7 @@ class Transformer:
 
     def decode(self, num_steps: Optional[int] = None, use_graph: bool = True, early_exit: bool = False,
                return_first_logits: bool = False, skip_self_attn: bool = False,
-               skip_cross_attn: bool = False):
+               skip_cross_attn: bool = False, chains: int = 0):
         """Greedy decode for the batch of the last `encode`.  Returns int32 CUDA [B, L] ids
         (and the step-0 logits [B, V] if asked)."""
         import torch
@@ -170,7 +170,7 @@ class Transformer:
             if return_first_logits else None
         flags = (0 if use_graph else _lib.DECODE_NO_GRAPH) | (_lib.DECODE_EARLY_EXIT if early_exit else 0) | \
             (_lib.DECODE_SKIP_SELF_ATTN if skip_self_attn else 0) | \
-            (_lib.DECODE_SKIP_CROSS_ATTN if skip_cross_attn else 0)       # skip_*: profiling only
+            (_lib.DECODE_SKIP_CROSS_ATTN if skip_cross_attn else 0) | ((chains & 0xF) << 8)   # skip_*: profiling only
         ran = C.c_int32()
         _lib.check(self._lib.mt3_engine_decode(self._h, B, num_steps or L, flags, ids.data_ptr(),
                                                logits.data_ptr() if logits is not None else None, C.byref(ran),

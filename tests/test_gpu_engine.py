@@ -141,6 +141,27 @@ def test_full_length_decode_and_early_exit(setup):
     assert np.array_equal(two[:, :16], full[:2, :16])
 
 
+def test_decode_chains_are_bit_identical(setup):
+    """The batch dealt to 1 / 2 / 4 / 8 parallel graph branches decodes to exactly the same ids."""
+    B = 64
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(B, T, 512, device="cuda", generator=g) * 2 - 4
+    cfg = network.T5Config(dtype="bfloat16")
+    eng = network.Transformer(cfg, input_length=T, max_decode_length=L, max_batch=B, decode_chains=1)
+    eng.load_params(setup["params"])
+    eng.encode(x)
+    ref = eng.decode(num_steps=24, chains=1).cpu().numpy()
+    for n in (2, 4, 8):
+        for graph in (True, False):
+            got = eng.decode(num_steps=24, chains=n, use_graph=graph).cpu().numpy()
+            assert np.array_equal(got, ref), f"chains={n} graph={graph}"
+    # ragged split: 50 rows over 3 chains
+    eng.encode(x[:50])
+    a = eng.decode(num_steps=8, chains=1).cpu().numpy()
+    b = eng.decode(num_steps=8, chains=3).cpu().numpy()
+    assert np.array_equal(a, b)
+
+
 def test_inference_model_end_to_end():
     """InferenceModel('random:0', 'mt3')(audio): product notes == oracle symbolic stage on the product's tokens."""
     from mt3_amd import inference

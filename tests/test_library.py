@@ -29,7 +29,7 @@ def test_argument_errors_are_reported_not_swallowed():
     bad = _lib.FrontendConfig(16000, 160, 512, 2048, 20.0, 7600.0)            # unsupported hop
     assert lib.mt3_frontend_create(C.byref(bad), C.byref(h)) == _lib.MT3_ERR_INVALID
     assert b"hop_width" in lib.mt3_last_error()
-    cfg = _lib.EngineConfig(1536, 512, 6, 32, 1024, 8, 8, 512, 256, 1024, 8, _lib.MT3_BF16)   # head_dim 32
+    cfg = _lib.EngineConfig(1536, 512, 6, 32, 1024, 8, 8, 512, 256, 1024, 8, _lib.MT3_BF16, 1)   # head_dim 32
     assert lib.mt3_engine_create(C.byref(cfg), C.byref(h)) == _lib.MT3_ERR_INVALID
     with pytest.raises(_lib.Mt3Error):
         _lib.check(lib.mt3_ids_to_tokens(None, 1, 1, 1, None, None))
@@ -49,7 +49,7 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback():
 
 def test_missing_weight_is_an_error():
     lib = _lib.load()
-    cfg = _lib.EngineConfig(1536, 512, 6, 64, 1024, 1, 1, 512, 256, 1024, 1, _lib.MT3_BF16)
+    cfg = _lib.EngineConfig(1536, 512, 6, 64, 1024, 1, 1, 512, 256, 1024, 1, _lib.MT3_BF16, 1)
     h = C.c_void_p()
     assert lib.mt3_engine_create(C.byref(cfg), C.byref(h)) == 0
     rc = lib.mt3_engine_finalize(h)
