@@ -176,9 +176,23 @@ def main():
         self_us = (t_full - t_noself) * 1e3 / launches
         cross_us = (t_full - t_nocross) * 1e3 / launches
         ach = self_bytes / launches / (self_us * 1e-6) / 1e9
+        # HBM traffic of that kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # passes, FETCH_SIZE x2 on gfx950 -- calibrated on a 1 GiB copy): collected by tools/gpu_pmc.sh at this
+        # exact shape, committed as profiles/r1_pmc_summary.json (a bench run cannot wrap itself in rocprofv3)
+        traffic, traffic_src = None, None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
+                pmc = json.load(f)
+            if pmc["shape"]["B"] == B and args.dtype == "bfloat16" and args.decode_steps == 1024:
+                ratio = pmc["dec_attn_self_append"]["n_keys_513"]["traffic_over_algorithmic"]
+                traffic = ratio * self_bytes / launches
+                traffic_src = "profiles/r1_pmc_summary.json (measured traffic/algorithmic = %.4f at the mean launch)" % ratio
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {"bound": "hbm", "kernel": "mt3k::dec_attn_kernel<bf16, APPEND=true> (decode self-attention over the "
                                           "K/V cache)",
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src,
                 "avg_launch_us": self_us, "algorithmic_bytes_per_launch": self_bytes / launches, "launches": launches,
                 "method": "HIP events on the launch stream around the whole graph-replayed decode, with and "
                           "without this kernel in the step graph; (difference)/launches",
