@@ -24,6 +24,8 @@
 //     one-hot multiply-add: layers.py:272-292).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "device.h"
 #include "kernels.h"
@@ -198,16 +200,16 @@ int launch_encoder_attention(int dtype, const void* qkv, void* out, int B, int T
 }
 
 // ------------------------------------------------------------------------- decode attention
-template <typename CT, bool APPEND>
-__global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs a) {
+template <typename CT, bool APPEND, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int KPL = CTraits<CT>::KPL;
   constexpr int D = 64;
   constexpr int LPK = D / KPL;            // lanes sharing one key (8 bf16 / 16 f32)
   constexpr int KPW = 64 / LPK;           // keys per wave per load
-  constexpr int STRIDE = 4 * KPW;         // keys per block iteration
+  constexpr int STRIDE = NW * KPW;        // keys per block iteration
   constexpr int UNROLL = 4;
 
-  __shared__ float s_m[4][LPK], s_l[4][LPK], s_acc[4][LPK][KPL];
+  __shared__ float s_m[NW][LPK], s_l[NW][LPK], s_acc[NW][LPK][KPL];
 
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -311,12 +313,12 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs a) {
   if (tid < LPK) {
     float M = s_m[0][tid];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) M = fmaxf(M, s_m[w][tid]);
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, s_m[w][tid]);
     float L = 0.f, o[KPL];
 #pragma unroll
     for (int j = 0; j < KPL; ++j) o[j] = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const float c = expf(s_m[w][tid] - M);
       L += s_l[w][tid] * c;
 #pragma unroll
@@ -341,16 +343,31 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
   if (!a.step && (a.n_keys <= 0 || a.n_keys > a.cap)) return mt3::fail(MT3_ERR_INVALID, "decode_attention: n_keys");
   const bool append = a.new_k != nullptr;
   if (append && !a.new_v) return mt3::fail(MT3_ERR_INVALID, "decode_attention: new_k without new_v");
-  const dim3 grid(a.B * a.H), block(256);
+  // waves per (batch, head) workgroup.  B*H workgroups must all be resident for an even HBM stream:
+  // at 84 VGPRs a CU holds 20 waves, so 3 waves per workgroup keeps B*H = 1536 groups (4608 waves)
+  // co-resident on 256 CUs, while 4 would leave a 256-group second round running at 1/5 occupancy.
+  static const int nw = [] {
+    const char* v = getenv("MT3_DEC_ATTN_WAVES");
+    const int n = v ? atoi(v) : 3;
+    return (n == 2 || n == 3 || n == 4) ? n : 3;
+  }();
+  const dim3 grid(a.B * a.H), block(nw * 64);
+#define MT3_LAUNCH_DEC(CT, AP)                                                                    \
+  do {                                                                                            \
+    if (nw == 2) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 2>), grid, block, 0, s, a);          \
+    else if (nw == 3) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 3>), grid, block, 0, s, a);     \
+    else hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 4>), grid, block, 0, s, a);                  \
+  } while (0)
   if (dtype == MT3_BF16) {
-    if (append) hipLaunchKernelGGL((dec_attn_kernel<__bf16, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((dec_attn_kernel<__bf16, false>), grid, block, 0, s, a);
+    if (append) MT3_LAUNCH_DEC(__bf16, true);
+    else MT3_LAUNCH_DEC(__bf16, false);
   } else if (dtype == MT3_F32) {
-    if (append) hipLaunchKernelGGL((dec_attn_kernel<float, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((dec_attn_kernel<float, false>), grid, block, 0, s, a);
+    if (append) MT3_LAUNCH_DEC(float, true);
+    else MT3_LAUNCH_DEC(float, false);
   } else {
     return mt3::fail(MT3_ERR_INVALID, "decode_attention: unknown dtype");
   }
+#undef MT3_LAUNCH_DEC
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }
