@@ -189,3 +189,49 @@ def test_inference_model_end_to_end():
     assert got == ref.as_tuples() and ns.total_time == ref.total_time
     with pytest.raises(ValueError):
         inference.InferenceModel("random:0", "nope")
+
+
+def test_ismir2021_preset_and_base_shape():
+    """The other reference presets: ismir2021 (T = 512 frames, 127 velocity bins, vocab 1664,
+    NoteEncodingSpec) end to end, and the ismir2022/base.gin shape (emb 768, 12 heads, 12+12 layers,
+    mlp 2048) encoder + first decode steps against the oracle (bf16 tolerances)."""
+    from mt3_amd import inference
+    from oracle import symbolic as S
+    audio = OF.synth_audio(5, seed=9).reshape(-1)[: 2 * 65536 + 7000]        # 2 full 4.096 s segments + a short one
+    m = inference.InferenceModel("random:1", "ismir2021", batch_size=2, early_exit=False)
+    assert m.inputs_length == 512 and m.model_config.vocab_size == 1664
+    assert m.codec.num_classes == 1514 and m.vocabulary.vocab_size == 1617
+    ns = m(audio)
+    ex = m.preprocess(m.audio_to_dataset(audio))
+    assert [e["inputs"].shape[0] for e in ex[:2]] == [512, 512] and len(ex) == 3
+    feats = np.zeros((3, 512, 512), np.float32)
+    for i, e in enumerate(ex):
+        feats[i, : e["inputs"].shape[0]] = e["inputs"]
+    toks = m.predict_tokens({"encoder_input_tokens": feats})
+    preds = [m.postprocess(t, e) for t, e in zip(toks, ex)]
+    assert abs(preds[1]["start_time"] - 4.09) < 1e-9                       # 4.096 floored to the 10 ms grid
+    ref = S.event_predictions_to_ns(preds, S.build_codec(S.VocabularyConfig(num_velocity_bins=127)), "notes")["est_ns"]
+    got = [(n.start_time, n.end_time, n.pitch, n.velocity, n.program, n.is_drum, n.instrument) for n in ns.notes]
+    assert got == ref.as_tuples()
+    # engine vs oracle at T = 512 (bf16)
+    params = network.init_random_params(m.model_config, seed=1)
+    orc = _oracle(m.model_config, params)
+    enc_ref = orc.encode(feats[:2]).numpy()
+    enc = m.model.encode(torch.from_numpy(feats[:2]).cuda(), return_encoded=True).cpu().numpy()
+    assert rel(enc, enc_ref) < 2e-2
+    del m
+    # ismir2022/base.gin shape
+    base = network.T5Config(**{**{f: getattr(network.MT3_BASE, f) for f in network.MT3_BASE.__dataclass_fields__},
+                               "dtype": "bfloat16"})
+    pb = network.init_random_params(base, seed=2, norm_scale_jitter=0.1)
+    assert sum(v.size for v in pb.values()) == 200_980_992                  # SURVEY A.3
+    eng = network.Transformer(base, input_length=T, max_decode_length=L, max_batch=2)
+    eng.load_params(pb)
+    x = _inputs(2, seed=4)
+    enc = eng.encode(torch.from_numpy(x).cuda(), return_encoded=True).cpu().numpy()
+    ids, logits0 = eng.decode(num_steps=4, return_first_logits=True)
+    ob = _oracle(base, pb)
+    enc_ref = ob.encode(x)
+    _, lref = ob.greedy_decode(enc_ref, 1, return_logits=True)
+    assert rel(enc, enc_ref.numpy()) < 3e-2, rel(enc, enc_ref.numpy())
+    assert rel(logits0.cpu().numpy(), lref[:, 0].numpy()) < 4e-2
