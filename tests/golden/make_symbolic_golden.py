@@ -252,6 +252,41 @@ def main():
                        int(n.program), bool(n.is_drum), int(n.instrument)] for n in ens.notes],
         })
     out["decode_cases"] = cases
+
+    # ---- encode side (N2): the reference's encode_and_index_events on random note sets
+    enc_cases = []
+    for case_id in range(12):
+        mode = ("ties", "notes", "onsets")[case_id % 3]
+        bins = 1 if mode == "ties" else 127
+        codec = vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=bins))
+        spec = specs[mode]
+        total = float(rng.uniform(1.0, 5.0))
+        notes = []
+        for _ in range(int(rng.integers(1, 25))):
+            st = round(float(rng.uniform(0, total - 0.05)), int(rng.integers(2, 5)))
+            en = round(float(min(total, st + rng.uniform(0.0, 2.0))), int(rng.integers(2, 5)))
+            drum = bool(mode == "ties" and rng.random() < 0.2)
+            notes.append(dict(start_time=st, end_time=max(en, st), pitch=int(rng.integers(21, 109)),
+                              velocity=int(rng.integers(1, 128)),
+                              program=0 if mode != "ties" or drum else int(rng.choice([0, 24, 40])), is_drum=drum))
+        ns = _NoteSequence(ticks_per_quarter=220)
+        for n in notes:
+            ns.notes.add(**n)
+        if mode == "onsets":
+            times, values = note_sequences.note_sequence_to_onsets(ns)
+        elif mode == "notes":
+            times, values = note_sequences.note_sequence_to_onsets_and_offsets(ns)
+        else:
+            times, values = note_sequences.note_sequence_to_onsets_and_offsets_and_programs(ns)
+        frame_times = np.arange(int(total * 125) + 1) / 125.0
+        ev, es, ee, se, si = run_length_encoding.encode_and_index_events(
+            state=spec.init_encoding_state_fn(), event_times=times, event_values=values,
+            encode_event_fn=spec.encode_event_fn, codec=codec, frame_times=frame_times,
+            encoding_state_to_events_fn=spec.encoding_state_to_events_fn)
+        enc_cases.append({"mode": mode, "num_velocity_bins": bins, "notes": notes, "n_frames": len(frame_times),
+                          "events": [int(x) for x in ev], "start": [int(x) for x in es], "end": [int(x) for x in ee],
+                          "state_events": [int(x) for x in se], "state_idx": [int(x) for x in si]})
+    out["encode_cases"] = enc_cases
     with open(OUT, "w") as f:
         json.dump(out, f, separators=(",", ":"))
     print("wrote", OUT, os.path.getsize(OUT), "bytes;", len(cases), "cases;",
