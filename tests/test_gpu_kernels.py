@@ -113,7 +113,8 @@ def test_gemm_geglu(dtype, small):
 
 
 @pytest.mark.parametrize("dtype", [BF16, F32])
-def test_gemm_pos_and_heads(dtype):
+@pytest.mark.parametrize("small", [False, True])
+def test_gemm_pos_and_heads(dtype, small):
     B, T, K, N = 3, 256, 512, 512
     M = B * T
     g = torch.Generator(device="cuda").manual_seed(11)
@@ -122,7 +123,7 @@ def test_gemm_pos_and_heads(dtype):
     Wt = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(ct)
     pos = torch.randn(T, N, device="cuda", generator=g)
     out = torch.zeros(M, N, device="cuda")
-    run_gemm(dtype, x, True, False, Wt, out, M, N, K, _lib.EPI_POS, aux=pos, seq_len=T)
+    run_gemm(dtype, x, True, False, Wt, out, M, N, K, _lib.EPI_POS, aux=pos, seq_len=T, small=small)
     ref = x.to(ct).double() @ Wt.double().T + pos.double().repeat(B, 1)
     assert rel_err(out, ref) < 2e-5
     # HEADS: N = 2*H*64 -> [2][B][H][T][64]
@@ -131,7 +132,7 @@ def test_gemm_pos_and_heads(dtype):
     A = torch.randn(M, K, device="cuda", generator=g).to(ct)
     W2 = (torch.randn(N2, K, device="cuda", generator=g) / math.sqrt(K)).to(ct)
     o2 = torch.zeros(2, B, H, T, 64, device="cuda", dtype=ct)
-    run_gemm(dtype, A, False, False, W2, o2, M, N2, K, _lib.EPI_HEADS, seq_len=T)
+    run_gemm(dtype, A, False, False, W2, o2, M, N2, K, _lib.EPI_HEADS, seq_len=T, small=small)
     r2 = (A.double() @ W2.double().T).view(B, T, 2, H, 64).permute(2, 0, 3, 1, 4)
     assert rel_err(o2, r2) < (6e-3 if dtype == BF16 else 2e-5)
 
