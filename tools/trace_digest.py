@@ -13,20 +13,30 @@ if not files:
 rows = []
 with open(files[0]) as f:
     for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+                     int(r.get("Grid_Size", 0) or 0), int(r.get("Workgroup_Size", 0) or 0)))
 rows.sort()
 tot = defaultdict(lambda: [0, 0.0])
-for s, e, n in rows:
+for s, e, n, _, _ in rows:
     tot[n][0] += 1
     tot[n][1] += (e - s) / 1e3
 allus = sum(v[1] for v in tot.values())
 print("kernel,calls,total_us,avg_us,pct")
 for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:24]:
     print("%s,%d,%.1f,%.3f,%.2f" % (n[:110].replace(",", ";"), c, us, us / c, 100 * us / allus))
-for key in ("Lb1EEEvNS_11DecAttnArgs", "Lb0EEEvNS_11DecAttnArgs", "dec_attn_kernel"):
-    d = [(e - s) / 1e3 for s, e, n in rows if key in n]
-    if len(d) >= 8192:
-        one = d[:8192]
+# decode attention by launch geometry: the timed passes of bench.py may deal the batch to 2 chains
+# (half-batch launches on parallel graph branches), the roofline passes always launch the full batch
+# (B*H workgroups = the largest grid); the roofline's avg_launch_us must agree with the latter.
+groups = defaultdict(list)
+for s, e, n, grid, wg in rows:
+    if "dec_attn_kernel" in n:
+        kind = "cross(no append)" if "Lb0E" in n else "self(append)"
+        groups[(kind, grid // max(wg, 1))].append((e - s) / 1e3)
+for (kind, wgs), d in sorted(groups.items()):
+    line = "dec_attn %s, %d workgroups: %d launches, avg %.3f us" % (kind, wgs, len(d), sum(d) / len(d))
+    if len(d) >= 8192 and len(d) % 8192 == 0:
+        one = d[-8192:]
         per = [sum(one[i * 8:(i + 1) * 8]) / 8 for i in range(1024)]
-        print(key, "first decode pass: avg us per launch at t=0,15,63,127,255,511,767,1023:",
-              [round(per[i], 1) for i in (0, 15, 63, 127, 255, 511, 767, 1023)], "mean", round(sum(per) / 1024, 2))
+        line += "; last pass by step t=0,15,63,127,255,511,767,1023: %s" % [round(per[i], 1) for i in
+                                                                            (0, 15, 63, 127, 255, 511, 767, 1023)]
+    print(line)
