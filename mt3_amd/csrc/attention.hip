@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPK, slot = lane / LPK;
-  const int n_keys = a.step ? (*a.step + 1) : a.n_keys;
+  const int n_keys = a.step ? (a.step[b] + 1) : a.n_keys;      // per-row position counter
   const int pos = n_keys - 1;
 
   const CT* kc = static_cast<const CT*>(a.kcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;

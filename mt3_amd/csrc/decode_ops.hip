@@ -7,8 +7,8 @@
 //                       + FixedEmbed decode slice pos[t] (layers.py:589-596).
 //   argmax_step_kernel  greedy pick of the step (lowest id on ties), EOS bookkeeping, writes
 //                       ids[b][t]; rows that already emitted EOS get 0 (pad).
-//                       The last block to arrive also does t += 1 in device memory, so ONE captured
-//                       hipGraph serves every step.
+//                       Positions are PER-ROW device counters (no cross-row sync), so ONE captured
+//                       hipGraph serves every step; the block also writes the next step's embedding row.
 //   ids_to_tokens_kernel GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271), bit-exact.
 #include <hip/hip_runtime.h>
 
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(128) void embed_kernel(const float* __restrict__ ta
                                                      float* __restrict__ y, int dim) {
   const int b = blockIdx.x;
   const float* e = table + static_cast<size_t>(tok[b]) * dim;
-  const float* p = pos + static_cast<size_t>(*step) * dim;
+  const float* p = pos + static_cast<size_t>(step[b]) * dim;
   for (int i = threadIdx.x * 4; i < dim; i += 512) {
     const float4 a = *reinterpret_cast<const float4*>(e + i), c = *reinterpret_cast<const float4*>(p + i);
     *reinterpret_cast<float4*>(y + static_cast<size_t>(b) * dim + i) = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
@@ -85,9 +85,13 @@ int launch_embed(const float* table, const float* pos, const int* tok, const int
 __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restrict__ logits, int vocab,
                                                            int* __restrict__ ids, int ids_stride,
                                                            int* __restrict__ cur_tok, int* __restrict__ done,
-                                                           int* __restrict__ n_done, int* step, int* arrive) {
+                                                           int* __restrict__ n_done, int* __restrict__ step,
+                                                           const float* __restrict__ table,
+                                                           const float* __restrict__ pos_table, int max_pos,
+                                                           float* __restrict__ y_next, int dim) {
   __shared__ float s_v[4];
   __shared__ int s_i[4];
+  __shared__ int s_tok, s_t;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = logits + static_cast<size_t>(b) * vocab;
   float best = -3.0e38f;
@@ -122,25 +126,36 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
       }
     const int was_done = done[b];
     const int tok = was_done ? 0 : bi;
-    ids[static_cast<size_t>(b) * ids_stride + *step] = tok;
+    const int t = step[b];                // this row's own position counter: no cross-row synchronisation
+    ids[static_cast<size_t>(b) * ids_stride + t] = tok;
     cur_tok[b] = tok;
+    step[b] = t + 1;
     if (!was_done && tok == 1) {          // EOS
       done[b] = 1;
       atomicAdd(n_done, 1);
     }
-    // every row has consumed *step once its block arrives here; the last arriver advances the step
-    // (device-memory step counter: the SAME captured graph serves every decode step)
-    if (atomicAdd(arrive, 1) == static_cast<int>(gridDim.x) - 1) {
-      *arrive = 0;
-      *step = *step + 1;
+    s_tok = tok;
+    s_t = t + 1;
+  }
+  __syncthreads();
+  // the next step's decoder input row: Embed(tok) + FixedEmbed[t+1]  (saves the embed launch of every step)
+  if (y_next) {
+    const int tp = s_t < max_pos ? s_t : max_pos - 1;
+    const float* e = table + static_cast<size_t>(s_tok) * dim;
+    const float* p = pos_table + static_cast<size_t>(tp) * dim;
+    for (int i = tid * 4; i < dim; i += 1024) {
+      const float4 a = *reinterpret_cast<const float4*>(e + i), c = *reinterpret_cast<const float4*>(p + i);
+      *reinterpret_cast<float4*>(y_next + static_cast<size_t>(b) * dim + i) =
+          make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
     }
   }
 }
 
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
-                       int* n_done, int* step, int* arrive, int B, hipStream_t s) {
+                       int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
+                       float* y_next, int dim, int B, hipStream_t s) {
   hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok, done,
-                     n_done, step, arrive);
+                     n_done, step, table, pos_table, max_pos, y_next, dim);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

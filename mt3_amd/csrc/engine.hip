@@ -16,7 +16,8 @@
 //     them inside every decode step unless XLA hoists them.
 //   * the self-attention cache is [B][H][L][64] written in place at position t (the reference
 //     rewrites the whole [B,H,64,L] cache per step: layers.py:272-292).
-//   * one decode step = 8 x 8 + 3 kernels with the step index in DEVICE memory, captured once per
+//   * one decode step = 8 x 8 + 2 kernels with per-row position counters in DEVICE memory (the argmax
+//     kernel also writes the next step's embedding row), captured once per
 //     batch size into a hipGraph and replayed L times.  The batch is dealt to `decode_chains`
 //     independent row groups, one graph BRANCH each (fork/join capture over several streams): the
 //     small-M GEMMs are latency-bound and the attention kernels HBM-bound, so concurrent branches
@@ -102,7 +103,6 @@ struct mt3_engine {
   int* done = nullptr;
   int* step = nullptr;
   int* n_done = nullptr;
-  int* arrive = nullptr;
   int* h_pinned = nullptr;
 
   int cur_batch = 0;             // batch of the last encode
@@ -261,9 +261,10 @@ int enqueue_chain_step(mt3_engine* e, int row0, int rows, int chain, int B_total
   char* q_d = static_cast<char*>(e->q_d) + static_cast<size_t>(row0) * hd * es;
   char* h_d = static_cast<char*>(e->h_d) + static_cast<size_t>(row0) * c.mlp_dim * es;
   float* logits = e->logits + static_cast<size_t>(row0) * c.vocab_size;
-  int* step = e->step + chain;
-  int* arrive = e->arrive + chain;
-  MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok + row0, step, y, rows, emb, s));
+  (void)chain;
+  int* step = e->step + row0;                    // per-row position counters
+  // the decoder input row of this step (Embed(tok) + FixedEmbed[t]) is already in `y`: written by the
+  // embed launch before the first step and by the previous step's argmax kernel afterwards
   for (int l = 0; l < c.num_decoder_layers; ++l) {
     LayerDev& L = e->dec[l];
     MT3_TRY(mt3k::launch_gemm(dt, gemm_args(y, L.wqkv, qkv_d, rows, 3 * hd, emb, 3 * hd), true, true, MT3_EPI_STORE,
@@ -306,7 +307,8 @@ int enqueue_chain_step(mt3_engine* e, int row0, int rows, int chain, int B_total
   MT3_TRY(mt3k::launch_gemm(dt, gemm_args(y, e->logits_w, logits, rows, c.vocab_size, emb, c.vocab_size), true, true,
                             MT3_EPI_F32, small, s));
   MT3_TRY(mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
-                                   e->cur_tok + row0, e->done + row0, e->n_done, step, arrive, rows, s));
+                                   e->cur_tok + row0, e->done + row0, e->n_done, step, e->embedding, e->pos_table,
+                                   kMaxPos, y, emb, rows, s));
   return MT3_OK;
 }
 
@@ -532,9 +534,8 @@ int mt3_engine_finalize(mt3_engine* e) {
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->ids), static_cast<size_t>(Bm) * L * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->cur_tok), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->done), static_cast<size_t>(Bm) * 4))) return rc;
-  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->step), 4 * kMaxChains))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->step), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->n_done), 4))) return rc;
-  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->arrive), 4 * kMaxChains))) return rc;
   MT3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned), 64, hipHostMallocDefault));
   e->raw.clear();
   e->finalized = true;
@@ -588,12 +589,13 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: num_steps out of range or null ids");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = c.max_decode_len;
-  MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, 4 * kMaxChains, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, static_cast<size_t>(batch) * 4, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->n_done, 0, 4, s));
-  MT3_HIP_CHECK(hipMemsetAsync(e->arrive, 0, 4 * kMaxChains, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->done, 0, static_cast<size_t>(batch) * 4, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->cur_tok, 0, static_cast<size_t>(batch) * 4, s));     // BOS = 0
   MT3_HIP_CHECK(hipMemsetAsync(e->ids, 0, static_cast<size_t>(batch) * L * 4, s));
+  // decoder input of step 0: Embed(BOS) + FixedEmbed[0]; later steps get theirs from the argmax kernel
+  MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y, batch, c.emb_dim, s));
 
   // profiling-only variants: leave the self (1) / cross (2) attention launches out of the step, so that
   // their in-situ cost can be read as a DIFFERENCE of whole-decode times (results are garbage)

@@ -33,7 +33,7 @@ struct DecAttnArgs {
   const void* new_k;    // [B, kv_stride] rows; head h at +h*64 (NULL: no append)
   const void* new_v;
   int kv_stride;
-  const int* step;      // device: n_keys = *step + 1 (NULL: use n_keys)
+  const int* step;      // device, per row: n_keys = step[b] + 1 (NULL: use n_keys)
   int n_keys;
   void* out;            // [B, H*64] compute type
   int B, H;
@@ -43,12 +43,13 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s);
 // out_ct[row] = x[row] * rsqrt(mean(x^2)+eps) * scale ; optional f32 copy
 int launch_rmsnorm(int dtype, const float* x, const float* scale, void* out_ct, float* out_f32, int rows, int dim,
                    hipStream_t s);
-// y[b] = table[tok[b]] + pos[*step]
+// y[b] = table[tok[b]] + pos[step[b]]
 int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, int B, int dim,
                  hipStream_t s);
 // greedy pick + bookkeeping for one decode step (see decode_ops.hip)
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
-                       int* n_done, int* step, int* arrive, int B, hipStream_t s);
+                       int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
+                       float* y_next, int dim, int B, hipStream_t s);
 int launch_ids_to_tokens(const int* ids, int B, int L, int num_regular, int* out, hipStream_t s);
 
 }  // namespace mt3k

@@ -167,7 +167,7 @@ def test_decode_attention_append(dtype, n_keys):
     qkv = torch.randn(B, 3 * H * 64, device="cuda", generator=g)
     qkv[:, : H * 64] *= 0.35
     qkv = qkv.to(ct)
-    step = torch.tensor([n_keys - 1], device="cuda", dtype=torch.int32)
+    step = torch.full((B,), n_keys - 1, device="cuda", dtype=torch.int32)      # per-row position counters
     out = torch.zeros(B, H * 64, device="cuda", dtype=ct)
     kc0, vc0 = kc.clone(), vc.clone()
     es = qkv.element_size()
