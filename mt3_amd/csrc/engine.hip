@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -249,66 +250,95 @@ mt3k::GemmArgs gemm_args(const void* A, const void* Wt, void* out, int M, int N,
 // `e->chains` such chains; they are data-independent (a segment never looks at another segment), so
 // the step graph has one branch per chain and the GPU overlaps one chain's latency-bound GEMMs with
 // another chain's HBM-bound attention streams.  Every row-indexed workspace is simply offset.
-int enqueue_chain_step(mt3_engine* e, int row0, int rows, int chain, int B_total, int skip, hipStream_t s) {
+// Op `op` of the decode step of rows [row0, row0 + rows): per decoder layer 8 ops
+//   0 QKV GEMM (fused RMSNorm)   1 self-attention (+cache append)   2 out-proj + residual
+//   3 q-proj (fused RMSNorm)     4 cross-attention                  5 out-proj + residual
+//   6 GEGLU GEMM (fused RMSNorm) 7 wo + residual
+// then  8*L: logits GEMM (fused decoder_norm),  8*L + 1: argmax / EOS / position += 1 / next input row.
+// Ops 1 and 4 are the HBM-streaming ("heavy") ones; everything else is latency-bound.
+inline int chain_num_ops(const mt3_engine* e) { return 8 * e->cfg.num_decoder_layers + 2; }
+inline bool chain_op_is_heavy(const mt3_engine* e, int op) {
+  return op < 8 * e->cfg.num_decoder_layers && ((op & 7) == 1 || (op & 7) == 4);
+}
+
+int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, int op, hipStream_t s) {
   const mt3_engine_config& c = e->cfg;
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), H = c.num_heads, T = c.input_length;
   const int Lmax = c.max_decode_len;
   const size_t es = e->esize;
   const bool small = true;
+  // the decoder input row of this step (Embed(tok) + FixedEmbed[t]) is already in `y`: written by the
+  // embed launch before the first step and by the previous step's argmax kernel afterwards
   float* y = e->y + static_cast<size_t>(row0) * emb;
   char* qkv_d = static_cast<char*>(e->qkv_d) + static_cast<size_t>(row0) * 3 * hd * es;
   char* attn_d = static_cast<char*>(e->attn_d) + static_cast<size_t>(row0) * hd * es;
   char* q_d = static_cast<char*>(e->q_d) + static_cast<size_t>(row0) * hd * es;
   char* h_d = static_cast<char*>(e->h_d) + static_cast<size_t>(row0) * c.mlp_dim * es;
   float* logits = e->logits + static_cast<size_t>(row0) * c.vocab_size;
-  (void)chain;
   int* step = e->step + row0;                    // per-row position counters
-  // the decoder input row of this step (Embed(tok) + FixedEmbed[t]) is already in `y`: written by the
-  // embed launch before the first step and by the previous step's argmax kernel afterwards
-  for (int l = 0; l < c.num_decoder_layers; ++l) {
-    LayerDev& L = e->dec[l];
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(y, L.wqkv, qkv_d, rows, 3 * hd, emb, 3 * hd), true, true, MT3_EPI_STORE,
-                              small, s));
-    mt3k::DecAttnArgs a{};
-    a.q = qkv_d;
-    a.q_stride = 3 * hd;
-    a.kcache = static_cast<char*>(L.self_k) + static_cast<size_t>(row0) * H * Lmax * 64 * es;
-    a.vcache = static_cast<char*>(L.self_v) + static_cast<size_t>(row0) * H * Lmax * 64 * es;
-    a.cap = Lmax;
-    a.new_k = qkv_d + static_cast<size_t>(hd) * es;
-    a.new_v = qkv_d + static_cast<size_t>(2 * hd) * es;
-    a.kv_stride = 3 * hd;
-    a.step = step;
-    a.out = attn_d;
-    a.B = rows;
-    a.H = H;
-    if (!(skip & 1)) MT3_TRY(mt3k::launch_decode_attention(dt, a, s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(attn_d, L.wo, y, rows, emb, hd, emb), false, false, MT3_EPI_RESID, small,
-                              s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(y, L.wq_x, q_d, rows, hd, emb, hd), true, true, MT3_EPI_STORE, small, s));
-    mt3k::DecAttnArgs x{};
-    x.q = q_d;
-    x.q_stride = hd;
-    x.kcache = static_cast<char*>(L.cross_kv) + static_cast<size_t>(row0) * H * T * 64 * es;
-    x.vcache = static_cast<char*>(L.cross_kv) + (static_cast<size_t>(B_total) + row0) * H * T * 64 * es;
-    x.cap = T;
-    x.n_keys = T;
-    x.out = attn_d;
-    x.B = rows;
-    x.H = H;
-    if (!(skip & 2)) MT3_TRY(mt3k::launch_decode_attention(dt, x, s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(attn_d, L.wo_x, y, rows, emb, hd, emb), false, false, MT3_EPI_RESID, small,
-                              s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(y, L.wi, h_d, rows, 2 * c.mlp_dim, emb, c.mlp_dim), true, true,
-                              MT3_EPI_GEGLU, small, s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(h_d, L.wo_mlp, y, rows, emb, c.mlp_dim, emb), false, false, MT3_EPI_RESID,
-                              small, s));
+  const int nl = c.num_decoder_layers;
+  if (op == 8 * nl)
+    return mt3k::launch_gemm(dt, gemm_args(y, e->logits_w, logits, rows, c.vocab_size, emb, c.vocab_size), true, true,
+                             MT3_EPI_F32, small, s);
+  if (op == 8 * nl + 1)
+    return mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
+                                    e->cur_tok + row0, e->done + row0, e->n_done, step, e->embedding, e->pos_table,
+                                    kMaxPos, y, emb, rows, s);
+  LayerDev& L = e->dec[op >> 3];
+  switch (op & 7) {
+    case 0:
+      return mt3k::launch_gemm(dt, gemm_args(y, L.wqkv, qkv_d, rows, 3 * hd, emb, 3 * hd), true, true, MT3_EPI_STORE,
+                               small, s);
+    case 1: {
+      if (skip & 1) return MT3_OK;
+      mt3k::DecAttnArgs a{};
+      a.q = qkv_d;
+      a.q_stride = 3 * hd;
+      a.kcache = static_cast<char*>(L.self_k) + static_cast<size_t>(row0) * H * Lmax * 64 * es;
+      a.vcache = static_cast<char*>(L.self_v) + static_cast<size_t>(row0) * H * Lmax * 64 * es;
+      a.cap = Lmax;
+      a.new_k = qkv_d + static_cast<size_t>(hd) * es;
+      a.new_v = qkv_d + static_cast<size_t>(2 * hd) * es;
+      a.kv_stride = 3 * hd;
+      a.step = step;
+      a.out = attn_d;
+      a.B = rows;
+      a.H = H;
+      return mt3k::launch_decode_attention(dt, a, s);
+    }
+    case 2:
+      return mt3k::launch_gemm(dt, gemm_args(attn_d, L.wo, y, rows, emb, hd, emb), false, false, MT3_EPI_RESID, small, s);
+    case 3:
+      return mt3k::launch_gemm(dt, gemm_args(y, L.wq_x, q_d, rows, hd, emb, hd), true, true, MT3_EPI_STORE, small, s);
+    case 4: {
+      if (skip & 2) return MT3_OK;
+      mt3k::DecAttnArgs x{};
+      x.q = q_d;
+      x.q_stride = hd;
+      x.kcache = static_cast<char*>(L.cross_kv) + static_cast<size_t>(row0) * H * T * 64 * es;
+      x.vcache = static_cast<char*>(L.cross_kv) + (static_cast<size_t>(B_total) + row0) * H * T * 64 * es;
+      x.cap = T;
+      x.n_keys = T;
+      x.out = attn_d;
+      x.B = rows;
+      x.H = H;
+      return mt3k::launch_decode_attention(dt, x, s);
+    }
+    case 5:
+      return mt3k::launch_gemm(dt, gemm_args(attn_d, L.wo_x, y, rows, emb, hd, emb), false, false, MT3_EPI_RESID, small,
+                               s);
+    case 6:
+      return mt3k::launch_gemm(dt, gemm_args(y, L.wi, h_d, rows, 2 * c.mlp_dim, emb, c.mlp_dim), true, true,
+                               MT3_EPI_GEGLU, small, s);
+    default:
+      return mt3k::launch_gemm(dt, gemm_args(h_d, L.wo_mlp, y, rows, emb, c.mlp_dim, emb), false, false, MT3_EPI_RESID,
+                               small, s);
   }
-  MT3_TRY(mt3k::launch_gemm(dt, gemm_args(y, e->logits_w, logits, rows, c.vocab_size, emb, c.vocab_size), true, true,
-                            MT3_EPI_F32, small, s));
-  MT3_TRY(mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
-                                   e->cur_tok + row0, e->done + row0, e->n_done, step, e->embedding, e->pos_table,
-                                   kMaxPos, y, emb, rows, s));
+}
+
+int enqueue_chain_step(mt3_engine* e, int row0, int rows, int chain, int B_total, int skip, hipStream_t s) {
+  (void)chain;
+  for (int op = 0, n = chain_num_ops(e); op < n; ++op) MT3_TRY(enqueue_chain_op(e, row0, rows, B_total, skip, op, s));
   return MT3_OK;
 }
 
