@@ -44,13 +44,17 @@ __device__ __forceinline__ void gemm_load_tiles(u32x4 (&a_reg)[A_PASSES], u32x4 
         const float4 u = src[0], v = src[1];
         const float f[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
         if constexpr (NORM) {
+          // explicit FMA chain: every row must see the SAME rounding sequence whichever unrolled pass
+          // (= row position inside the tile) handles it -- results are bit-identical under a permutation
+          // of the batch (left to the compiler, some passes were contracted to FMA and others not)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) ss[p] += f[i] * f[i];
+          for (int i = 0; i < 8; ++i) ss[p] = __builtin_fmaf(f[i], f[i], ss[p]);
         }
         a_reg[p] = pack_bf16x8(f);
       } else {
         const float4 u = src[0];
-        if constexpr (NORM) ss[p] += u.x * u.x + u.y * u.y + u.z * u.z + u.w * u.w;
+        if constexpr (NORM)
+          ss[p] = __builtin_fmaf(u.w, u.w, __builtin_fmaf(u.z, u.z, __builtin_fmaf(u.y, u.y, __builtin_fmaf(u.x, u.x, ss[p]))));
         a_reg[p] = pack_f32x4(u.x, u.y, u.z, u.w);
       }
     } else {
