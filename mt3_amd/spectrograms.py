@@ -24,14 +24,10 @@ class SpectrogramConfig:
 
     @property
     def abbrev_str(self):
-        s = ""
-        if self.sample_rate != DEFAULT_SAMPLE_RATE:
-            s += "sr%d" % self.sample_rate
-        if self.hop_width != DEFAULT_HOP_WIDTH:
-            s += "hw%d" % self.hop_width
-        if self.num_mel_bins != DEFAULT_NUM_MEL_BINS:
-            s += "mb%d" % self.num_mel_bins
-        return s
+        """Suffix naming the non-default fields (used by the reference in task names)."""
+        tags = (("sr", self.sample_rate, DEFAULT_SAMPLE_RATE), ("hw", self.hop_width, DEFAULT_HOP_WIDTH),
+                ("mb", self.num_mel_bins, DEFAULT_NUM_MEL_BINS))
+        return "".join("%s%d" % (k, v) for k, v, default in tags if v != default)
 
     @property
     def frames_per_second(self):
