@@ -14,7 +14,8 @@ rows = []
 with open(files[0]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
-                     int(r.get("Grid_Size", 0) or 0), int(r.get("Workgroup_Size", 0) or 0)))
+                     int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0),
+                     int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0)))
 rows.sort()
 tot = defaultdict(lambda: [0, 0.0])
 for s, e, n, _, _ in rows:
