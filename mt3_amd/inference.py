@@ -24,6 +24,7 @@ from typing import Any, Dict, List, Optional, Sequence
 import numpy as np
 
 from . import metrics_utils
+from . import models
 from . import network
 from . import note_sequences
 from . import spectrograms
@@ -116,11 +117,8 @@ class InferenceModel(object):
         """1-d numpy array of 16 kHz samples -> NoteSequence."""
         ds = self.audio_to_dataset(audio)
         examples = self.preprocess(ds)
-        T = self.inputs_length
-        feats = np.zeros((len(examples), T, self.spectrogram_config.num_mel_bins), np.float32)
-        for i, ex in enumerate(examples):              # feature converter: pad/trim to [T, 512]
-            feats[i, : ex["inputs"].shape[0]] = ex["inputs"][:T]
-        tokens = self.predict_tokens({"encoder_input_tokens": feats})
+        batch = models.convert_features(examples, self.sequence_length)     # pad/trim to [T, 512] / [1024]
+        tokens = self.predict_tokens(batch)
         predictions = [self.postprocess(t, ex) for t, ex in zip(tokens, examples)]
         result = metrics_utils.event_predictions_to_ns(predictions, codec=self.codec,
                                                        encoding_spec=self.encoding_spec)
