@@ -39,6 +39,17 @@ constexpr int kTileSamples = kFramesPerBlock * kHop + (mt3fe::kFft - kHop);   //
 constexpr int kWaves = 4;
 constexpr int kMelBins = 512;
 constexpr int kMagStride = 1028;
+constexpr int kMaxBandWeights = 2048;       // >= sum of band lengths (1934 for the reference's mel matrix)
+
+// The 4 waves of a workgroup work on different frames and only meet at the initial staging barrier;
+// inside the frame loop every LDS hand-off is between lanes of ONE wave (private xchg / mag regions).
+// A wave executes its LDS instructions in order, so it suffices to (a) wait for the wave's own
+// outstanding LDS writes and (b) stop the compiler from moving LDS accesses across the point.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
 struct FrontendDev {
   const float* hann;
@@ -48,6 +59,7 @@ struct FrontendDev {
   const int* cnt;
   const int* off;
   const float* w;
+  int n_w;
 };
 
 __global__ __launch_bounds__(256) void logmel_kernel(FrontendDev t, const float* __restrict__ audio,
@@ -56,6 +68,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(FrontendDev t, const float*
   __shared__ __attribute__((aligned(16))) float s_samples[kTileSamples];
   __shared__ __attribute__((aligned(16))) cpx s_xchg[kWaves][mt3fe::kXchg];   // also holds Z in natural order
   __shared__ __attribute__((aligned(16))) float s_mag[kWaves][kMagStride];
+  __shared__ int s_k0[kMelBins], s_cnt[kMelBins], s_off[kMelBins];      // band tables: read per frame
+  __shared__ float s_w[kMaxBandWeights];
 
   const int tiles = frames_per_segment / kFramesPerBlock;
   const int seg = blockIdx.x / tiles;
@@ -72,9 +86,15 @@ __global__ __launch_bounds__(256) void logmel_kernel(FrontendDev t, const float*
     if (idx < valid) v = *reinterpret_cast<const float4*>(seg_audio + idx);
     *reinterpret_cast<float4*>(&s_samples[4 * i]) = v;
   }
+  for (int i = tid; i < kMelBins; i += 256) {
+    s_k0[i] = t.k0[i];
+    s_cnt[i] = t.cnt[i];
+    s_off[i] = t.off[i];
+  }
+  for (int i = tid; i < t.n_w; i += 256) s_w[i] = t.w[i];
   mt3fe::LaneConst lc;
   mt3fe::load_lane_const(lc, lane, t.hann, t.tw1024, t.tw2048);
-  const mt3fe::MelTables mel{t.k0, t.cnt, t.off, t.w};
+  const mt3fe::MelTables mel{s_k0, s_cnt, s_off, s_w};
   __syncthreads();
 
   cpx* xchg = s_xchg[wave];
@@ -82,16 +102,16 @@ __global__ __launch_bounds__(256) void logmel_kernel(FrontendDev t, const float*
   for (int r = 0; r < kFramesPerBlock / kWaves; ++r) {
     const int fl = wave + kWaves * r;                            // frame inside the tile
     mt3fe::stage_a(lc, lane, s_samples + fl * kHop, mt3fe::kFft, xchg);
-    __syncthreads();
+    wave_lds_sync();
     mt3fe::stage_b(lc, lane, xchg);
-    __syncthreads();
+    wave_lds_sync();
     cpx z[16];
     mt3fe::stage_c(lane, xchg, z);
-    __syncthreads();
+    wave_lds_sync();
     mt3fe::publish_z(lane, z, xchg);
-    __syncthreads();
+    wave_lds_sync();
     mt3fe::untangle_mag(lc, lane, z, xchg, mag);
-    __syncthreads();
+    wave_lds_sync();
     const int f = f0 + fl;
     float* dst = out + (static_cast<size_t>(seg) * frames_per_segment + f) * kMelBins;
     if (f < n) {
@@ -146,6 +166,10 @@ int mt3_frontend_create(const mt3_frontend_config* cfg, mt3_frontend** out) {
   if (!fe) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
   fe->cfg = *cfg;
   fe->host = mt3fe::build_tables(cfg->sample_rate, cfg->fft_size, cfg->num_mel_bins, cfg->lo_hz, cfg->hi_hz);
+  if (static_cast<int>(fe->host.w.size()) > kMaxBandWeights) {
+    delete fe;
+    return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_create: mel band table too large for the kernel's LDS budget");
+  }
   *out = fe;
   return MT3_OK;
 }
@@ -205,7 +229,7 @@ int mt3_frontend_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segmen
   FrontendDev t{static_cast<const float*>(fe->d_hann), static_cast<const cpx*>(fe->d_tw1024),
                 static_cast<const cpx*>(fe->d_tw2048), static_cast<const int*>(fe->d_k0),
                 static_cast<const int*>(fe->d_cnt),    static_cast<const int*>(fe->d_off),
-                static_cast<const float*>(fe->d_w)};
+                static_cast<const float*>(fe->d_w), static_cast<int>(fe->host.w.size())};
   const int tiles = frames_per_segment / kFramesPerBlock;
   hipLaunchKernelGGL(logmel_kernel, dim3(n_segments * tiles), dim3(256), 0, s, t, d_audio, d_n, frames_per_segment,
                      d_logmel);
