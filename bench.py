@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--chains", type=int, default=2,
                     help="independent row groups run as parallel branches of the step graph (measured on "
                          "MI355X/ROCm 7.2 at batch 256: 1 -> 649, 2 -> 689, 3 -> 666, 4 -> 627, 8 -> 349 audio-s/s)")
+    ap.add_argument("--decoding", default="beam1", choices=["beam1", "greedy"],
+                    help="token selection: t5x beam_search with one beam (what the reference runs) or plain greedy")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-segments", type=int, default=2)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -111,7 +113,7 @@ def main():
         with torch.cuda.stream(stream):
             logmel = spectrograms.compute_spectrogram_batch(audio, None)
             eng.encode(logmel)
-            ids = eng.decode(num_steps=args.decode_steps)
+            ids = eng.decode(num_steps=args.decode_steps, beam1=args.decoding == "beam1")
             tokens = vocab.decode_tf(ids)                                  # CUDA int32 [B, L]
             tokens = distributed.gather_token_rows(tokens, world * B)   # RCCL all-gather (identity at N=1)
             if rank == 0:
@@ -214,7 +216,7 @@ def main():
                                    "exit), hipGraph step replay, ids->tokens + host note decoding included"
                                    % (B, args.decode_steps),
                        "segments_per_gpu": B, "decode_steps": args.decode_steps, "segment_seconds": SEG_SECONDS,
-                       "decode_chains": args.chains,
+                       "decode_chains": args.chains, "decoding": args.decoding,
                        "parallelism": "dp%d (segments sharded, weights replicated, RCCL all-gather of token rows)"
                                       % world if world > 1 else "single GPU",
                        "notes_decoded_last_step": n_notes},

@@ -116,15 +116,24 @@ int64_t mt3_engine_device_bytes(const mt3_engine* e);
 int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch,
                       float* d_encoded_f32, void* stream);
 
-/* Greedy autoregressive decode (BOS=0, EOS=1; ids after a row's EOS are 0).
+/* Autoregressive decode (BOS=0, EOS=1; ids after a row's EOS are 0): the loop t5x
+ * `predict_batch_with_aux` drives over Transformer.decode (network.py:303-343).
+ * Default: greedy until EOS.  MT3_DECODE_BEAM1: the token selection of t5x
+ * `decoding.beam_search` with num_decodes=1, alpha=0.6 (what the reference's
+ * InferenceModel.predict_tokens runs): per step the top-2 of log_softmax; the live
+ * hypothesis follows the best non-EOS token, an EOS candidate finishes
+ * prefix+EOS with score logp/((5+len)/6)^alpha; a row stops once its best finished
+ * score exceeds live_logp/((5+L+1)/6)^alpha; the best finished hypothesis is
+ * returned, or the live one if none finished.
  * Runs `num_steps` (<= L) steps; each step is one hipGraph replay unless
  * flags & MT3_DECODE_NO_GRAPH.  d_ids [batch, L] int32 (columns >= num_steps
  * are zero-filled).  d_first_logits: [batch, vocab] f32 logits of step 0, or NULL.
  * With MT3_DECODE_EARLY_EXIT the host polls a device flag every 32 steps and
- * stops once every row has emitted EOS (this synchronises the stream). */
+ * stops once every row has emitted EOS / finished its search (this synchronises the stream). */
 enum {
   MT3_DECODE_NO_GRAPH = 1,
   MT3_DECODE_EARLY_EXIT = 2,
+  MT3_DECODE_BEAM1 = 4,
   /* profiling only: drop the self / cross decode-attention launches from every step (output invalid);
    * (full decode time) - (time without the kernel) = in-situ time of that kernel, measured with two
    * HIP events around the whole graph-replayed decode instead of 8192 per-launch event pairs */

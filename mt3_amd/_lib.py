@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libmt3hip.so")
 MT3_OK, MT3_ERR_INVALID, MT3_ERR_HIP, MT3_ERR_CAPACITY, MT3_ERR_MISSING = 0, -1, -2, -3, -4
 MT3_BF16, MT3_F32 = 0, 1
 EPI_STORE, EPI_RESID, EPI_GEGLU, EPI_POS, EPI_F32, EPI_HEADS = range(6)
-DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_SKIP_SELF_ATTN, DECODE_SKIP_CROSS_ATTN = 1, 2, 8, 16
+DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SKIP_SELF_ATTN, DECODE_SKIP_CROSS_ATTN = 1, 2, 4, 8, 16
 EV_SHIFT, EV_PITCH, EV_VELOCITY, EV_TIE, EV_PROGRAM, EV_DRUM = range(6)
 EVENT_TYPE_NAMES = ("shift", "pitch", "velocity", "tie", "program", "drum")
 SPEC_ONSETS, SPEC_NOTES, SPEC_TIES = range(3)

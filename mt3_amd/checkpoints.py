@@ -1,0 +1,251 @@
+"""t5x checkpoint directories <-> the flat parameter dict the engine loads.
+
+The reference restores its weights with t5x (`InferenceModel.restore_from_checkpoint`, notebook cell
+"Imports and Definitions", `t5x.utils.RestoreCheckpointConfig(path, mode='specific', dtype='float32')`).
+t5x itself is not part of the reference tree, so this is a restatement of its on-disk format
+[from memory of t5x/checkpoints.py; no real checkpoint is available offline to pin it]:
+
+    <dir>/checkpoint                        msgpack of the train-state dict {'version', 'optimizer':
+                                            {'target': {...}, 'state': {...}}} (older: {'target': ...}).
+                                            A leaf is either an inline array (flax.serialization
+                                            ext type 1 = msgpack (shape, dtype-name, bytes)) or a
+                                            TensorStore spec {'driver': 'zarr', 'kvstore': {'path': ...},
+                                            'metadata': {...}} that points at a sibling directory.
+    <dir>/target.<a>.<b>...<leaf>/          one zarr-v2 array per parameter: `.zarray` (JSON: shape,
+                                            chunks, dtype, compressor {id: gzip|zlib|null}, order C,
+                                            dimension_separator '.') and one file per chunk ('0.0', ...).
+
+Only numpy + zlib + msgpack are needed.  `load_t5x_checkpoint` returns {'encoder/layers_0/attention/
+query/kernel': f32 array, ...}, i.e. the Flax tree paths joined by '/', which is what
+`network.Transformer.load_params` / `mt3_engine_load_weight` take.  `save_t5x_checkpoint` writes the
+same layout (used by the tests and to hand weights back to a t5x-side tool).
+"""
+from __future__ import annotations
+
+import json
+import os
+import zlib
+from typing import Any, Dict, Iterable, Optional, Tuple
+
+import numpy as np
+
+_TARGET_PREFIX = "target."
+_FLAX_EXT_NDARRAY, _FLAX_EXT_NPSCALAR = 1, 3
+
+
+class CheckpointError(ValueError):
+    pass
+
+
+# ---------------------------------------------------------------------------------------- zarr v2
+def _np_dtype(name: str) -> Tuple[np.dtype, bool]:
+    """zarr dtype string -> (storage dtype, is_bfloat16)."""
+    if name in ("bfloat16", "<V2", "|V2"):
+        return np.dtype("<u2"), True
+    try:
+        return np.dtype(name), False
+    except TypeError as e:
+        raise CheckpointError("unsupported zarr dtype %r" % (name,)) from e
+
+
+def _bf16_to_f32(u16: np.ndarray) -> np.ndarray:
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def _decompress(raw: bytes, compressor: Optional[Dict[str, Any]]) -> bytes:
+    if compressor is None:
+        return raw
+    cid = compressor.get("id")
+    if cid == "gzip":
+        return zlib.decompress(raw, 16 + zlib.MAX_WBITS)
+    if cid == "zlib":
+        return zlib.decompress(raw)
+    raise CheckpointError("unsupported zarr compressor %r (t5x writes gzip)" % (cid,))
+
+
+def read_zarr_array(path: str) -> np.ndarray:
+    """One zarr-v2 array directory -> ndarray (bfloat16 is widened to float32)."""
+    meta_path = os.path.join(path, ".zarray")
+    if not os.path.isfile(meta_path):
+        raise CheckpointError("%s: not a zarr array (no .zarray)" % path)
+    with open(meta_path) as f:
+        meta = json.load(f)
+    if meta.get("zarr_format", 2) != 2:
+        raise CheckpointError("%s: zarr_format %r not supported" % (path, meta.get("zarr_format")))
+    if meta.get("filters"):
+        raise CheckpointError("%s: zarr filters are not supported" % path)
+    shape, chunks = tuple(meta["shape"]), tuple(meta["chunks"])
+    order = meta.get("order", "C")
+    dtype, is_bf16 = _np_dtype(meta["dtype"])
+    sep = meta.get("dimension_separator", ".")
+    fill = meta.get("fill_value")
+    out = np.empty(shape, dtype)
+    if len(shape) == 0:                                   # scalar: a single chunk named '0'
+        grid: Iterable[Tuple[int, ...]] = [()]
+    else:
+        grid = np.ndindex(*[-(-s // c) for s, c in zip(shape, chunks)])
+    n_chunk = int(np.prod(chunks)) if chunks else 1
+    for idx in grid:
+        key = sep.join(str(i) for i in idx) if idx else "0"
+        cpath = os.path.join(path, key)
+        if os.path.isfile(cpath):
+            with open(cpath, "rb") as f:
+                buf = _decompress(f.read(), meta.get("compressor"))
+            if len(buf) != n_chunk * dtype.itemsize:
+                raise CheckpointError("%s: chunk %s holds %d bytes, expected %d"
+                                      % (path, key, len(buf), n_chunk * dtype.itemsize))
+            chunk = np.frombuffer(buf, dtype).reshape(chunks, order=order)
+        elif fill is not None:
+            chunk = np.full(chunks, fill, dtype)         # zarr: a missing chunk is all fill_value
+        else:
+            raise CheckpointError("%s: chunk %s is missing" % (path, key))
+        sel = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, shape))
+        out[sel] = chunk[tuple(slice(0, s.stop - s.start) for s in sel)]   # edge chunks are stored full-size
+    return _bf16_to_f32(out) if is_bf16 else out
+
+
+def write_zarr_array(path: str, arr: np.ndarray, chunks: Optional[Tuple[int, ...]] = None,
+                     compressor: Optional[str] = "gzip") -> None:
+    arr = np.asarray(arr)
+    chunks = tuple(chunks) if chunks is not None else tuple(max(1, s) for s in arr.shape)
+    os.makedirs(path, exist_ok=True)
+    meta = {"chunks": list(chunks), "compressor": {"id": compressor, "level": 1} if compressor else None,
+            "dtype": arr.dtype.str, "fill_value": None, "filters": None, "order": "C",
+            "shape": list(arr.shape), "zarr_format": 2}
+    with open(os.path.join(path, ".zarray"), "w") as f:
+        json.dump(meta, f)
+    grid = [()] if arr.ndim == 0 else np.ndindex(*[-(-s // c) for s, c in zip(arr.shape, chunks)])
+    for idx in grid:
+        block = np.zeros(chunks, arr.dtype)
+        sel = tuple(slice(i * c, min((i + 1) * c, s)) for i, c, s in zip(idx, chunks, arr.shape))
+        block[tuple(slice(0, s.stop - s.start) for s in sel)] = arr[sel]
+        raw = block.tobytes()
+        if compressor == "gzip":
+            co = zlib.compressobj(1, zlib.DEFLATED, 16 + zlib.MAX_WBITS)
+            raw = co.compress(raw) + co.flush()
+        elif compressor == "zlib":
+            raw = zlib.compress(raw, 1)
+        elif compressor is not None:
+            raise CheckpointError("unsupported compressor %r" % (compressor,))
+        with open(os.path.join(path, ".".join(str(i) for i in idx) if idx else "0"), "wb") as f:
+            f.write(raw)
+
+
+# ---------------------------------------------------------------------------------------- msgpack index
+def _ext_hook(code: int, data: bytes):
+    import msgpack
+    if code == _FLAX_EXT_NDARRAY:
+        shape, dtype_name, buf = msgpack.unpackb(data, raw=False)
+        dtype, is_bf16 = _np_dtype(dtype_name)
+        a = np.frombuffer(buf, dtype).reshape(shape)
+        return _bf16_to_f32(a) if is_bf16 else a
+    if code == _FLAX_EXT_NPSCALAR:
+        shape, dtype_name, buf = msgpack.unpackb(data, raw=False)
+        return np.frombuffer(buf, np.dtype(dtype_name)).reshape(shape)[()]
+    return msgpack.ExtType(code, data)
+
+
+def read_index(ckpt_dir: str) -> Optional[Dict[str, Any]]:
+    """The msgpack `checkpoint` file as nested dicts, or None if the directory has none."""
+    path = os.path.join(ckpt_dir, "checkpoint")
+    if not os.path.isfile(path):
+        return None
+    import msgpack
+    with open(path, "rb") as f:
+        return msgpack.unpackb(f.read(), ext_hook=_ext_hook, raw=False, strict_map_key=False)
+
+
+def _is_ts_spec(node: Any) -> bool:
+    return isinstance(node, dict) and "kvstore" in node and "driver" in node
+
+
+def _spec_path(spec: Dict[str, Any]) -> str:
+    kv = spec["kvstore"]
+    return kv["path"] if isinstance(kv, dict) else str(kv)
+
+
+def _walk(node: Any, prefix: Tuple[str, ...]):
+    if isinstance(node, dict) and not _is_ts_spec(node):
+        for k, v in node.items():
+            yield from _walk(v, prefix + (str(k),))
+    else:
+        yield prefix, node
+
+
+def _target_tree(index: Dict[str, Any]) -> Optional[Dict[str, Any]]:
+    if "optimizer" in index and isinstance(index["optimizer"], dict) and "target" in index["optimizer"]:
+        return index["optimizer"]["target"]
+    return index.get("target")
+
+
+# ---------------------------------------------------------------------------------------- public API
+def load_t5x_checkpoint(ckpt_dir: str, dtype=np.float32) -> Dict[str, np.ndarray]:
+    """All model parameters (`target.*`) of a t5x checkpoint directory as {'a/b/c': array}.
+
+    The msgpack index is authoritative when present (inline leaves, TensorStore specs resolved
+    relative to the directory); array directories named `target.*` that the index does not mention
+    are picked up as well, so a directory without an index still loads."""
+    if not os.path.isdir(ckpt_dir):
+        raise CheckpointError("%s: not a directory" % (ckpt_dir,))
+    params: Dict[str, np.ndarray] = {}
+    index = read_index(ckpt_dir)
+    tree = _target_tree(index) if index is not None else None
+    if tree is not None:
+        for keys, leaf in _walk(tree, ()):
+            name = "/".join(keys)
+            if _is_ts_spec(leaf):
+                sub = os.path.join(ckpt_dir, os.path.basename(_spec_path(leaf).rstrip("/")))
+                params[name] = read_zarr_array(sub)
+            elif isinstance(leaf, np.ndarray) or np.isscalar(leaf):
+                params[name] = np.asarray(leaf)
+            elif leaf is None:
+                continue
+            else:
+                raise CheckpointError("%s: leaf %s has unsupported type %s" % (ckpt_dir, name, type(leaf).__name__))
+    for entry in sorted(os.listdir(ckpt_dir)):
+        if entry.startswith(_TARGET_PREFIX) and os.path.isfile(os.path.join(ckpt_dir, entry, ".zarray")):
+            name = entry[len(_TARGET_PREFIX):].replace(".", "/")
+            if name not in params:
+                params[name] = read_zarr_array(os.path.join(ckpt_dir, entry))
+    if not params:
+        raise CheckpointError("%s: no `target.*` parameters found (is this a t5x checkpoint directory?)" % ckpt_dir)
+    return {k: np.ascontiguousarray(v, dtype=dtype) for k, v in params.items()}
+
+
+def save_t5x_checkpoint(ckpt_dir: str, params: Dict[str, np.ndarray], step: int = 0,
+                        inline_below: int = 0, chunk_rows: Optional[int] = None) -> None:
+    """Write `params` ({'a/b/c': array}) in the layout above.  Arrays with fewer than `inline_below`
+    elements go inline into the msgpack index (t5x does this for leaves without partitioning axes);
+    `chunk_rows` splits the first axis into chunks of that many rows (t5x chunks per shard)."""
+    import msgpack
+    os.makedirs(ckpt_dir, exist_ok=True)
+    tree: Dict[str, Any] = {}
+    for name, arr in params.items():
+        arr = np.asarray(arr)
+        node = tree
+        keys = name.split("/")
+        for k in keys[:-1]:
+            node = node.setdefault(k, {})
+        if arr.size < inline_below:
+            node[keys[-1]] = msgpack.ExtType(
+                _FLAX_EXT_NDARRAY, msgpack.packb((list(arr.shape), arr.dtype.name, arr.tobytes()), use_bin_type=True))
+            continue
+        sub = _TARGET_PREFIX + ".".join(keys)
+        chunks = None
+        if chunk_rows and arr.ndim >= 1:
+            chunks = (min(chunk_rows, max(1, arr.shape[0])),) + tuple(max(1, s) for s in arr.shape[1:])
+        write_zarr_array(os.path.join(ckpt_dir, sub), arr, chunks=chunks)
+        node[keys[-1]] = {"driver": "zarr", "kvstore": {"driver": "file", "path": sub},
+                          "metadata": {"shape": list(arr.shape), "dtype": arr.dtype.str,
+                                       "chunks": list(chunks or arr.shape), "compressor": {"id": "gzip"}}}
+    index = {"version": 3, "optimizer": {"target": tree, "state": {"step": int(step)}}}
+    with open(os.path.join(ckpt_dir, "checkpoint"), "wb") as f:
+        f.write(msgpack.packb(index, use_bin_type=True))
+
+
+def is_t5x_checkpoint_dir(path: str) -> bool:
+    if not os.path.isdir(path):
+        return False
+    if os.path.isfile(os.path.join(path, "checkpoint")):
+        return True
+    return any(e.startswith(_TARGET_PREFIX) for e in os.listdir(path))

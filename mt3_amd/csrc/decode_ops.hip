@@ -6,7 +6,8 @@
 //   embed_kernel        Embed (one-hot matmul in the reference, layers.py:530-533 -> a row gather)
 //                       + FixedEmbed decode slice pos[t] (layers.py:589-596).
 //   argmax_step_kernel  greedy pick of the step (lowest id on ties), EOS bookkeeping, writes
-//                       ids[b][t]; rows that already emitted EOS get 0 (pad).
+//                       ids[b][t]; rows that already emitted EOS get 0 (pad).  BEAM1 variant: one step
+//                       of t5x beam_search with num_decodes=1 (top-2 of log_softmax, live/finished sets).
 //                       Positions are PER-ROW device counters (no cross-row sync), so ONE captured
 //                       hipGraph serves every step; the block also writes the next step's embedding row.
 //   ids_to_tokens_kernel GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271), bit-exact.
@@ -82,58 +83,136 @@ int launch_embed(const float* table, const float* pos, const int* tok, const int
   return MT3_OK;
 }
 
+// order of candidates: larger logit first, lower id on ties (lax.top_k / argmax convention)
+__device__ inline bool cand_better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+struct Top2 {
+  float v1, v2;
+  int i1, i2;
+  __device__ inline void insert(float v, int i) {
+    if (cand_better(v, i, v1, i1)) {
+      v2 = v1;
+      i2 = i1;
+      v1 = v;
+      i1 = i;
+    } else if (cand_better(v, i, v2, i2)) {
+      v2 = v;
+      i2 = i;
+    }
+  }
+};
+
+// BEAM1 = false: greedy pick (the product default).
+// BEAM1 = true : one step of t5x `beam_search` with num_decodes = 1: the two best
+//   candidates of log_softmax are taken; the LIVE hypothesis follows the best non-EOS one; an EOS candidate
+//   finishes `live prefix + EOS` with score (live_logp + logp_eos) / brevity_penalty(t + 1), kept if it
+//   beats the best finished score of the row; the row is done once that score exceeds
+//   live_logp / brevity_penalty(max_len + 1), after which no later finish can win.  beam_f holds
+//   [live_logp | best_score] per row, beam_len the prefix length of the best finished hypothesis (-1: none);
+//   beam_cfg[0] = brevity_penalty(max_len + 1) of this call, beam_cfg[1 + n] = brevity_penalty(n) =
+//   ((5 + n) / 6) ^ alpha, tabulated on the host.
+template <bool BEAM1>
 __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restrict__ logits, int vocab,
                                                            int* __restrict__ ids, int ids_stride,
                                                            int* __restrict__ cur_tok, int* __restrict__ done,
                                                            int* __restrict__ n_done, int* __restrict__ step,
                                                            const float* __restrict__ table,
                                                            const float* __restrict__ pos_table, int max_pos,
-                                                           float* __restrict__ y_next, int dim) {
-  __shared__ float s_v[4];
-  __shared__ int s_i[4];
+                                                           float* __restrict__ y_next, int dim,
+                                                           float* __restrict__ beam_f, int* __restrict__ beam_len,
+                                                           const float* __restrict__ beam_cfg, int beam_rows) {
+  __shared__ float s_v[8], s_sum[4];
+  __shared__ int s_i[8];
   __shared__ int s_tok, s_t;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = logits + static_cast<size_t>(b) * vocab;
-  float best = -3.0e38f;
-  int bi = 0x7fffffff;
-  for (int i = tid; i < vocab; i += 256) {
-    const float v = row[i];
-    if (v > best) {            // ascending i: strict > keeps the lowest index on ties
-      best = v;
-      bi = i;
+  // thread 0 issues its state loads up front so that their latency hides behind the reductions
+  int was_done = 0, t = 0, blen = -1;
+  float live = 0.f, best = 0.f, bp_max = 1.f, bp_t = 1.f;
+  if (tid == 0) {
+    was_done = done[b];
+    t = step[b];
+    if (BEAM1) {
+      live = beam_f[b];
+      best = beam_f[beam_rows + b];
+      blen = beam_len[b];
+      bp_max = beam_cfg[0];
+      bp_t = beam_cfg[1 + t + 1];
     }
   }
+  Top2 t2{-3.0e38f, -3.0e38f, 0x7fffffff, 0x7fffffff};
+  for (int i = tid; i < vocab; i += 256) t2.insert(row[i], i);   // ascending i per thread
+  float acc = 0.f;
+  if (BEAM1) {
+    // sum of exp(x - thread max) over this thread's (cache-hot) elements; rescaled to the wave max below
+    for (int i = tid; i < vocab; i += 256) acc += __expf(row[i] - t2.v1);
+  }
+  const float own_max = t2.v1;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o);
-    const int oi = __shfl_xor(bi, o);
-    if (ov > best || (ov == best && oi < bi)) {
-      best = ov;
-      bi = oi;
-    }
+    const float ov1 = __shfl_xor(t2.v1, o), ov2 = __shfl_xor(t2.v2, o);
+    const int oi1 = __shfl_xor(t2.i1, o), oi2 = __shfl_xor(t2.i2, o);
+    t2.insert(ov1, oi1);
+    if (BEAM1) t2.insert(ov2, oi2);
+  }
+  if (BEAM1) {
+    acc *= __expf(own_max - t2.v1);                     // every lane now holds the wave max in t2.v1
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   }
   if (lane == 0) {
-    s_v[wave] = best;
-    s_i[wave] = bi;
+    s_v[wave] = t2.v1;
+    s_i[wave] = t2.i1;
+    s_v[4 + wave] = t2.v2;
+    s_i[4 + wave] = t2.i2;
+    s_sum[wave] = acc;
   }
   __syncthreads();
   if (tid == 0) {
+    float m = t2.v1;                                    // wave 0's max; the block max after the merge
 #pragma unroll
-    for (int w = 1; w < 4; ++w)
-      if (s_v[w] > best || (s_v[w] == best && s_i[w] < bi)) {
-        best = s_v[w];
-        bi = s_i[w];
+    for (int w = 1; w < 4; ++w) {
+      t2.insert(s_v[w], s_i[w]);
+      if (BEAM1) t2.insert(s_v[4 + w], s_i[4 + w]);
+    }
+    int tok;
+    if (!BEAM1) {
+      tok = was_done ? 0 : t2.i1;
+      if (!was_done && tok == 1) {        // EOS
+        done[b] = 1;
+        atomicAdd(n_done, 1);
       }
-    const int was_done = done[b];
-    const int tok = was_done ? 0 : bi;
-    const int t = step[b];                // this row's own position counter: no cross-row synchronisation
+    } else {
+      tok = 0;
+      if (!was_done) {
+        m = t2.v1;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sum += s_sum[w] * __expf(s_v[w] - m);
+        const float lse = m + __logf(sum);
+        const float lp1 = t2.v1 - lse, lp2 = t2.v2 - lse;
+        const int eos_slot = t2.i1 == 1 ? 1 : (t2.i2 == 1 ? 2 : 0);
+        if (eos_slot) {
+          const float score = (live + (eos_slot == 1 ? lp1 : lp2)) / bp_t;
+          if (blen < 0 || score > best) {
+            best = score;
+            blen = t;
+          }
+        }
+        tok = eos_slot == 1 ? t2.i2 : t2.i1;
+        live += eos_slot == 1 ? lp2 : lp1;
+        beam_f[b] = live;
+        beam_f[beam_rows + b] = best;
+        beam_len[b] = blen;
+        if (blen >= 0 && best > live / bp_max) {
+          done[b] = 1;
+          atomicAdd(n_done, 1);
+        }
+      }
+    }
     ids[static_cast<size_t>(b) * ids_stride + t] = tok;
     cur_tok[b] = tok;
     step[b] = t + 1;
-    if (!was_done && tok == 1) {          // EOS
-      done[b] = 1;
-      atomicAdd(n_done, 1);
-    }
     s_tok = tok;
     s_t = t + 1;
   }
@@ -153,9 +232,30 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
 
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
-                       float* y_next, int dim, int B, hipStream_t s) {
-  hipLaunchKernelGGL(argmax_step_kernel, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok, done,
-                     n_done, step, table, pos_table, max_pos, y_next, dim);
+                       float* y_next, int dim, int B, const BeamState* beam, hipStream_t s) {
+  if (beam)
+    hipLaunchKernelGGL(argmax_step_kernel<true>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
+                       done, n_done, step, table, pos_table, max_pos, y_next, dim, beam->f, beam->len, beam->cfg,
+                       beam->rows);
+  else
+    hipLaunchKernelGGL(argmax_step_kernel<false>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
+                       done, n_done, step, table, pos_table, max_pos, y_next, dim, nullptr, nullptr, nullptr, 0);
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+
+// end of a beam-1 decode: rows with a finished hypothesis return live[:len] + EOS (+ pad), the others
+// keep their live sequence (t5x beam_search: "if no finished sequence, return the live one")
+__global__ __launch_bounds__(256) void beam1_finalize_kernel(int* __restrict__ ids, int L,
+                                                              const int* __restrict__ beam_len) {
+  const int b = blockIdx.x, n = beam_len[b];
+  if (n < 0) return;
+  int* row = ids + static_cast<size_t>(b) * L;
+  for (int i = n + threadIdx.x; i < L; i += 256) row[i] = i == n ? 1 : 0;
+}
+
+int launch_beam1_finalize(int* ids, int L, const int* beam_len, int B, hipStream_t s) {
+  hipLaunchKernelGGL(beam1_finalize_kernel, dim3(B), dim3(256), 0, s, ids, L, beam_len);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

@@ -105,19 +105,26 @@ struct mt3_engine {
   int* step = nullptr;
   int* n_done = nullptr;
   int* h_pinned = nullptr;
+  float* beam_f = nullptr;       // [2][max_batch]: live log-prob | best finished score (MT3_DECODE_BEAM1)
+  int* beam_len = nullptr;       // [max_batch]
+  float* beam_cfg = nullptr;     // [0] brevity penalty of the loop bound, [1 + n] brevity_penalty(n)
 
   int cur_batch = 0;             // batch of the last encode
   hipStream_t cap_stream[8] = {};     // one capture stream per chain (kMaxChains)
   hipEvent_t cap_event[8] = {};
-  // one captured decode step per (batch, skip-mask); skip-mask != 0 only for differential profiling
-  hipGraphExec_t graph_exec[4][9] = {};   // [skip-mask][chains]
-  hipGraph_t graph[4][9] = {};
+  // one captured decode step per (batch, variant); variant bits: 1 = no self-attention, 2 = no
+  // cross-attention (differential profiling only), 4 = beam-1 token selection
+  hipGraphExec_t graph_exec[8][9] = {};   // [variant][chains]
+  hipGraph_t graph[8][9] = {};
   int graph_batch = 0;
 
   int HD() const { return cfg.num_heads * cfg.head_dim; }
 };
 
 namespace {
+
+// t5x decoding.brevity_penalty(alpha = 0.6, length): ((5 + length) / 6) ^ alpha
+float brevity_penalty(int length) { return static_cast<float>(std::pow((5.0 + length) / 6.0, 0.6)); }
 
 int dmalloc(mt3_engine* e, void** p, size_t bytes) {
   MT3_HIP_CHECK(hipMalloc(p, bytes));
@@ -280,10 +287,12 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   if (op == 8 * nl)
     return mt3k::launch_gemm(dt, gemm_args(y, e->logits_w, logits, rows, c.vocab_size, emb, c.vocab_size), true, true,
                              MT3_EPI_F32, small, s);
-  if (op == 8 * nl + 1)
+  if (op == 8 * nl + 1) {
+    const mt3k::BeamState beam{e->beam_f + row0, e->beam_len + row0, e->beam_cfg, c.max_batch};
     return mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
                                     e->cur_tok + row0, e->done + row0, e->n_done, step, e->embedding, e->pos_table,
-                                    kMaxPos, y, emb, rows, s);
+                                    kMaxPos, y, emb, rows, (skip & 4) ? &beam : nullptr, s);
+  }
   LayerDev& L = e->dec[op >> 3];
   switch (op & 7) {
     case 0:
@@ -367,7 +376,7 @@ int enqueue_decode_step(mt3_engine* e, int B, int skip, int n, hipStream_t s) {
 }
 
 void drop_graph(mt3_engine* e) {
-  for (int v = 0; v < 4; ++v)
+  for (int v = 0; v < 8; ++v)
     for (int n = 0; n < 9; ++n) {
       if (e->graph_exec[v][n]) (void)hipGraphExecDestroy(e->graph_exec[v][n]);
       if (e->graph[v][n]) (void)hipGraphDestroy(e->graph[v][n]);
@@ -566,6 +575,15 @@ int mt3_engine_finalize(mt3_engine* e) {
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->done), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->step), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->n_done), 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->beam_f), static_cast<size_t>(2) * Bm * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->beam_len), static_cast<size_t>(Bm) * 4))) return rc;
+  {
+    // beam_cfg[0]: loop bound of the current call; beam_cfg[1 + n] = brevity_penalty(n), n = 0 .. L + 1
+    std::vector<float> bp(static_cast<size_t>(L) + 3, 0.f);
+    for (int n = 0; n <= L + 1; ++n) bp[1 + n] = brevity_penalty(n);
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->beam_cfg), bp.size() * 4))) return rc;
+    MT3_HIP_CHECK(hipMemcpy(e->beam_cfg, bp.data(), bp.size() * 4, hipMemcpyHostToDevice));
+  }
   MT3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&e->h_pinned), 64, hipHostMallocDefault));
   e->raw.clear();
   e->finalized = true;
@@ -629,7 +647,17 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
 
   // profiling-only variants: leave the self (1) / cross (2) attention launches out of the step, so that
   // their in-situ cost can be read as a DIFFERENCE of whole-decode times (results are garbage)
-  const int skip = ((flags & MT3_DECODE_SKIP_SELF_ATTN) ? 1 : 0) | ((flags & MT3_DECODE_SKIP_CROSS_ATTN) ? 2 : 0);
+  const bool beam1 = (flags & MT3_DECODE_BEAM1) != 0;
+  const int skip = ((flags & MT3_DECODE_SKIP_SELF_ATTN) ? 1 : 0) | ((flags & MT3_DECODE_SKIP_CROSS_ATTN) ? 2 : 0) |
+                   (beam1 ? 4 : 0);
+  if (beam1) {
+    // t5x beam_search(alpha = 0.6): live log-prob 0, nothing finished; the loop bound uses the brevity
+    // penalty of max_decode_len + 1 (the dummy start token extends the length by one)
+    const float bp_max = brevity_penalty(num_steps + 1);
+    MT3_HIP_CHECK(hipMemcpyAsync(e->beam_cfg, &bp_max, 4, hipMemcpyHostToDevice, s));
+    MT3_HIP_CHECK(hipMemsetAsync(e->beam_f, 0, static_cast<size_t>(2) * c.max_batch * 4, s));
+    MT3_HIP_CHECK(hipMemsetAsync(e->beam_len, 0xFF, static_cast<size_t>(c.max_batch) * 4, s));   // -1
+  }
   bool use_graph = !(flags & MT3_DECODE_NO_GRAPH);
   const int chains = chains_for(e, batch, (flags >> 8) & 0xF);
   if (use_graph && ensure_graph(e, batch, skip, chains) != MT3_OK) use_graph = false;   // fall back to direct launches
@@ -647,6 +675,7 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
       if (e->h_pinned[0] >= batch) break;
     }
   }
+  if (beam1) MT3_TRY(mt3k::launch_beam1_finalize(e->ids, L, e->beam_len, batch, s));
   MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
   if (h_steps_run) *h_steps_run = ran;
   return MT3_OK;

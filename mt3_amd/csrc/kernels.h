@@ -46,10 +46,20 @@ int launch_rmsnorm(int dtype, const float* x, const float* scale, void* out_ct, 
 // y[b] = table[tok[b]] + pos[step[b]]
 int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, int B, int dim,
                  hipStream_t s);
-// greedy pick + bookkeeping for one decode step (see decode_ops.hip)
+// per-row state of the beam-1 search (t5x beam_search, num_decodes = 1): f = [live_logp | best finished
+// score], the second array `rows` floats after the first; len = prefix length of the best finished
+// hypothesis or -1; cfg[0] = brevity_penalty(max_len + 1), cfg[1 + n] = brevity_penalty(n) (device memory)
+struct BeamState {
+  float* f;
+  int* len;
+  const float* cfg;
+  int rows;
+};
+// token pick + bookkeeping for one decode step (see decode_ops.hip); beam == nullptr: greedy
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
-                       float* y_next, int dim, int B, hipStream_t s);
+                       float* y_next, int dim, int B, const BeamState* beam, hipStream_t s);
+int launch_beam1_finalize(int* ids, int L, const int* beam_len, int B, hipStream_t s);
 int launch_ids_to_tokens(const int* ids, int B, int L, int num_regular, int* out, hipStream_t s);
 
 }  // namespace mt3k

@@ -12,8 +12,10 @@ mt3/inference.py:34-138 (the t5x `infer` write_fn).
 Differences that are deliberate: the t5x/gin/tf.data plumbing is gone -- segments
 are cut and padded on the host exactly as the reference's preprocessors do
 (`_audio_to_frames`, split into `inputs_length`-frame chunks, zero rows after the
-log for a short last segment), everything numeric runs in libmt3hip.so, and decode
-is greedy-until-EOS (the reference runs t5x beam search with beam size 1).
+log for a short last segment), everything numeric runs in libmt3hip.so.  Decoding
+defaults to `decoding="beam1"`: the selection rule of t5x beam search with one beam and
+alpha 0.6, which is what the reference's predict_batch_with_aux runs (SURVEY.md A.5);
+`decoding="greedy"` stops a row at its first arg-max EOS.
 """
 from __future__ import annotations
 
@@ -45,7 +47,8 @@ class InferenceModel(object):
     """Wrapper of the MI355X engine for music transcription."""
 
     def __init__(self, checkpoint_path, model_type="mt3", *, config: Optional[network.T5Config] = None,
-                 dtype: str = "bfloat16", batch_size: int = 8, early_exit: bool = True):
+                 dtype: str = "bfloat16", batch_size: int = 8, early_exit: bool = True,
+                 decoding: str = "beam1"):
         if model_type == "ismir2021":
             num_velocity_bins = 127
             self.encoding_spec = note_sequences.NoteEncodingSpec
@@ -61,6 +64,9 @@ class InferenceModel(object):
         self.outputs_length = 1024
         self.sequence_length = {"inputs": self.inputs_length, "targets": self.outputs_length}
         self.early_exit = early_exit
+        if decoding not in ("beam1", "greedy"):
+            raise ValueError("decoding must be 'beam1' or 'greedy', got %r" % (decoding,))
+        self.decoding = decoding
 
         self.spectrogram_config = spectrograms.SpectrogramConfig()
         self.codec = vocabularies.build_codec(
@@ -83,19 +89,24 @@ class InferenceModel(object):
                 "decoder_input_tokens": (self.batch_size, self.outputs_length)}
 
     def restore_from_checkpoint(self, checkpoint_path):
-        """Weights: a flat `.npz` (names = the reference's Flax tree joined by '/'), a dict of arrays,
-        or 'random:<seed>' / None for the reference's initialisers (no checkpoint ships with the
-        repo; reading t5x's native TensorStore format is the N1 follow-up in DESIGN.md)."""
+        """Weights: a t5x checkpoint DIRECTORY (what the reference restores: msgpack index + one zarr
+        array per `target.*` parameter, read by mt3_amd.checkpoints), a flat `.npz` (names = the
+        reference's Flax tree joined by '/'), a dict of arrays, or 'random:<seed>' / None for the
+        reference's initialisers (no checkpoint ships with the repo)."""
         if isinstance(checkpoint_path, dict):
             params = checkpoint_path
         elif checkpoint_path is None or str(checkpoint_path).startswith("random"):
             seed = int(str(checkpoint_path).split(":")[1]) if checkpoint_path and ":" in str(checkpoint_path) else 0
             params = network.init_random_params(self.model_config, seed=seed)
+        elif os.path.isdir(str(checkpoint_path)):
+            from . import checkpoints
+            params = checkpoints.load_t5x_checkpoint(str(checkpoint_path))
         elif str(checkpoint_path).endswith(".npz") and os.path.exists(str(checkpoint_path)):
             with np.load(str(checkpoint_path)) as z:
                 params = {k: z[k] for k in z.files}
         else:
-            raise ValueError("unsupported checkpoint %r: pass a flat .npz, a dict, or 'random:<seed>'"
+            raise ValueError("unsupported checkpoint %r: pass a t5x checkpoint directory, a flat .npz, a dict, "
+                             "or 'random:<seed>'"
                              % (checkpoint_path,))
         self.model.load_params(params)
 
@@ -109,7 +120,7 @@ class InferenceModel(object):
         out = []
         for s in range(0, x.shape[0], self.batch_size):
             self.model.encode(x[s:s + self.batch_size].cuda())
-            ids = self.model.decode(early_exit=self.early_exit)
+            ids = self.model.decode(early_exit=self.early_exit, beam1=self.decoding == "beam1")
             out.append(self.vocabulary.decode_tf(ids))
         return torch.cat(out, 0).cpu().numpy()
 

@@ -224,7 +224,7 @@ class Oracle:
                 live_lp += v
                 live.append(i)
                 tok = torch.tensor([i])
-                bound = live_lp / (((5.0 + max_steps) / 6.0) ** alpha)
+                bound = live_lp / (((5.0 + max_steps + 1) / 6.0) ** alpha)   # t5x: max_decode_len += 1 (dummy start token)
                 if best_fin is not None and best_score > bound:
                     break
             seq = best_fin if best_fin is not None else live

@@ -106,6 +106,41 @@ def test_engine_bf16_within_tolerance(setup):
     assert np.array_equal(got[safe], lr.argmax(-1)[safe])
 
 
+def test_beam1_decode_matches_oracle():
+    """MT3_DECODE_BEAM1 = the selection rule of t5x beam_search(num_decodes=1), against the
+    oracle's emulation.  Flat logits with a boosted EOS column give rows that (a) finish on a top-1 EOS like
+    greedy, (b) finish EARLIER than greedy through a top-2 EOS, (c) never finish and return the live row."""
+    cfg32 = network.T5Config(dtype="float32")
+    params = _params(cfg32, seed=1)
+    k = params["decoder/logits_dense/kernel"].copy() * 0.3
+    k[:, 1] *= 1.5
+    params["decoder/logits_dense/kernel"] = k
+    x = _inputs(6, seed=3)
+    x[2, 100:] = 0.0
+    orc = _oracle(cfg32, params)
+    enc_ref = orc.encode(x)
+    steps = 32
+    greedy_ref, _ = orc.greedy_decode(enc_ref, steps, return_logits=True)
+    ref = orc.beam1_decode(enc_ref, steps)
+    assert (ref != greedy_ref).any(axis=1).sum() >= 2          # the case set does discriminate the two rules
+    assert not (ref == 1).any(axis=1).all()                    # ... and holds a row that never finishes
+    eng = _engine("float32", params, 6)
+    eng.encode(torch.from_numpy(x).cuda())
+    got = {}
+    for name, kw in (("graph", {}), ("direct", dict(use_graph=False)),
+                     ("early_exit", dict(early_exit=True))):
+        ids = eng.decode(num_steps=steps, beam1=True, **kw).cpu().numpy()
+        assert (ids[:, steps:] == 0).all()
+        got[name] = ids[:, :steps]
+    for name, ids in got.items():
+        if name == "early_exit":        # rows that never finish keep the search alive: same result
+            assert eng.steps_run <= steps
+        assert np.array_equal(ids, ref), f"{name}: beam-1 tokens differ from the oracle\n{ids}\n{ref}"
+    # greedy on the same engine still follows the greedy oracle
+    ids = eng.decode(num_steps=steps).cpu().numpy()[:, :steps]
+    assert np.array_equal(ids, greedy_ref)
+
+
 @pytest.mark.parametrize("dtype", ["bfloat16", "float32"])
 def test_graph_replay_equals_direct_launch(setup, dtype):
     eng = _engine(dtype, setup["params"], 3)
@@ -159,6 +194,10 @@ def test_decode_chains_are_bit_identical(setup):
     eng.encode(x[:50])
     a = eng.decode(num_steps=8, chains=1).cpu().numpy()
     b = eng.decode(num_steps=8, chains=3).cpu().numpy()
+    assert np.array_equal(a, b)
+    # the beam-1 selection keeps its per-row state in the same row-sliced arrays
+    a = eng.decode(num_steps=16, chains=1, beam1=True).cpu().numpy()
+    b = eng.decode(num_steps=16, chains=3, beam1=True).cpu().numpy()
     assert np.array_equal(a, b)
 
 
@@ -291,6 +330,13 @@ def test_npz_checkpoint_round_trip(tmp_path):
     tb = b.predict_tokens({"encoder_input_tokens": np.stack([e["inputs"] if len(e["inputs"]) == 256 else np.pad(
         e["inputs"], ((0, 256 - len(e["inputs"])), (0, 0))) for e in b.preprocess(b.audio_to_dataset(audio))])})
     assert np.array_equal(ta, tb)
+    # the t5x directory layout (msgpack index + zarr arrays) restores the same weights
+    from mt3_amd import checkpoints
+    checkpoints.save_t5x_checkpoint(str(tmp_path / "t5x_ckpt"), params, chunk_rows=100)
+    c = inference.InferenceModel(str(tmp_path / "t5x_ckpt"), "mt3", config=cfg, batch_size=2, early_exit=False)
+    tc = c.predict_tokens({"encoder_input_tokens": np.stack([e["inputs"] if len(e["inputs"]) == 256 else np.pad(
+        e["inputs"], ((0, 256 - len(e["inputs"])), (0, 0))) for e in c.preprocess(c.audio_to_dataset(audio))])})
+    assert np.array_equal(ta, tc)
     with pytest.raises(ValueError):
         inference.InferenceModel("/nonexistent/checkpoint_dir", "mt3", config=cfg)
     with pytest.raises(Exception):
