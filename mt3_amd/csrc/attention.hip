@@ -200,6 +200,46 @@ int launch_encoder_attention(int dtype, const void* qkv, void* out, int B, int T
 }
 
 // ------------------------------------------------------------------------- decode attention
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+
+// q . k over one 16-byte chunk.  bf16: 4 x v_dot2c_f32_bf16 straight on the packed operands (exact
+// products, f32 accumulate) -- neither q nor k is unpacked; f32: 4 FMAs.
+template <typename CT>
+__device__ __forceinline__ float chunk_dot(const u32x4& q, const u32x4& k);
+template <>
+__device__ __forceinline__ float chunk_dot<__bf16>(const u32x4& q, const u32x4& k) {
+  const bf16x8 a = __builtin_bit_cast(bf16x8, q), b = __builtin_bit_cast(bf16x8, k);
+  float s = 0.f;
+  s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), s, false);
+  s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), s, false);
+  s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), s, false);
+  s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), s, false);
+  return s;
+}
+template <>
+__device__ __forceinline__ float chunk_dot<float>(const u32x4& q, const u32x4& k) {
+  const f32x4 a = __builtin_bit_cast(f32x4, q), b = __builtin_bit_cast(f32x4, k);
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s = __builtin_fmaf(a[j], b[j], s);
+  return s;
+}
+
+// sum over the LPK (8 or 16) consecutive lanes that share a key, on the DPP network (no LDS traffic):
+// xor 1 and xor 2 inside a quad, then the mirrored half-row / row holds the other partial sum
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int LPK>
+__device__ __forceinline__ float key_group_sum(float v) {
+  v = dpp_add<0xB1>(v);                          // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);                          // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);                         // row_half_mirror: lane i <-> 7 - i
+  if constexpr (LPK == 16) v = dpp_add<0x140>(v);   // row_mirror: lane i <-> 15 - i
+  return v;
+}
+
 template <typename CT, bool APPEND, int NW>
 __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int KPL = CTraits<CT>::KPL;
@@ -208,6 +248,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int KPW = 64 / LPK;           // keys per wave per load
   constexpr int STRIDE = NW * KPW;        // keys per block iteration
   constexpr int UNROLL = 4;
+  constexpr float kLog2e = 1.4426950408889634f;
 
   __shared__ float s_m[NW][LPK], s_l[NW][LPK], s_acc[NW][LPK][KPL];
 
@@ -216,85 +257,87 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   const int sub = lane % LPK, slot = lane / LPK;
   const int n_keys = a.step ? (a.step[b] + 1) : a.n_keys;      // per-row position counter
   const int pos = n_keys - 1;
+  const int n_cache = APPEND ? pos : n_keys;                   // keys that come from the cache
 
   const CT* kc = static_cast<const CT*>(a.kcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;
   const CT* vc = static_cast<const CT*>(a.vcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;
-  const CT* nk = nullptr;
-  const CT* nv = nullptr;
+  u32x4 new_k = {0u, 0u, 0u, 0u}, new_v = {0u, 0u, 0u, 0u};
   if constexpr (APPEND) {
-    nk = static_cast<const CT*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D;
-    nv = static_cast<const CT*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D;
-    // persist this step's K/V row (read back by later steps; this step reads it from nk/nv)
-    if (tid < 2 * LPK) {
-      const int which = tid / LPK, piece = tid % LPK;
-      const CT* src = (which ? nv : nk) + piece * KPL;
-      CT* dst = (which ? static_cast<CT*>(a.vcache) : static_cast<CT*>(a.kcache)) +
-                ((static_cast<size_t>(b) * a.H + h) * a.cap + pos) * D + piece * KPL;
-      *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(src);
+    // this step's K/V row: folded in below from registers, persisted for the later steps
+    new_k = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride +
+                                            h * D + sub * KPL);
+    new_v = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride +
+                                            h * D + sub * KPL);
+    if (tid < LPK) {
+      const size_t at = ((static_cast<size_t>(b) * a.H + h) * a.cap + pos) * D + sub * KPL;
+      *reinterpret_cast<u32x4*>(static_cast<CT*>(a.kcache) + at) = new_k;
+      *reinterpret_cast<u32x4*>(static_cast<CT*>(a.vcache) + at) = new_v;
     }
   }
 
-  float qf[KPL];
-  {
-    const u32x4 qc = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.q) +
-                                                     static_cast<size_t>(b) * a.q_stride + h * D + sub * KPL);
-    unpack_chunk<CT>(qc, qf);
-  }
+  const u32x4 qc = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.q) +
+                                                   static_cast<size_t>(b) * a.q_stride + h * D + sub * KPL);
 
+  // Online softmax in base 2 (scores scaled by log2 e once; v_exp_f32 is 2^x) with ONE rescale of the
+  // running state per group of UNROLL keys.  Out-of-range keys re-read the row's last cached key and get
+  // weight 0, so the loop is wave-uniform and branch-free; q.k runs on the packed operands.
   float m = -1.0e30f, l = 0.f, acc[KPL];
 #pragma unroll
   for (int j = 0; j < KPL; ++j) acc[j] = 0.f;
 
-  for (int k0 = wave * KPW + slot; k0 < n_keys; k0 += STRIDE * UNROLL) {
+  for (int base = wave * KPW; base < n_cache; base += STRIDE * UNROLL) {
     u32x4 kv[UNROLL], vv[UNROLL];
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const int key = k0 + u * STRIDE;
-      if (key < n_keys) {
-        const CT* kp = kc + static_cast<size_t>(key) * D + sub * KPL;
-        const CT* vp = vc + static_cast<size_t>(key) * D + sub * KPL;
-        if constexpr (APPEND) {
-          if (key == pos) {
-            kp = nk + sub * KPL;
-            vp = nv + sub * KPL;
-          }
-        }
-        // streamed once per step by exactly one CU: non-temporal, so the K/V stream (up to 3.2 GB per
-        // step) does not evict the decoder weights / activations the GEMMs re-read from L2 / MALL
-        kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kp));
-        vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vp));
-      } else {
-        kv[u] = u32x4{0u, 0u, 0u, 0u};
-        vv[u] = u32x4{0u, 0u, 0u, 0u};
-      }
+      const int key = min(base + slot + u * STRIDE, n_cache - 1);
+      // streamed once per step by exactly one CU: non-temporal, so the K/V stream (up to 3.2 GB per
+      // step) does not evict the decoder weights / activations the GEMMs re-read from L2 / MALL
+      kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + static_cast<size_t>(key) * D + sub * KPL));
+      vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + static_cast<size_t>(key) * D + sub * KPL));
     }
+    float sc[UNROLL];
+    float mn = m;
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
-      const int key = k0 + u * STRIDE;
-      float kf[KPL], vf[KPL];
-      unpack_chunk<CT>(kv[u], kf);
-      unpack_chunk<CT>(vv[u], vf);
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < KPL; ++j) s += qf[j] * kf[j];
-#pragma unroll
-      for (int o = LPK / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);      // the LPK lanes of this key
-      if (key < n_keys) {                                              // uniform within the key's lanes
-        const float mn = fmaxf(m, s);
-        const float sc = expf(m - mn), p = expf(s - mn);
-        l = l * sc + p;
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) acc[j] = acc[j] * sc + p * vf[j];
-        m = mn;
-      }
+      sc[u] = key_group_sum<LPK>(chunk_dot<CT>(qc, kv[u])) * kLog2e;
+      if (base + slot + u * STRIDE < n_cache) mn = fmaxf(mn, sc[u]);
     }
+    const float rs = __builtin_amdgcn_exp2f(m - mn);
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) acc[j] *= rs;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const float p = base + slot + u * STRIDE < n_cache ? __builtin_amdgcn_exp2f(sc[u] - mn) : 0.f;
+      psum += p;
+      float vf[KPL];
+      unpack_chunk<CT>(vv[u], vf);
+#pragma unroll
+      for (int j = 0; j < KPL; ++j) acc[j] = __builtin_fmaf(p, vf[j], acc[j]);
+    }
+    l = l * rs + psum;
+    m = mn;
+  }
+  if constexpr (APPEND) {
+    // the new key: one lane group of the block carries it (weight 0 everywhere else)
+    const float s_new = key_group_sum<LPK>(chunk_dot<CT>(qc, new_k)) * kLog2e;
+    const bool mine = tid < LPK;
+    const float mn = mine ? fmaxf(m, s_new) : m;
+    const float rs = __builtin_amdgcn_exp2f(m - mn);
+    const float p = mine ? __builtin_amdgcn_exp2f(s_new - mn) : 0.f;
+    float vf[KPL];
+    unpack_chunk<CT>(new_v, vf);
+#pragma unroll
+    for (int j = 0; j < KPL; ++j) acc[j] = __builtin_fmaf(p, vf[j], acc[j] * rs);
+    l = l * rs + p;
+    m = mn;
   }
   // merge the key slots of this wave (lanes with equal `sub`)
 #pragma unroll
   for (int o = LPK; o < 64; o <<= 1) {
     const float mo = __shfl_xor(m, o), lo = __shfl_xor(l, o);
     const float mn = fmaxf(m, mo);
-    const float ca = expf(m - mn), cb = expf(mo - mn);
+    const float ca = __builtin_amdgcn_exp2f(m - mn), cb = __builtin_amdgcn_exp2f(mo - mn);
     l = l * ca + lo * cb;
 #pragma unroll
     for (int j = 0; j < KPL; ++j) {
@@ -319,7 +362,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
     for (int j = 0; j < KPL; ++j) o[j] = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      const float c = expf(s_m[w][tid] - M);
+      const float c = __builtin_amdgcn_exp2f(s_m[w][tid] - M);
       L += s_l[w][tid] * c;
 #pragma unroll
       for (int j = 0; j < KPL; ++j) o[j] += s_acc[w][tid][j] * c;
