@@ -23,3 +23,4 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if "dec_attn" in n or "copy" in n.lower() or "elementwise" in n.lower():
             print(c, n[:70], r.get("Counter_Name"), r.get("Counter_Value"), "grid", r.get("Grid_Size"))
 PY
+python tools/pmc_summary.py gpurun_out/pmc gpurun_out/pmc > gpurun_out/pmc/summary.log 2>&1; tail -45 gpurun_out/pmc/summary.log

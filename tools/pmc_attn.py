@@ -28,7 +28,7 @@ for _ in range(2):
     b = a.clone()
 torch.cuda.synchronize()
 for n_keys in (1024, 513, 129, 1024, 513, 129):
-    step = torch.tensor([n_keys - 1], device=dev, dtype=torch.int32)
+    step = torch.full((B,), n_keys - 1, device=dev, dtype=torch.int32)      # per-row position counters
     for l in range(layers):
         _lib.check(lib.mt3_op_decode_attention(_lib.MT3_BF16, qkv.data_ptr(), 3 * H * 64, kc[l].data_ptr(),
                                                vc[l].data_ptr(), cap, qkv.data_ptr() + H * 64 * es,

@@ -1,0 +1,71 @@
+"""Reduce the two rocprofv3 --pmc passes of tools/pmc_attn.py (tools/gpu_pmc.sh) to profiles/r1_pmc_summary.json:
+HBM traffic per decode-attention launch = FETCH_SIZE x 2 (gfx950 tallies 128-byte requests as 64: calibrated on
+the 1 GiB copy of the same run) + WRITE_SIZE, against the algorithmic bytes of the launch.
+Usage: python tools/pmc_summary.py gpurun_out/pmc profiles"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+B, H, D, ES, CAP = 256, 6, 64, 2, 1024
+
+
+def rows(counter):
+    fs = glob.glob(os.path.join(src, "**", "%s_counter_collection.csv" % counter), recursive=True)
+    if not fs:
+        raise SystemExit("no %s csv under %s" % (counter, src))
+    shutil.copy(fs[0], os.path.join(dst, "r1_pmc_%s_counter_collection.csv" % counter))
+    out = []
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] == counter:
+            out.append((r["Kernel_Name"], int(r["Grid_Size"]), float(r["Counter_Value"])))
+    return out
+
+
+fetch, write = rows("FETCH_SIZE"), rows("WRITE_SIZE")
+
+
+def pick(rs, pred):
+    return [v for n, g, v in rs if pred(n, g)]
+
+
+# calibration: the LAST 1 GiB f32 clone (a blit kernel: 1 GiB read + 1 GiB written)
+is_copy = lambda n, g: "copyBuffer" in n and g >= 131072
+cal_f, cal_w = pick(fetch, is_copy)[-1], pick(write, is_copy)[-1]
+factor = (1 << 30) / (cal_f * 1024.0)
+
+is_attn = lambda n, g: "dec_attn_kernel" in n
+af, aw = pick(fetch, is_attn), pick(write, is_attn)
+# launch order of pmc_attn.py: (1024, 513, 129) x 2 rounds x 4 layers of self/append, then 8 cross launches
+assert len(af) == 32 and len(aw) == 32, (len(af), len(aw))
+summary = {
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python tools/pmc_attn.py "
+              "(tools/gpu_pmc.sh, reduced by tools/pmc_summary.py), MI355X, round 1",
+    "units": "counter values are KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B: "
+             "MI355X_MICROARCH.md, HBM section), WRITE_SIZE is used as is",
+    "calibration_1GiB_copy": {"FETCH_SIZE_KiB": cal_f, "WRITE_SIZE_KiB": cal_w, "read_bytes_true": 1 << 30,
+                              "fetch_correction_factor": factor},
+    "shape": {"B": B, "H": H, "head_dim": D, "dtype": "bf16", "cap": CAP},
+    "dec_attn_self_append": {},
+}
+
+
+def entry(f_kib, w_kib, n_keys, append):
+    # algorithmic: K and V rows of every cached key, the query, the output (+ the new K/V row read and written)
+    alg = B * H * (2 * (n_keys - (1 if append else 0)) * D * ES + D * ES + D * ES + (4 * D * ES if append else 0))
+    traffic = f_kib * 1024 * 2 + w_kib * 1024
+    return {"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib, "traffic_bytes": traffic, "algorithmic_bytes": alg,
+            "traffic_over_algorithmic": traffic / alg}
+
+
+for i, n_keys in enumerate((1024, 513, 129)):
+    sel = list(range(12 + i * 4, 12 + i * 4 + 4))            # second round: caches hold nothing of these layers
+    summary["dec_attn_self_append"]["n_keys_%d" % n_keys] = entry(
+        sum(af[j] for j in sel) / 4, sum(aw[j] for j in sel) / 4, n_keys, True)
+summary["dec_attn_cross_256_keys"] = entry(sum(af[24:]) / 8, sum(aw[24:]) / 8, 256, False)
+with open(os.path.join(dst, "r1_pmc_summary.json"), "w") as f:
+    json.dump(summary, f, indent=1)
+print(json.dumps({k: v for k, v in summary.items() if k.startswith("dec_attn") or k.startswith("calib")}, indent=1))
