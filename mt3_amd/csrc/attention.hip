@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const CT* __restrict__ qk
   constexpr int KPL = CTraits<CT>::KPL;
   constexpr int KG = CTraits<CT>::KGROUP;       // head-dim / key elements per chunk-MFMA
   constexpr int D = 64;
-  constexpr int ROWK = D + KPL;                 // K tile row (elements), one pad chunk
+  constexpr int ROWK = D + 2 * KPL;             // K tile row (elements): stride 32 mod 64 bytes, conflict-free b128 reads
   constexpr int ROWV = T + 8;                   // V^T row (elements): keeps 8/16-byte alignment
   constexpr int CH = D / KPL;                   // chunks per K/V row
   constexpr int NC = D / KG;                    // K-groups across the head dim

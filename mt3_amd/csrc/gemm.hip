@@ -75,7 +75,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   constexpr int KPL = CTraits<CT>::KPL;
   constexpr int KG = CTraits<CT>::KGROUP;
   constexpr int CPR = BK / KPL;          // 16-byte chunks per tile row
-  constexpr int ROWE = BK + KPL;         // LDS row length in elements (one pad chunk)
+  // LDS row length in elements: two pad chunks make the row stride 32 (mod 64) bytes, the stride at which the
+  // 16-lane groups of a ds_read_b128 fragment read (16 rows x one 16-byte chunk) touch every bank exactly once;
+  // with one pad chunk (stride 16 mod 64) they are 2-way conflicted (8 instead of 4 LDS cycles per read)
+  constexpr int ROWE = BK + 2 * KPL;
   constexpr int FM = BM / (WM * 16), FN = BN / (WN * 16);
   constexpr int A_PASSES = BM * CPR / NT, B_PASSES = BN * CPR / NT;
   constexpr int ROWS_PER_PASS = NT / CPR;

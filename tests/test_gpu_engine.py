@@ -230,6 +230,40 @@ def test_inference_model_end_to_end():
         inference.InferenceModel("random:0", "nope")
 
 
+def test_inference_edge_cases():
+    """Boundaries of the host framing the reference tests only implicitly (NB:318-335): empty audio (one
+    1-frame segment), an exact multiple of the segment length (the always-added hop spills into one more
+    1-frame segment), more segments than `batch_size` (several engine batches == one big batch, row for row),
+    and the C ABI's error path surfacing as an exception instead of a silent fallback."""
+    from mt3_amd import _lib, inference
+    small = dict(batch_size=2, early_exit=True, decoding="greedy")
+    m = inference.InferenceModel("random:0", "mt3", **small)
+    ns = m(np.zeros(0, np.float32))
+    ex = m.preprocess(m.audio_to_dataset(np.zeros(0, np.float32)))
+    assert len(ex) == 1 and ex[0]["inputs"].shape == (1, 512) and ns.total_time >= 0.0
+    audio = OF.synth_audio(2, seed=11).reshape(-1)                          # exactly 2 x 32768 samples
+    ex = m.preprocess(m.audio_to_dataset(audio))
+    assert [e["inputs"].shape[0] for e in ex] == [256, 256, 1]
+    assert abs(ex[2]["input_times"][0] - 4.096) < 1e-12
+    feats = np.zeros((3, 256, 512), np.float32)
+    for i, e in enumerate(ex):
+        feats[i, : e["inputs"].shape[0]] = e["inputs"]
+    split = m.predict_tokens({"encoder_input_tokens": feats})               # batches of 2 + 1
+    big = inference.InferenceModel("random:0", "mt3", batch_size=4, early_exit=True, decoding="greedy")
+    whole = big.predict_tokens({"encoder_input_tokens": feats})
+    assert np.array_equal(split, whole)
+    # error path: decode before any encode, bad shapes
+    eng = network.Transformer(network.T5Config(), input_length=256, max_decode_length=1024, max_batch=2)
+    eng.load_params(network.init_random_params(network.T5Config(), seed=0))
+    with pytest.raises(_lib.Mt3Error):
+        eng._batch = 1
+        eng.decode(num_steps=4)
+    with pytest.raises(ValueError):
+        eng.encode(torch.zeros(1, 100, 512, device="cuda"))
+    with pytest.raises(_lib.Mt3Error):
+        eng.encode(torch.zeros(3, 256, 512, device="cuda"))               # batch > max_batch
+
+
 def test_ismir2021_preset_and_base_shape():
     """The other reference presets: ismir2021 (T = 512 frames, 127 velocity bins, vocab 1664,
     NoteEncodingSpec) end to end, and the ismir2022/base.gin shape (emb 768, 12 heads, 12+12 layers,
