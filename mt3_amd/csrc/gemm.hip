@@ -20,6 +20,8 @@
 // column tiles of one row panel share an L2.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 #include "device.h"
 #include "kernels.h"
@@ -28,14 +30,31 @@ namespace mt3k {
 
 // stage one K-slice of A (optionally f32 -> compute type, accumulating sum of squares for the fused
 // RMSNorm) and of Wt from global memory into registers
-template <typename CT, bool A_F32, bool NORM, int A_PASSES, int B_PASSES, int ROWS_PER_PASS>
+// Which 16-byte chunk of a [rows][CPR] tile thread `tid` moves in pass p.  Power-of-two CPR: CPR consecutive
+// lanes share a row (the fused-norm reduction relies on that); otherwise (K = 384: 48 chunks per row) chunks
+// are dealt linearly, NT per pass.
+template <int CPR, int NT>
+__device__ __forceinline__ void tile_chunk(int tid, int p, int* row, int* chunk) {
+  if constexpr ((CPR & (CPR - 1)) == 0 && NT % CPR == 0) {
+    *row = tid / CPR + p * (NT / CPR);
+    *chunk = tid % CPR;
+  } else {
+    const int c = tid + p * NT;
+    *row = c / CPR;
+    *chunk = c % CPR;
+  }
+}
+
+template <typename CT, bool A_F32, bool NORM, int A_PASSES, int B_PASSES, int CPR, int NT>
 __device__ __forceinline__ void gemm_load_tiles(u32x4 (&a_reg)[A_PASSES], u32x4 (&b_reg)[B_PASSES],
                                                 float (&ss)[A_PASSES], const void* gA, const void* gW, int m0,
-                                                int n0, int ld_row, int ld_chunk, int gM, int gLda, int gK, int k0) {
+                                                int n0, int tid, int gM, int gLda, int gK, int k0) {
   constexpr int KPL = CTraits<CT>::KPL;
 #pragma unroll
   for (int p = 0; p < A_PASSES; ++p) {
-    int row = m0 + ld_row + p * ROWS_PER_PASS;
+    int ld_row, ld_chunk;
+    tile_chunk<CPR, NT>(tid, p, &ld_row, &ld_chunk);
+    int row = m0 + ld_row;
     row = row < gM ? row : gM - 1;                       // clamp: out-of-range rows are never stored
     const size_t e = static_cast<size_t>(row) * gLda + k0 + ld_chunk * KPL;
     if constexpr (A_F32) {
@@ -63,7 +82,9 @@ __device__ __forceinline__ void gemm_load_tiles(u32x4 (&a_reg)[A_PASSES], u32x4 
   }
 #pragma unroll
   for (int p = 0; p < B_PASSES; ++p) {
-    const int row = n0 + ld_row + p * ROWS_PER_PASS;       // N is a multiple of BN: always in range
+    int ld_row, ld_chunk;
+    tile_chunk<CPR, NT>(tid, p, &ld_row, &ld_chunk);
+    const int row = n0 + ld_row;                           // N is a multiple of BN: always in range
     const size_t e = static_cast<size_t>(row) * gK + k0 + ld_chunk * KPL;
     b_reg[p] = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(gW) + e);
   }
@@ -83,7 +104,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   constexpr int A_PASSES = BM * CPR / NT, B_PASSES = BN * CPR / NT;
   constexpr int ROWS_PER_PASS = NT / CPR;
   static_assert(BM * CPR % NT == 0 && BN * CPR % NT == 0, "tile/threads mismatch");
-  static_assert(NT % CPR == 0 && (CPR & (CPR - 1)) == 0 && CPR <= 64, "CPR: power of two, <= one wave, divides NT");
+  static_assert(!NORM || (NT % CPR == 0 && (CPR & (CPR - 1)) == 0 && CPR <= 64),
+                "fused norm: CPR a power of two, <= one wave, dividing NT");
   static_assert(BK % KG == 0, "BK must be a multiple of the MFMA K-group");
   static_assert(!NORM || A_F32, "NORM needs the f32 A operand");
   static_assert(EPI != MT3_EPI_GEGLU || (FN % 2 == 0), "GEGLU pairs fragments");
@@ -122,20 +144,25 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   const CT* a_base = &As[(wm * FM * 16 + frag_row) * ROWE + frag_g * KPL];
   const CT* b_base = &Bs[(wn * FN * 16 + frag_row) * ROWE + frag_g * KPL];
 
-  gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, ROWS_PER_PASS>(a_reg, b_reg, ss, gA, gW, m0, n0, ld_row, ld_chunk,
-                                                                      gM, gLda, gK, 0);
+  gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg, b_reg, ss, gA, gW, m0, n0, tid, gM, gLda, gK, 0);
   for (int k0 = 0; k0 < gK; k0 += BK) {
     __syncthreads();                    // every wave is done reading the previous tile
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p)
-      *reinterpret_cast<u32x4*>(&As[(ld_row + p * ROWS_PER_PASS) * ROWE + ld_chunk * KPL]) = a_reg[p];
+    for (int p = 0; p < A_PASSES; ++p) {
+      int r, ch;
+      tile_chunk<CPR, NT>(tid, p, &r, &ch);
+      *reinterpret_cast<u32x4*>(&As[r * ROWE + ch * KPL]) = a_reg[p];
+    }
 #pragma unroll
-    for (int p = 0; p < B_PASSES; ++p)
-      *reinterpret_cast<u32x4*>(&Bs[(ld_row + p * ROWS_PER_PASS) * ROWE + ld_chunk * KPL]) = b_reg[p];
+    for (int p = 0; p < B_PASSES; ++p) {
+      int r, ch;
+      tile_chunk<CPR, NT>(tid, p, &r, &ch);
+      *reinterpret_cast<u32x4*>(&Bs[r * ROWE + ch * KPL]) = b_reg[p];
+    }
     __syncthreads();
     if (k0 + BK < gK)                   // next slice in flight while the MFMAs below run
-      gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, ROWS_PER_PASS>(a_reg, b_reg, ss, gA, gW, m0, n0, ld_row,
-                                                                          ld_chunk, gM, gLda, gK, k0 + BK);
+      gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg, b_reg, ss, gA, gW, m0, n0, tid, gM, gLda, gK,
+                                                                    k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK / KG; ++kk) {
       u32x4 af[FM], bf[FN];
@@ -234,6 +261,11 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
       if (deep) return launch_cfg<CT, 32, 64, 16 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 64, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
     } else {
+      if constexpr (!NORM && !A_F32 && KG == 32) {
+        // the attention out-projections (K = 384 = 12 K-groups) as ONE slice as well (-1 % of the decode; the
+        // same for wo, K = 1024 in 133 KB of LDS, measured slower than its two 512-slices)
+        if (g.K == 12 * KG) return launch_cfg<CT, 32, 32, 12 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
+      }
       if (deep) return launch_cfg<CT, 32, 32, 16 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 32, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
     }

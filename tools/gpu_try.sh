@@ -1,5 +1,5 @@
 #!/bin/bash
-# parity tests of the GEMM / engine groups, then the full bench line (no CPU baseline)
+# parity tests of the kernel / engine groups, then the full bench line twice (no CPU baseline)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
@@ -11,6 +11,6 @@ echo "bench exit $?"
 tail -1 gpurun_out/try_bench.log | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())
-print('  value %.1f  ms/step %.1f  roofline %s' % (d['value'], d['ms_per_step'], {k: d['roofline'][k] for k in ('achieved', 'frac')}))
+print('  value %.1f  ms/step %.1f  roofline %s  1-chain decode %.1f ms' % (d['value'], d['ms_per_step'], {k: round(d['roofline'][k], 3) for k in ('achieved', 'frac')}, d['roofline']['decode_ms_single_chain']))
 "
 done
