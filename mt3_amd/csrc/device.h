@@ -64,6 +64,19 @@ __device__ __forceinline__ float to_f32(CT v) {
   return static_cast<float>(v);
 }
 
+// value of the neighbouring lane (lane ^ 1) on the DPP network (quad_perm [1,0,3,2])
+__device__ __forceinline__ float lane_xor1(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+// two floats -> one dword of two bf16 (lo at the lower address), round-to-nearest-even
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+  bf16x2_v h;
+  h[0] = static_cast<__bf16>(lo);
+  h[1] = static_cast<__bf16>(hi);
+  return __builtin_bit_cast(unsigned, h);
+}
+
 // pack 8 floats into one bf16 chunk / 4 floats into one f32 chunk
 __device__ __forceinline__ u32x4 pack_bf16x8(const float (&v)[8]) {
   bf16x8 h;

@@ -26,6 +26,11 @@
 #include "device.h"
 #include "kernels.h"
 
+// phase marks for tools/micro/gemm_phases.hip (which defines the macro before including this file); no-ops here
+#ifndef MT3_PROF_MARK
+#define MT3_PROF_MARK(i)
+#endif
+
 namespace mt3k {
 
 // stage one K-slice of A (optionally f32 -> compute type, accumulating sum of squares for the fused
@@ -112,7 +117,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
 
   __shared__ __attribute__((aligned(16))) CT As[BM * ROWE];
   __shared__ __attribute__((aligned(16))) CT Bs[BN * ROWE];
-  __shared__ float rs_s[BM];
+  constexpr int NP = CPR > 16 ? CPR / 16 : 1;      // partial sums of squares per tile row (one per 16-lane DPP row)
+  __shared__ float ss_part[NORM ? BM * NP : 1];
 
   // scalars out of the by-value argument struct (never take its address: that forces a private copy)
   const void* const gA = g.A;
@@ -121,6 +127,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   const float* const gAux = g.aux;
   const int gM = g.M, gN = g.N, gK = g.K, gLda = g.lda, gLdo = g.ldo, gSeq = g.seq_len;
 
+  MT3_PROF_MARK(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = gN / BN;
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg, b_reg, ss, gA, gW, m0, n0, tid, gM, gLda, gK, 0);
   for (int k0 = 0; k0 < gK; k0 += BK) {
     __syncthreads();                    // every wave is done reading the previous tile
+    MT3_PROF_MARK(1);
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       int r, ch;
@@ -160,6 +168,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
       *reinterpret_cast<u32x4*>(&Bs[r * ROWE + ch * KPL]) = b_reg[p];
     }
     __syncthreads();
+    MT3_PROF_MARK(2);
     if (k0 + BK < gK)                   // next slice in flight while the MFMAs below run
       gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg, b_reg, ss, gA, gW, m0, n0, tid, gM, gLda, gK,
                                                                     k0 + BK);
@@ -176,62 +185,123 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
         for (int j = 0; j < FN; ++j) mfma_chunk<CT>(af[i], bf[j], acc[i][j]);
     }
   }
+  MT3_PROF_MARK(3);
 
   if constexpr (NORM) {
-    // each tile row was streamed by CPR consecutive lanes: finish mean(x^2) and publish rsqrt
+    // Each tile row was streamed by CPR consecutive lanes.  Their partial sums of squares meet on the DPP
+    // network inside each 16-lane row (4 v_add_f32_dpp per value; the 48 dependent ds_bpermute shuffles this
+    // replaces cost 2 us of a 7 us decode GEMM), and the <= 4 row partials are added by the reader.  The
+    // reduction tree is the same for every tile row, so results do not depend on where in a tile a row lands.
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
-      float s = ss[p];
-#pragma unroll
-      for (int o = CPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
-      if (ld_chunk == 0) rs_s[ld_row + p * ROWS_PER_PASS] = rsqrtf(s / static_cast<float>(gK) + 1e-6f);
+      float v = ss[p];
+      if constexpr (CPR >= 2) v += lane_xor1(v);
+      if constexpr (CPR >= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+      if constexpr (CPR >= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+      if constexpr (CPR >= 16) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+      const bool writer = CPR >= 16 ? (ld_chunk & 15) == 0 : ld_chunk == 0;
+      if (writer) ss_part[(ld_row + p * ROWS_PER_PASS) * NP + (CPR > 16 ? ld_chunk / 16 : 0)] = v;
     }
     __syncthreads();
   }
-
+  // 1 / rms of tile row `lrow` (fused RMSNorm: the scale vector is folded into the weights)
+  auto row_rs = [&](int lrow) -> float {
+    if constexpr (!NORM) return 1.f;
+    float t = ss_part[lrow * NP];
+#pragma unroll
+    for (int q = 1; q < NP; ++q) t += ss_part[lrow * NP + q];
+    return rsqrtf(t / static_cast<float>(gK) + 1e-6f);
+  };
+  MT3_PROF_MARK(5);
   // ---- epilogue: C fragment (i, j): rows (lane>>4)*4 + r, col lane & 15
+  // 2-byte outputs are never stored one element at a time (a sub-dword store costs a read-modify-write in the
+  // cache: the bf16 STORE epilogue of a decode GEMM took 2.5 us against 0.7 us for the f32 RESID one): lanes l
+  // and l^1 hold adjacent columns, so they swap over DPP and the even lane stores rows r = 0, 1, the odd lane
+  // rows r = 2, 3 of the pair as whole dwords.
+  constexpr bool PAIRED = sizeof(CT) == 2 && (EPI == MT3_EPI_STORE || EPI == MT3_EPI_GEGLU || EPI == MT3_EPI_HEADS);
+  if constexpr (PAIRED) {
+    const int odd = frag_row & 1;
 #pragma unroll
-  for (int i = 0; i < FM; ++i) {
+    for (int i = 0; i < FM; ++i) {
+      const int lrow0 = wm * FM * 16 + i * 16 + frag_g * 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int lrow = wm * FM * 16 + i * 16 + frag_g * 4 + r;
-      const int row = m0 + lrow;
-      if (row >= gM) continue;
-      const float rs = NORM ? rs_s[lrow] : 1.f;
-      if constexpr (EPI == MT3_EPI_GEGLU) {
-        CT* out = static_cast<CT*>(gO);
+      for (int j = 0; j < FN; j += (EPI == MT3_EPI_GEGLU ? 2 : 1)) {
+        float mine[4], other[4];
 #pragma unroll
-        for (int j = 0; j < FN; j += 2) {
-          const int col = n0 + wn * FN * 16 + j * 16;                  // multiple of 32
-          const float gate = acc[i][j][r] * rs, lin = acc[i][j + 1][r] * rs;
-          out[static_cast<size_t>(row) * gLdo + (col >> 1) + frag_row] = to_ct<CT>(gelu_tanh(gate) * lin);
+        for (int r = 0; r < 4; ++r) {
+          const float rs = row_rs(lrow0 + r);
+          if constexpr (EPI == MT3_EPI_GEGLU) mine[r] = gelu_tanh(acc[i][j][r] * rs) * (acc[i][j + 1][r] * rs);
+          else mine[r] = acc[i][j][r] * rs;
+          other[r] = lane_xor1(mine[r]);
         }
-      } else {
+        // logical output column of this lane's element, and of the pair's even element
+        const int col = EPI == MT3_EPI_GEGLU ? ((n0 + wn * FN * 16 + j * 16) >> 1) + frag_row
+                                             : n0 + wn * FN * 16 + j * 16 + frag_row;
+        const int col_even = col - odd;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const int col = n0 + wn * FN * 16 + j * 16 + frag_row;
-          const float v = acc[i][j][r] * rs;
-          if constexpr (EPI == MT3_EPI_STORE) {
-            static_cast<CT*>(gO)[static_cast<size_t>(row) * gLdo + col] = to_ct<CT>(v);
-          } else if constexpr (EPI == MT3_EPI_RESID) {
-            float* o = static_cast<float*>(gO) + static_cast<size_t>(row) * gLdo + col;
-            *o = *o + v;
-          } else if constexpr (EPI == MT3_EPI_POS) {
-            static_cast<float*>(gO)[static_cast<size_t>(row) * gLdo + col] =
-                v + gAux[static_cast<size_t>(row % gSeq) * gN + col];
-          } else if constexpr (EPI == MT3_EPI_F32) {
-            static_cast<float*>(gO)[static_cast<size_t>(row) * gLdo + col] = v;
-          } else {  // MT3_EPI_HEADS: col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
-            const int hd = gN >> 1;                       // H * 64
-            const int kv = col / hd, h = (col % hd) >> 6, d = col & 63;
-            const int b = row / gSeq, t = row % gSeq, H = hd >> 6, B = gM / gSeq;
-            const size_t dst = ((((static_cast<size_t>(kv) * B + b) * H + h) * gSeq) + t) * 64 + d;
-            static_cast<CT*>(gO)[dst] = to_ct<CT>(v);
+        for (int h = 0; h < 2; ++h) {
+          const int r = odd * 2 + h;
+          const int row = m0 + lrow0 + r;
+          if (row >= gM) continue;
+          const unsigned pair = odd ? pack_bf16x2(other[r], mine[r]) : pack_bf16x2(mine[r], other[r]);
+          size_t dst;
+          if constexpr (EPI == MT3_EPI_HEADS) {   // col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
+            const int hd = gN >> 1;               // H * 64
+            const int kv = col_even / hd, hh = (col_even % hd) >> 6, d = col_even & 63;
+            const int bb = row / gSeq, t = row % gSeq, H = hd >> 6, B = gM / gSeq;
+            dst = ((((static_cast<size_t>(kv) * B + bb) * H + hh) * gSeq) + t) * 64 + d;
+          } else {
+            dst = static_cast<size_t>(row) * gLdo + col_even;
+          }
+          *reinterpret_cast<unsigned*>(static_cast<CT*>(gO) + dst) = pair;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = wm * FM * 16 + i * 16 + frag_g * 4 + r;
+        const int row = m0 + lrow;
+        if (row >= gM) continue;
+        const float rs = row_rs(lrow);
+        if constexpr (EPI == MT3_EPI_GEGLU) {
+          CT* out = static_cast<CT*>(gO);
+#pragma unroll
+          for (int j = 0; j < FN; j += 2) {
+            const int col = n0 + wn * FN * 16 + j * 16;                  // multiple of 32
+            const float gate = acc[i][j][r] * rs, lin = acc[i][j + 1][r] * rs;
+            out[static_cast<size_t>(row) * gLdo + (col >> 1) + frag_row] = to_ct<CT>(gelu_tanh(gate) * lin);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int col = n0 + wn * FN * 16 + j * 16 + frag_row;
+            const float v = acc[i][j][r] * rs;
+            if constexpr (EPI == MT3_EPI_STORE) {
+              static_cast<CT*>(gO)[static_cast<size_t>(row) * gLdo + col] = to_ct<CT>(v);
+            } else if constexpr (EPI == MT3_EPI_RESID) {
+              float* o = static_cast<float*>(gO) + static_cast<size_t>(row) * gLdo + col;
+              *o = *o + v;
+            } else if constexpr (EPI == MT3_EPI_POS) {
+              static_cast<float*>(gO)[static_cast<size_t>(row) * gLdo + col] =
+                  v + gAux[static_cast<size_t>(row % gSeq) * gN + col];
+            } else if constexpr (EPI == MT3_EPI_F32) {
+              static_cast<float*>(gO)[static_cast<size_t>(row) * gLdo + col] = v;
+            } else {  // MT3_EPI_HEADS: col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
+              const int hd = gN >> 1;                       // H * 64
+              const int kv = col / hd, h = (col % hd) >> 6, d = col & 63;
+              const int b = row / gSeq, t = row % gSeq, H = hd >> 6, B = gM / gSeq;
+              const size_t dst = ((((static_cast<size_t>(kv) * B + b) * H + h) * gSeq) + t) * 64 + d;
+              static_cast<CT*>(gO)[dst] = to_ct<CT>(v);
+            }
           }
         }
       }
     }
   }
+  MT3_PROF_MARK(4);
 }
 
 // ------------------------------------------------------------------ dispatch
