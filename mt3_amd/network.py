@@ -111,7 +111,7 @@ class Transformer:
     """One engine per (device, stream)."""
 
     def __init__(self, config: T5Config, input_length: int = 256, max_decode_length: int = 1024,
-                 max_batch: int = 8, decode_chains: int = 2):
+                 max_batch: int = 8, decode_chains: int = 1):
         self.config = config
         self.input_length, self.max_decode_length, self.max_batch = input_length, max_decode_length, max_batch
         if config.dtype not in ("bfloat16", "float32"):
