@@ -18,10 +18,10 @@
 //     rewrites the whole [B,H,64,L] cache per step: layers.py:272-292).
 //   * one decode step = 8 x 8 + 2 kernels with per-row position counters in DEVICE memory (the argmax
 //     kernel also writes the next step's embedding row), captured once per
-//     batch size into a hipGraph and replayed L times.  The batch is dealt to `decode_chains`
-//     independent row groups, one graph BRANCH each (fork/join capture over several streams): the
-//     small-M GEMMs are latency-bound and the attention kernels HBM-bound, so concurrent branches
-//     overlap one chain's launch/latency floors with another chain's K/V streaming.
+//     batch size into a hipGraph and replayed L times.  The batch can be dealt to `decode_chains`
+//     independent row groups, one graph BRANCH each (fork/join capture over several streams), so that one
+//     chain's latency-bound GEMMs run beside another chain's HBM-bound K/V streaming; it paid +6 % with the
+//     first kernels and nothing with the current ones, so the default is one chain.
 //   * sized for 288 GB HBM: all workspaces for max_batch are allocated up front
 //     (B=256: ~3.3 GB KV cache + ~0.9 GB cross K/V + ~0.5 GB activations in bf16).
 #include <hip/hip_runtime.h>
