@@ -243,7 +243,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
           const int r = odd * 2 + h;
           const int row = m0 + lrow0 + r;
           if (row >= gM) continue;
-          const unsigned pair = odd ? pack_bf16x2(other[r], mine[r]) : pack_bf16x2(mine[r], other[r]);
+          // (selects, not mine[r]: a runtime index would put the arrays in scratch memory)
+          const float lo = odd ? other[2 + h] : mine[h], hi = odd ? mine[2 + h] : other[h];
+          const unsigned pair = pack_bf16x2(lo, hi);
           size_t dst;
           if constexpr (EPI == MT3_EPI_HEADS) {   // col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
             const int hd = gN >> 1;               // H * 64
