@@ -64,21 +64,38 @@ int launch_rmsnorm(int dtype, const float* x, const float* scale, void* out_ct, 
   return MT3_OK;
 }
 
+// one float4 of a decoder-input row: the f32 value, and for the bf16 decode path its compute-type copy and the
+// exact sum of squares of its 16-column group (4 consecutive lanes = one quad own one group)
+__device__ __forceinline__ void put_row_piece(float4 v, float* y, void* y_ct, float* y_ss, size_t row, int dim, int i) {
+  *reinterpret_cast<float4*>(y + row * dim + i) = v;
+  if (y_ct) {
+    float t = __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
+    t = quad_sum(t);
+    if ((threadIdx.x & 3) == 0) y_ss[row * (dim >> 4) + (i >> 4)] = t;
+    uint2 pk;
+    pk.x = pack_bf16x2(v.x, v.y);
+    pk.y = pack_bf16x2(v.z, v.w);
+    *reinterpret_cast<uint2*>(static_cast<__bf16*>(y_ct) + row * dim + i) = pk;
+  }
+}
+
 __global__ __launch_bounds__(128) void embed_kernel(const float* __restrict__ table, const float* __restrict__ pos,
                                                      const int* __restrict__ tok, const int* __restrict__ step,
-                                                     float* __restrict__ y, int dim) {
+                                                     float* __restrict__ y, void* __restrict__ y_ct,
+                                                     float* __restrict__ y_ss, int dim) {
   const int b = blockIdx.x;
   const float* e = table + static_cast<size_t>(tok[b]) * dim;
   const float* p = pos + static_cast<size_t>(step[b]) * dim;
   for (int i = threadIdx.x * 4; i < dim; i += 512) {
     const float4 a = *reinterpret_cast<const float4*>(e + i), c = *reinterpret_cast<const float4*>(p + i);
-    *reinterpret_cast<float4*>(y + static_cast<size_t>(b) * dim + i) = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+    put_row_piece(make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w), y, y_ct, y_ss, b, dim, i);
   }
 }
 
-int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, int B, int dim,
-                 hipStream_t s) {
-  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(128), 0, s, table, pos, tok, step, y, dim);
+int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, void* y_ct,
+                 float* y_ss, int B, int dim, hipStream_t s) {
+  if (y_ct && (!y_ss || dim % 16)) return mt3::fail(MT3_ERR_INVALID, "embed: y_ct needs y_ss and dim % 16 == 0");
+  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(128), 0, s, table, pos, tok, step, y, y_ct, y_ss, dim);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }
@@ -118,7 +135,8 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
                                                            int* __restrict__ n_done, int* __restrict__ step,
                                                            const float* __restrict__ table,
                                                            const float* __restrict__ pos_table, int max_pos,
-                                                           float* __restrict__ y_next, int dim,
+                                                           float* __restrict__ y_next, void* __restrict__ y_ct,
+                                                           float* __restrict__ y_ss, int dim,
                                                            float* __restrict__ beam_f, int* __restrict__ beam_len,
                                                            const float* __restrict__ beam_cfg, int beam_rows) {
   __shared__ float s_v[8], s_sum[4];
@@ -224,22 +242,21 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
     const float* p = pos_table + static_cast<size_t>(tp) * dim;
     for (int i = tid * 4; i < dim; i += 1024) {
       const float4 a = *reinterpret_cast<const float4*>(e + i), c = *reinterpret_cast<const float4*>(p + i);
-      *reinterpret_cast<float4*>(y_next + static_cast<size_t>(b) * dim + i) =
-          make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+      put_row_piece(make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w), y_next, y_ct, y_ss, b, dim, i);
     }
   }
 }
 
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
-                       float* y_next, int dim, int B, const BeamState* beam, hipStream_t s) {
+                       float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam, hipStream_t s) {
   if (beam)
     hipLaunchKernelGGL(argmax_step_kernel<true>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
-                       done, n_done, step, table, pos_table, max_pos, y_next, dim, beam->f, beam->len, beam->cfg,
-                       beam->rows);
+                       done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, beam->f, beam->len,
+                       beam->cfg, beam->rows);
   else
     hipLaunchKernelGGL(argmax_step_kernel<false>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
-                       done, n_done, step, table, pos_table, max_pos, y_next, dim, nullptr, nullptr, nullptr, 0);
+                       done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, nullptr, nullptr, nullptr, 0);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

@@ -68,6 +68,20 @@ __device__ __forceinline__ float to_f32(CT v) {
 __device__ __forceinline__ float lane_xor1(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
+// sum over the 16 lanes of a DPP row (every lane gets it): xor 1, xor 2 in the quad, then the mirrored half-row / row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += lane_xor1(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+// sum over the 4 lanes of a quad (every lane gets it)
+__device__ __forceinline__ float quad_sum(float v) {
+  v += lane_xor1(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  return v;
+}
 // two floats -> one dword of two bf16 (lo at the lower address), round-to-nearest-even
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));

@@ -94,6 +94,11 @@ struct mt3_engine {
   void* enc_out = nullptr;
   // decode workspaces
   float* y = nullptr;
+  // bf16 decode path: compute-type copy of the residual rows + their per-16-column sums of squares, kept up to
+  // date by every producer of `y` (embed / argmax / the RESID GEMMs), read by the RMSNorm-fused GEMMs
+  void* y_ct = nullptr;          // [max_batch][emb] bf16
+  float* y_ss = nullptr;         // [max_batch][emb/16]
+  bool y_split = false;
   void* qkv_d = nullptr;
   void* attn_d = nullptr;
   void* q_d = nullptr;
@@ -277,6 +282,24 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   // the decoder input row of this step (Embed(tok) + FixedEmbed[t]) is already in `y`: written by the
   // embed launch before the first step and by the previous step's argmax kernel afterwards
   float* y = e->y + static_cast<size_t>(row0) * emb;
+  // residual rows as the norm-fused GEMMs see them: f32 with in-kernel statistics, or (bf16 path) the
+  // compute-type copy with the producer's partial sums
+  const bool split = e->y_split;
+  char* y_ct = split ? static_cast<char*>(e->y_ct) + static_cast<size_t>(row0) * emb * es : nullptr;
+  float* y_ss = split ? e->y_ss + static_cast<size_t>(row0) * (emb / 16) : nullptr;
+  auto normed = [&](const void* Wt, void* out, int N, int ldo) {
+    mt3k::GemmArgs g = gemm_args(split ? static_cast<const void*>(y_ct) : static_cast<const void*>(y), Wt, out, rows, N,
+                                 emb, ldo);
+    g.a_ss = y_ss;
+    return g;
+  };
+  auto resid = [&](const void* A, const void* Wt, int K) {
+    mt3k::GemmArgs g = gemm_args(A, Wt, y, rows, emb, K, emb);
+    g.out_ct = y_ct;
+    g.out_ss = y_ss;
+    return g;
+  };
+  const int nrm = split ? 2 : 1;
   char* qkv_d = static_cast<char*>(e->qkv_d) + static_cast<size_t>(row0) * 3 * hd * es;
   char* attn_d = static_cast<char*>(e->attn_d) + static_cast<size_t>(row0) * hd * es;
   char* q_d = static_cast<char*>(e->q_d) + static_cast<size_t>(row0) * hd * es;
@@ -285,19 +308,18 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   int* step = e->step + row0;                    // per-row position counters
   const int nl = c.num_decoder_layers;
   if (op == 8 * nl)
-    return mt3k::launch_gemm(dt, gemm_args(y, e->logits_w, logits, rows, c.vocab_size, emb, c.vocab_size), true, true,
-                             MT3_EPI_F32, small, s);
+    return mt3k::launch_gemm(dt, normed(e->logits_w, logits, c.vocab_size, c.vocab_size), !split, nrm, MT3_EPI_F32,
+                             small, s);
   if (op == 8 * nl + 1) {
     const mt3k::BeamState beam{e->beam_f + row0, e->beam_len + row0, e->beam_cfg, c.max_batch};
     return mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
                                     e->cur_tok + row0, e->done + row0, e->n_done, step, e->embedding, e->pos_table,
-                                    kMaxPos, y, emb, rows, (skip & 4) ? &beam : nullptr, s);
+                                    kMaxPos, y, y_ct, y_ss, emb, rows, (skip & 4) ? &beam : nullptr, s);
   }
   LayerDev& L = e->dec[op >> 3];
   switch (op & 7) {
     case 0:
-      return mt3k::launch_gemm(dt, gemm_args(y, L.wqkv, qkv_d, rows, 3 * hd, emb, 3 * hd), true, true, MT3_EPI_STORE,
-                               small, s);
+      return mt3k::launch_gemm(dt, normed(L.wqkv, qkv_d, 3 * hd, 3 * hd), !split, nrm, MT3_EPI_STORE, small, s);
     case 1: {
       if (skip & 1) return MT3_OK;
       mt3k::DecAttnArgs a{};
@@ -316,9 +338,9 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
       return mt3k::launch_decode_attention(dt, a, s);
     }
     case 2:
-      return mt3k::launch_gemm(dt, gemm_args(attn_d, L.wo, y, rows, emb, hd, emb), false, false, MT3_EPI_RESID, small, s);
+      return mt3k::launch_gemm(dt, resid(attn_d, L.wo, hd), false, 0, MT3_EPI_RESID, small, s);
     case 3:
-      return mt3k::launch_gemm(dt, gemm_args(y, L.wq_x, q_d, rows, hd, emb, hd), true, true, MT3_EPI_STORE, small, s);
+      return mt3k::launch_gemm(dt, normed(L.wq_x, q_d, hd, hd), !split, nrm, MT3_EPI_STORE, small, s);
     case 4: {
       if (skip & 2) return MT3_OK;
       mt3k::DecAttnArgs x{};
@@ -334,14 +356,11 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
       return mt3k::launch_decode_attention(dt, x, s);
     }
     case 5:
-      return mt3k::launch_gemm(dt, gemm_args(attn_d, L.wo_x, y, rows, emb, hd, emb), false, false, MT3_EPI_RESID, small,
-                               s);
+      return mt3k::launch_gemm(dt, resid(attn_d, L.wo_x, hd), false, 0, MT3_EPI_RESID, small, s);
     case 6:
-      return mt3k::launch_gemm(dt, gemm_args(y, L.wi, h_d, rows, 2 * c.mlp_dim, emb, c.mlp_dim), true, true,
-                               MT3_EPI_GEGLU, small, s);
+      return mt3k::launch_gemm(dt, normed(L.wi, h_d, 2 * c.mlp_dim, c.mlp_dim), !split, nrm, MT3_EPI_GEGLU, small, s);
     default:
-      return mt3k::launch_gemm(dt, gemm_args(h_d, L.wo_mlp, y, rows, emb, c.mlp_dim, emb), false, false, MT3_EPI_RESID,
-                               small, s);
+      return mt3k::launch_gemm(dt, resid(h_d, L.wo_mlp, c.mlp_dim), false, 0, MT3_EPI_RESID, small, s);
   }
 }
 
@@ -565,6 +584,11 @@ int mt3_engine_finalize(mt3_engine* e) {
   if ((rc = dmalloc(e, &e->hbuf, M * c.mlp_dim * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->enc_out, M * emb * e->esize))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y), static_cast<size_t>(Bm) * emb * 4))) return rc;
+  e->y_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && emb <= 512 && !getenv("MT3_NO_Y_SPLIT");
+  if (e->y_split) {
+    if ((rc = dmalloc(e, &e->y_ct, static_cast<size_t>(Bm) * emb * 2))) return rc;
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y_ss), static_cast<size_t>(Bm) * (emb / 16) * 4))) return rc;
+  }
   if ((rc = dmalloc(e, &e->qkv_d, static_cast<size_t>(Bm) * 3 * hd * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->attn_d, static_cast<size_t>(Bm) * hd * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->q_d, static_cast<size_t>(Bm) * hd * e->esize))) return rc;
@@ -643,7 +667,8 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
   MT3_HIP_CHECK(hipMemsetAsync(e->cur_tok, 0, static_cast<size_t>(batch) * 4, s));     // BOS = 0
   MT3_HIP_CHECK(hipMemsetAsync(e->ids, 0, static_cast<size_t>(batch) * L * 4, s));
   // decoder input of step 0: Embed(BOS) + FixedEmbed[0]; later steps get theirs from the argmax kernel
-  MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y, batch, c.emb_dim, s));
+  MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y, e->y_ct, e->y_ss, batch, c.emb_dim,
+                             s));
 
   // profiling-only variants: leave the self (1) / cross (2) attention launches out of the step, so that
   // their in-situ cost can be read as a DIFFERENCE of whole-decode times (results are garbage)

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) CT Bs[BN * ROWE];
   constexpr int NP = CPR > 16 ? CPR / 16 : 1;      // partial sums of squares per tile row (one per 16-lane DPP row)
   __shared__ float ss_part[NORM ? BM * NP : 1];
+  __shared__ float rs_x[NORM ? 1 : BM];            // norm == 2: row scales from the producer's partial sums
 
   // scalars out of the by-value argument struct (never take its address: that forces a private copy)
   const void* const gA = g.A;
@@ -126,6 +127,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   void* const gO = g.out;
   const float* const gAux = g.aux;
   const int gM = g.M, gN = g.N, gK = g.K, gLda = g.lda, gLdo = g.ldo, gSeq = g.seq_len;
+  const float* const gAss = g.a_ss;
+  void* const gOutCt = g.out_ct;
+  float* const gOutSs = g.out_ss;
 
   MT3_PROF_MARK(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -135,7 +139,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
 
   const int ld_row = tid / CPR, ld_chunk = tid % CPR;
-
+  // norm == 2: the K/16 (<= 32) exact partial sums of squares of this thread's tile row, requested up front and
+  // folded only after the operand loads have been issued (the fold must not delay them)
+  float4 pv[8];
+  const bool scale_rows = !NORM && gAss != nullptr && tid < BM;
+  if constexpr (!NORM) {
+    const int prow = m0 + tid < gM ? m0 + tid : gM - 1;
+    const float4* p4 = reinterpret_cast<const float4*>(gAss + static_cast<size_t>(prow) * (gK >> 4));
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      pv[u] = (scale_rows && u < (gK >> 6)) ? p4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   u32x4 a_reg[A_PASSES], b_reg[B_PASSES];
   float ss[A_PASSES];
 #pragma unroll
@@ -152,6 +166,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   const CT* b_base = &Bs[(wn * FN * 16 + frag_row) * ROWE + frag_g * KPL];
 
   gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg, b_reg, ss, gA, gW, m0, n0, tid, gM, gLda, gK, 0);
+  if constexpr (!NORM) {
+    if (scale_rows) {
+      float t = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t = (((t + pv[u].x) + pv[u].y) + pv[u].z) + pv[u].w;      // fixed order per row
+      rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);                               // read after the K loop's barriers
+    }
+  }
   for (int k0 = 0; k0 < gK; k0 += BK) {
     __syncthreads();                    // every wave is done reading the previous tile
     MT3_PROF_MARK(1);
@@ -206,7 +228,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   }
   // 1 / rms of tile row `lrow` (fused RMSNorm: the scale vector is folded into the weights)
   auto row_rs = [&](int lrow) -> float {
-    if constexpr (!NORM) return 1.f;
+    if constexpr (!NORM) return gAss ? rs_x[lrow] : 1.f;
     float t = ss_part[lrow * NP];
 #pragma unroll
     for (int q = 1; q < NP; ++q) t += ss_part[lrow * NP + q];
@@ -256,6 +278,47 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
             dst = static_cast<size_t>(row) * gLdo + col_even;
           }
           *reinterpret_cast<unsigned*>(static_cast<CT*>(gO) + dst) = pair;
+        }
+      }
+    }
+  } else if constexpr (EPI == MT3_EPI_RESID && sizeof(CT) == 2) {
+    // residual update; on request also the compute-type copy of the new rows (dword stores of column pairs) and
+    // the sum of squares of each row over this fragment's 16 columns (exact f32, reduced on the DPP row)
+    const int odd = frag_row & 1;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int lrow0 = wm * FM * 16 + i * 16 + frag_g * 4;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wn * FN * 16 + j * 16 + frag_row;
+        float vnew[4], other[4], part[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + lrow0 + r;
+          const size_t at = static_cast<size_t>(row < gM ? row : gM - 1) * gLdo + col;
+          vnew[r] = static_cast<float*>(gO)[at] + acc[i][j][r];
+          if (row < gM) static_cast<float*>(gO)[at] = vnew[r];
+        }
+        if (gOutCt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            other[r] = lane_xor1(vnew[r]);
+            part[r] = row16_sum(vnew[r] * vnew[r]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + lrow0 + r;
+            if (frag_row == 0 && row < gM)
+              gOutSs[static_cast<size_t>(row) * (gN >> 4) + ((n0 + wn * FN * 16 + j * 16) >> 4)] = part[r];
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int row = m0 + lrow0 + odd * 2 + h;
+            if (row >= gM) continue;
+            const float lo = odd ? other[2 + h] : vnew[h], hi = odd ? vnew[2 + h] : other[h];
+            *reinterpret_cast<unsigned*>(static_cast<CT*>(gOutCt) + static_cast<size_t>(row) * gLdo + col - odd) =
+                pack_bf16x2(lo, hi);
+          }
         }
       }
     }
@@ -346,8 +409,20 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
 }
 
 template <typename CT>
-static int launch_typed(const GemmArgs& g, bool a_f32, bool norm, int epi, bool small, hipStream_t s) {
+static int launch_typed(const GemmArgs& g, bool a_f32, int norm, int epi, bool small, hipStream_t s) {
   // Only the combinations the engine uses are instantiated.
+  if (norm == 2) {
+    if (a_f32 || !g.a_ss || g.K % 64 || g.K > 512)
+      return mt3::fail(MT3_ERR_INVALID, "gemm: norm 2 needs a compute-type A, a_ss and K = 64n <= 512");
+    switch (epi) {
+      case MT3_EPI_STORE: return launch_tile<CT, false, false, MT3_EPI_STORE>(g, small, s);
+      case MT3_EPI_GEGLU: return launch_tile<CT, false, false, MT3_EPI_GEGLU>(g, small, s);
+      case MT3_EPI_F32: return launch_tile<CT, false, false, MT3_EPI_F32>(g, small, s);
+      default: break;
+    }
+    return mt3::fail(MT3_ERR_INVALID, "gemm: unsupported epilogue for norm 2");
+  }
+  if (g.a_ss) return mt3::fail(MT3_ERR_INVALID, "gemm: a_ss without norm 2");
   if (norm) {
     if (!a_f32) return mt3::fail(MT3_ERR_INVALID, "gemm: norm requires an f32 A operand");
     switch (epi) {
@@ -375,7 +450,7 @@ static int launch_typed(const GemmArgs& g, bool a_f32, bool norm, int epi, bool 
   return mt3::fail(MT3_ERR_INVALID, "gemm: unsupported (a_is_f32, norm, epilogue) combination");
 }
 
-int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, bool norm, int epi, bool small, hipStream_t s) {
+int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, int norm, int epi, bool small, hipStream_t s) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.Wt || !g.out)
     return mt3::fail(MT3_ERR_INVALID, "gemm: bad shape or null pointer");
   if (epi == MT3_EPI_POS && (!g.aux || g.seq_len <= 0)) return mt3::fail(MT3_ERR_INVALID, "gemm: POS needs aux/seq_len");
@@ -402,5 +477,5 @@ extern "C" int mt3_op_gemm(int32_t dtype, const void* d_A, int32_t a_is_f32, int
   g.lda = K;
   g.ldo = epilogue == MT3_EPI_GEGLU ? N / 2 : N;
   g.seq_len = seq_len;
-  return mt3k::launch_gemm(dtype, g, a_is_f32 != 0, norm != 0, epilogue, small != 0, static_cast<hipStream_t>(stream));
+  return mt3k::launch_gemm(dtype, g, a_is_f32 != 0, norm != 0 ? 1 : 0, epilogue, small != 0, static_cast<hipStream_t>(stream));
 }

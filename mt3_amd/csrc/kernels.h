@@ -17,9 +17,16 @@ struct GemmArgs {
   int M, N, K;
   int lda, ldo;
   int seq_len;        // EPI_POS / EPI_HEADS: rows per batch item
+  // bf16 decode path: the residual stream travels as f32 rows PLUS a compute-type copy and, per row, the sums of
+  // squares of every 16-column group (exact f32), so that the RMSNorm-fused GEMMs read half the A bytes and need
+  // no statistics pass of their own
+  const float* a_ss;  // norm == 2: [M][K/16] partial sums of squares of the rows whose compute-type copy is A
+  void* out_ct;       // EPI_RESID: also write the updated rows in the compute type here [M][ldo] (nullptr: no)
+  float* out_ss;      // EPI_RESID with out_ct: [M][N/16] partial sums of squares of the updated rows
 };
 
-int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, bool norm, int epi, bool small, hipStream_t s);
+// norm: 0 none, 1 fused RMSNorm with statistics from the f32 A stream, 2 fused RMSNorm from g.a_ss (A = compute type)
+int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, int norm, int epi, bool small, hipStream_t s);
 
 // encoder self-attention, qkv [B, T, 3, H, 64] -> out [B, T, H*64]
 int launch_encoder_attention(int dtype, const void* qkv, void* out, int B, int T, int H, hipStream_t s);
@@ -44,8 +51,9 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s);
 int launch_rmsnorm(int dtype, const float* x, const float* scale, void* out_ct, float* out_f32, int rows, int dim,
                    hipStream_t s);
 // y[b] = table[tok[b]] + pos[step[b]]
-int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, int B, int dim,
-                 hipStream_t s);
+// y_ct / y_ss (both or neither): bf16 copy of the rows and their per-16-column sums of squares (see GemmArgs)
+int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, void* y_ct,
+                 float* y_ss, int B, int dim, hipStream_t s);
 // per-row state of the beam-1 search (t5x beam_search, num_decodes = 1): f = [live_logp | best finished
 // score], the second array `rows` floats after the first; len = prefix length of the best finished
 // hypothesis or -1; cfg[0] = brevity_penalty(max_len + 1), cfg[1 + n] = brevity_penalty(n) (device memory)
@@ -58,7 +66,7 @@ struct BeamState {
 // token pick + bookkeeping for one decode step (see decode_ops.hip); beam == nullptr: greedy
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
-                       float* y_next, int dim, int B, const BeamState* beam, hipStream_t s);
+                       float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam, hipStream_t s);
 int launch_beam1_finalize(int* ids, int L, const int* beam_len, int B, hipStream_t s);
 int launch_ids_to_tokens(const int* ids, int B, int L, int num_regular, int* out, hipStream_t s);
 
