@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--chains", type=int, default=1,
                     help="independent row groups run as parallel branches of the step graph (measured on "
-                         "MI355X/ROCm 7.2 at batch 256 with the round-1 kernels: 1 -> 758, 2 -> 744 audio-s/s; "
+                         "MI355X/ROCm 7.2 at batch 256: 1 -> 758, 2 -> 744 audio-s/s; "
                          "two chains were +6 %% while the decode GEMMs were 2 us slower)")
     ap.add_argument("--decoding", default="greedy", choices=["greedy", "beam1"],
                     help="token selection: plain greedy (what BASELINE configs[2] names) or the rule of t5x "
