@@ -201,6 +201,29 @@ def test_decode_chains_are_bit_identical(setup):
     assert np.array_equal(a, b)
 
 
+def test_split_residual_stream_matches_the_single_f32_stream(setup, monkeypatch):
+    """bf16 decode keeps the residual rows as f32 + a bf16 copy + exact per-16-column sums of squares (DESIGN.md
+    section 2); MT3_NO_Y_SPLIT=1 (read when an engine is finalized) keeps the single f32 stream with in-kernel
+    statistics.  Same MFMA operands, row scales equal up to the summation order: step-0 logits must agree to
+    f32 round-off (a wrong partial sum would show as a percent-level shift that the bf16 tolerances could hide),
+    and the greedy tokens must be identical."""
+    x = torch.from_numpy(np.repeat(setup["x"], 12, axis=0)[:34]).cuda()          # ragged: 34 rows = 32 + 2
+    out = {}
+    for name, env in (("split", None), ("single", "1")):
+        if env is None:
+            monkeypatch.delenv("MT3_NO_Y_SPLIT", raising=False)
+        else:
+            monkeypatch.setenv("MT3_NO_Y_SPLIT", env)
+        eng = _engine("bfloat16", setup["params"], 34)
+        eng.encode(x)
+        ids, logits0 = eng.decode(num_steps=40, return_first_logits=True)
+        out[name] = (ids.cpu().numpy(), logits0.cpu().numpy())
+    a, b = out["split"][1], out["single"][1]
+    assert rel(a, b) < 2e-6, rel(a, b)
+    assert np.abs(a - b).max() < 1e-4 * np.abs(b).max()
+    assert np.array_equal(out["split"][0], out["single"][0])
+
+
 def test_inference_model_end_to_end():
     """InferenceModel('random:0', 'mt3')(audio): product notes == oracle symbolic stage on the product's tokens."""
     from mt3_amd import inference
