@@ -102,3 +102,17 @@ def test_bench_contract_statics():
     import json
     base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert base["metric"] in src
+
+
+def test_bench_cpu_baseline_leg_runs_and_reports_the_contract_fields():
+    """`bench.py --cpu-baseline-only` (the leg the GPU bench spawns as a subprocess) on a tiny sample."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline-only", "--cpu-segments", "1",
+                        "--decode-steps", "4"], capture_output=True, text=True, timeout=300, cwd=ROOT)
+    line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
+    assert r.returncode == 0 and line, r.stderr[-500:]
+    d = json.loads(line[-1][len("CPU_BASELINE "):])
+    assert d["unit"] == "audio-s/s" and d["kind"] == "port" and d["value"] > 0 and 1 <= d["cores"] <= 16
+    assert "segments" in d["sample"]
