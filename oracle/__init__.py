@@ -13,9 +13,14 @@ Pinning status (see DESIGN.md "Oracle"):
     reference's own unit tests and against golden vectors produced by running
     the reference's real Python modules in the build container
     (tests/golden/make_symbolic_golden.py).
-  * layers (attention math, masks, DenseGeneral, MLP): pinned by the literals
-    of mt3/layers_test.py that do not need JAX to evaluate.
-  * log-mel frontend (tf.signal.*) and the t5x decode loop: PARITY UNPINNED --
-    TensorFlow / JAX / t5x are not installable here, so those parts restate the
-    published algorithms and are anchored only on the reference's call sites.
+  * network (layers + encoder-decoder wiring + the decode-mode K/V cache path): PINNED on golden vectors
+    produced by the reference's REAL mt3/layers.py + mt3/network.py, run unmodified in the build container on a
+    numpy stand-in for the jax/flax entry points they use (tests/golden/make_network_golden.py,
+    tests/golden/jax_standin.py -> tests/golden/network_golden.npz: encoder output, teacher-forced logits,
+    cached one-token decode as t5x drives it), plus the literals of mt3/layers_test.py that do not need JAX.
+    The leaf numerics (einsum, softmax, tanh-GELU) are numpy in that run, not XLA.
+  * log-mel frontend (tf.signal.*) and the t5x decode loop (beam_search): PARITY UNPINNED --
+    TensorFlow / t5x are not installable here and not part of the reference tree, so those parts restate the
+    published algorithms, are anchored on the reference's call sites and cross-checked against independent
+    implementations (torch.stft, scipy, torch operators: tests/test_oracle_cross_checks.py).
 """
