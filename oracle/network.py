@@ -11,10 +11,14 @@ and the t5x decode loop the model wrapper selects (mt3/models.py:121-137 ->
 t5x `decoding.beam_search`, num_decodes=1) [third-party, from memory]: greedy is
 the product semantics; `beam1_decode` emulates t5x's beam-size-1 search.
 
-PARITY UNPINNED vs JAX/Flax/t5x (not installable here).  Pinned pieces: attention
-math, masks, cache write, DenseGeneral and the ReLU-MLP known answer of
-mt3/layers_test.py (tests/test_oracle_network.py).  `nn.gelu` = tanh
-approximation [from memory: flax.linen.gelu default approximate=True].
+PINNED for the network itself: encoder output, teacher-forced logits and the cached
+one-token decode path match golden vectors produced by the reference's REAL
+mt3/layers.py + mt3/network.py, executed unmodified on a numpy stand-in for jax/flax
+(tests/golden/make_network_golden.py -> tests/test_oracle_network_golden.py, 2e-5),
+plus the attention / mask / DenseGeneral / ReLU-MLP literals of mt3/layers_test.py
+(tests/test_oracle_network.py).  `nn.gelu` = tanh approximation [flax.linen.gelu
+default approximate=True; cross-checked against torch's].  PARITY UNPINNED: the t5x
+decode loop (beam search) -- t5x is neither installable here nor in the reference tree.
 
 Parameters are a flat dict name -> np.float32 array, names/shapes exactly the
 Flax tree of SURVEY.md A.3 joined with '/'.
