@@ -8,16 +8,19 @@
 //   * NORM fuses T5 LayerNorm (layers.py:604-621 = RMSNorm, eps 1e-6) into the GEMM that consumes
 //     it: the learned scale is folded into Wt's columns at load time, and the per-row
 //     rsqrt(mean(x^2) + eps) is accumulated from the f32 A values as they stream through the
-//     K loop and applied in the epilogue -- no separate normalisation pass over HBM.
+//     K loop (reduced across the lanes of a row on the DPP network) and applied in the epilogue --
+//     no separate normalisation pass over HBM.  In the bf16 decode loop the row instead arrives as
+//     a bf16 copy plus the exact f32 sums of squares of its 16-column groups (GemmArgs::a_ss), left
+//     there by whichever kernel produced the row, and the GEMM only adds up those K/16 partials.
 //   * epilogues: STORE (compute type), RESID (f32 out += acc, the residual add of
-//     network.py:66,83,120,136,150), GEGLU (gelu(wi_0 x) * wi_1 x of layers.py:460-473 with the
+//     network.py:66,83,120,136,150; on request also the bf16 copy + partial sums above), GEGLU (gelu(wi_0 x) * wi_1 x of layers.py:460-473 with the
 //     two weight matrices interleaved in 16-column groups so gate and linear land in the same
 //     lane), POS (+ sinusoidal table row, network.py:174-180), F32 (logits, network.py:256-261),
 //     HEADS (cross-attention K/V written head-major [2][B][H][T][64] for the decode kernel).
 // Tiling: workgroup tile BMxBN, WMxWN waves, each wave FMxFN 16x16 MFMA fragments, K step BK;
-// global -> register prefetch of tile t+1 overlaps the MFMAs of tile t; LDS rows padded by one
-// 16-byte chunk (conflict-free 16-lane fragment reads); XCD-aware block remap so that the
-// column tiles of one row panel share an L2.
+// global -> register prefetch of tile t+1 overlaps the MFMAs of tile t; LDS rows padded by two
+// 16-byte chunks (conflict-free 16-lane fragment reads); 2-byte outputs leave as dwords (lane
+// pairs swap over DPP); XCD-aware block remap so that the column tiles of one row panel share an L2.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
