@@ -17,11 +17,14 @@
 //       V is consumed as V^T rows so the B operand is K-contiguous (8-byte LDS reads).
 // (2) dec_attn_kernel: single-query attention of one decode step -- pure HBM streaming of the
 //     K/V cache [B][H][cap][64]; LPK lanes share a key (16 bytes each), a wave covers 64/LPK
-//     consecutive keys per load (1 KiB contiguous), 4-deep unrolled so every lane keeps 8 loads
-//     in flight; online softmax per lane group, merged across groups by shuffles and across the
-//     4 waves through LDS.  With APPEND the step's new K/V row is written to the cache at
-//     position *step by the same kernel (the reference rewrites the WHOLE cache per step with a
-//     one-hot multiply-add: layers.py:272-292).
+//     consecutive keys per load (1 KiB contiguous), 4-deep unrolled so every lane keeps 8 non-temporal
+//     loads in flight.  The arithmetic is kept thin so that it never throttles the stream: q.k on the
+//     packed bf16 operands (v_dot2c_f32_bf16), key-group sums on the DPP network, base-2 online softmax
+//     with ONE rescale per 4 keys, a wave-uniform branch-free key loop (out-of-range slots re-read the
+//     last cached key with weight 0); lane groups merged by shuffles, waves through LDS.  With APPEND the
+//     step's new K/V row is folded in from registers and written to the cache at position step[b] by
+//     the same kernel (the reference rewrites the WHOLE cache per step with a one-hot multiply-add:
+//     layers.py:272-292).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
