@@ -19,8 +19,12 @@ Pinning status (see DESIGN.md "Oracle"):
     tests/golden/jax_standin.py -> tests/golden/network_golden.npz: encoder output, teacher-forced logits,
     cached one-token decode as t5x drives it), plus the literals of mt3/layers_test.py that do not need JAX.
     The leaf numerics (einsum, softmax, tanh-GELU) are numpy in that run, not XLA.
-  * log-mel frontend (tf.signal.*) and the t5x decode loop (beam_search): PARITY UNPINNED --
-    TensorFlow / t5x are not installable here and not part of the reference tree, so those parts restate the
-    published algorithms, are anchored on the reference's call sites and cross-checked against independent
-    implementations (torch.stft, scipy, torch operators: tests/test_oracle_cross_checks.py).
+  * log-mel frontend: composition and parameters PINNED on the reference's REAL mt3/spectrograms.py +
+    mt3/spectral_ops.py, run unmodified on a numpy stand-in for TensorFlow (tests/golden/make_frontend_golden.py,
+    tf_standin.py -> frontend_golden.npz).  The tf.signal leaves (frame / stft / hann / HTK filterbank) are
+    third-party code outside the reference tree: restated from the TensorFlow documentation (independently in the
+    stand-in and in oracle/frontend.py) and cross-checked against torch.stft and scipy
+    (tests/test_oracle_cross_checks.py) -- PARITY UNPINNED against TensorFlow itself.
+  * t5x decode loop (beam_search): PARITY UNPINNED -- t5x is neither installable here nor in the reference tree;
+    restated from memory of its source.
 """

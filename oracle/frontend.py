@@ -6,9 +6,13 @@ whose arithmetic lives in TensorFlow (`tf.signal.frame/stft/hann_window/
 linear_to_mel_weight_matrix`) -- not installable here, so this file restates the
 published definitions of those ops [from memory] and is **PARITY UNPINNED**
 against TF itself (the reference has no frontend test either).  What is pinned:
-internal consistency (f32 vs f64 noise floor), Parseval / linearity properties,
-and the mel-matrix structure quoted in SURVEY.md A.2 (1934 nnz, <=2 per row,
-2 empty columns).
+the reference's own composition and parameters -- its real spectrograms.py /
+spectral_ops.py run unmodified on a numpy stand-in for TensorFlow and agree with
+this file to 2e-6 x peak (tests/golden/make_frontend_golden.py,
+tests/test_oracle_frontend_golden.py); torch.stft / scipy / a from-the-docs HTK
+filterbank agree with the leaves (tests/test_oracle_cross_checks.py); internal
+consistency (f32 vs f64 noise floor), linearity, and the mel-matrix structure quoted
+in SURVEY.md A.2 (1934 nnz, <=2 per row, 2 empty columns).
 
     frames   : frame i = x[i*hop : i*hop + fft] zero-padded past the end
                (tf.signal.stft(frame_length=2048, frame_step=128, pad_end=True);
