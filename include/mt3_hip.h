@@ -71,6 +71,13 @@ int mt3_frontend_mel_matrix(const mt3_frontend* fe, float* h_out /*[(fft/2+1)*me
 int mt3_frontend_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segments,
                         int32_t frames_per_segment, const int32_t* h_n_frames /* may be NULL = all full */,
                         float* d_logmel, void* stream);
+/* The same with the per-segment frame counts already in DEVICE memory (caller-owned, must stay valid until the
+ * launch has run).  mt3_frontend_logmel copies h_n_frames into a pre-sized ring inside the frontend (65536
+ * counts, device + pinned mirror, created with the first call's tables): no allocation on the call path, the
+ * caller's host buffer is free when the call returns, and calls on different streams never share a slot. */
+int mt3_frontend_logmel_dev(mt3_frontend* fe, const float* d_audio, int32_t n_segments,
+                            int32_t frames_per_segment, const int32_t* d_n_frames /* may be NULL */,
+                            float* d_logmel, void* stream);
 
 /* -------------------------------------------------------------------- engine
  * Replaces network.Transformer (mt3/network.py:265-409, layers in mt3/layers.py)
@@ -144,6 +151,24 @@ enum {
 #define MT3_DECODE_CHAINS(n) (((n) & 0xF) << 8)
 int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags,
                       int32_t* d_ids, float* d_first_logits, int32_t* h_steps_run, void* stream);
+
+/* Teacher-forced cached decode: Transformer.decode (mt3/network.py:303-361) on GIVEN decoder inputs, driven one
+ * token per call through the same cached step (layers.py:246-314) the autoregressive loop uses -- the input of
+ * step 0 is BOS, the input of step t+1 is d_forced_ids[b][t] (i.e. decoder_input_tokens = shift_right(forced),
+ * seqio autoregressive_inputs as in mt3/models.py:96).  d_forced_ids [batch, L] int32.  d_step_logits (may be
+ * NULL): [num_steps, batch, vocab] f32, the logits of EVERY step (the parity tests compare them with the
+ * reference's teacher-forced logits at all cache depths).  d_ids [batch, L]: the arg-max of each step (no EOS
+ * bookkeeping).  flags: MT3_DECODE_NO_GRAPH, MT3_DECODE_CHAINS(n); not BEAM1 / EARLY_EXIT. */
+int mt3_engine_decode_forced(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags,
+                             const int32_t* d_forced_ids, float* d_step_logits, int32_t* d_ids, void* stream);
+
+/* Engine facts a caller cannot see from results alone (a negative return is an mt3_status).
+ * GRAPH_FALLBACKS: decode calls so far whose step graph could not be captured/instantiated and that therefore
+ * ran as direct launches (same ids, slower) -- the fallback is counted, never silent;
+ * LAST_DECODE_USED_GRAPH: 1/0 for the most recent decode; RESIDUAL_SPLIT: 1 if the bf16 decode loop carries the
+ * residual rows as f32 + bf16 copy + partial sums of squares. */
+enum { MT3_STATUS_GRAPH_FALLBACKS = 0, MT3_STATUS_LAST_DECODE_USED_GRAPH = 1, MT3_STATUS_RESIDUAL_SPLIT = 2 };
+int mt3_engine_status(const mt3_engine* e, int32_t what);
 
 /* GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271): -1 from the
  * first EOS(1) to the end of the row, id-3 for 3 <= id < 3+num_regular, else -2. */

@@ -17,6 +17,7 @@ MT3_OK, MT3_ERR_INVALID, MT3_ERR_HIP, MT3_ERR_CAPACITY, MT3_ERR_MISSING = 0, -1,
 MT3_BF16, MT3_F32 = 0, 1
 EPI_STORE, EPI_RESID, EPI_GEGLU, EPI_POS, EPI_F32, EPI_HEADS = range(6)
 DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SKIP_SELF_ATTN, DECODE_SKIP_CROSS_ATTN = 1, 2, 4, 8, 16
+STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT = range(3)
 EV_SHIFT, EV_PITCH, EV_VELOCITY, EV_TIE, EV_PROGRAM, EV_DRUM = range(6)
 EVENT_TYPE_NAMES = ("shift", "pitch", "velocity", "tie", "program", "drum")
 SPEC_ONSETS, SPEC_NOTES, SPEC_TIES = range(3)
@@ -63,6 +64,7 @@ SIGNATURES = {
     "mt3_frontend_destroy": (None, [_P]),
     "mt3_frontend_mel_matrix": (C.c_int, [_P, _P, C.POINTER(C.c_int64)]),
     "mt3_frontend_logmel": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    "mt3_frontend_logmel_dev": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     "mt3_engine_create": (C.c_int, [C.POINTER(EngineConfig), C.POINTER(_P)]),
     "mt3_engine_destroy": (None, [_P]),
     "mt3_engine_load_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32]),
@@ -70,6 +72,8 @@ SIGNATURES = {
     "mt3_engine_device_bytes": (C.c_int64, [_P]),
     "mt3_engine_encode": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "mt3_engine_decode": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), _P]),
+    "mt3_engine_decode_forced": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "mt3_engine_status": (C.c_int, [_P, C.c_int32]),
     "mt3_ids_to_tokens": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mt3_op_gemm": (C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                               C.c_int32, _P, C.c_int32, C.c_int32, _P]),

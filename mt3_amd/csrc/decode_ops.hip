@@ -138,7 +138,8 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
                                                            float* __restrict__ y_next, void* __restrict__ y_ct,
                                                            float* __restrict__ y_ss, int dim,
                                                            float* __restrict__ beam_f, int* __restrict__ beam_len,
-                                                           const float* __restrict__ beam_cfg, int beam_rows) {
+                                                           const float* __restrict__ beam_cfg, int beam_rows,
+                                                           const int* __restrict__ forced, int forced_stride) {
   __shared__ float s_v[8], s_sum[4];
   __shared__ int s_i[8];
   __shared__ int s_tok, s_t;
@@ -195,8 +196,9 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
     }
     int tok;
     if (!BEAM1) {
+      if (forced) was_done = 0;           // teacher forcing: every step reports its own arg-max, no EOS bookkeeping
       tok = was_done ? 0 : t2.i1;
-      if (!was_done && tok == 1) {        // EOS
+      if (!was_done && tok == 1 && !forced) {        // EOS
         done[b] = 1;
         atomicAdd(n_done, 1);
       }
@@ -229,6 +231,9 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
       }
     }
     ids[static_cast<size_t>(b) * ids_stride + t] = tok;
+    // teacher forcing (Transformer.decode on given decoder_input_tokens, network.py:303-361): the NEXT input is
+    // the caller's token for position t + 1, whatever this step predicted
+    if (!BEAM1 && forced) tok = forced[static_cast<size_t>(b) * forced_stride + t];
     cur_tok[b] = tok;
     step[b] = t + 1;
     s_tok = tok;
@@ -249,14 +254,25 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
 
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
-                       float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam, hipStream_t s) {
+                       float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam,
+                       const int* forced, int forced_stride, hipStream_t s) {
+  if (beam && forced) return mt3::fail(MT3_ERR_INVALID, "argmax_step: teacher forcing is a greedy-path feature");
   if (beam)
     hipLaunchKernelGGL(argmax_step_kernel<true>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
                        done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, beam->f, beam->len,
-                       beam->cfg, beam->rows);
+                       beam->cfg, beam->rows, nullptr, 0);
   else
     hipLaunchKernelGGL(argmax_step_kernel<false>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
-                       done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, nullptr, nullptr, nullptr, 0);
+                       done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, nullptr, nullptr, nullptr, 0,
+                       forced, forced_stride);
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+
+// one float into device memory from a kernel ARGUMENT (no host buffer has to outlive the call)
+__global__ void set_float_kernel(float* dst, float v) { *dst = v; }
+int launch_set_float(float* dst, float v, hipStream_t s) {
+  hipLaunchKernelGGL(set_float_kernel, dim3(1), dim3(1), 0, s, dst, v);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

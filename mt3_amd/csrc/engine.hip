@@ -110,6 +110,9 @@ struct mt3_engine {
   int* step = nullptr;
   int* n_done = nullptr;
   int* h_pinned = nullptr;
+  int* forced = nullptr;         // [max_batch][L] teacher-forcing tokens of the current mt3_engine_decode_forced call
+  int graph_fallbacks = 0;       // decode calls whose step graph could not be captured (ran as direct launches)
+  int last_used_graph = 0;
   float* beam_f = nullptr;       // [2][max_batch]: live log-prob | best finished score (MT3_DECODE_BEAM1)
   int* beam_len = nullptr;       // [max_batch]
   float* beam_cfg = nullptr;     // [0] brevity penalty of the loop bound, [1 + n] brevity_penalty(n)
@@ -118,9 +121,9 @@ struct mt3_engine {
   hipStream_t cap_stream[8] = {};     // one capture stream per chain (kMaxChains)
   hipEvent_t cap_event[8] = {};
   // one captured decode step per (batch, variant); variant bits: 1 = no self-attention, 2 = no
-  // cross-attention (differential profiling only), 4 = beam-1 token selection
-  hipGraphExec_t graph_exec[8][9] = {};   // [variant][chains]
-  hipGraph_t graph[8][9] = {};
+  // cross-attention (differential profiling only), 4 = beam-1 token selection, 8 = teacher forcing
+  hipGraphExec_t graph_exec[16][9] = {};   // [variant][chains]
+  hipGraph_t graph[16][9] = {};
   int graph_batch = 0;
 
   int HD() const { return cfg.num_heads * cfg.head_dim; }
@@ -314,7 +317,8 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     const mt3k::BeamState beam{e->beam_f + row0, e->beam_len + row0, e->beam_cfg, c.max_batch};
     return mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
                                     e->cur_tok + row0, e->done + row0, e->n_done, step, e->embedding, e->pos_table,
-                                    kMaxPos, y, y_ct, y_ss, emb, rows, (skip & 4) ? &beam : nullptr, s);
+                                    kMaxPos, y, y_ct, y_ss, emb, rows, (skip & 4) ? &beam : nullptr,
+                                    (skip & 8) ? e->forced + static_cast<size_t>(row0) * Lmax : nullptr, Lmax, s);
   }
   LayerDev& L = e->dec[op >> 3];
   switch (op & 7) {
@@ -395,7 +399,7 @@ int enqueue_decode_step(mt3_engine* e, int B, int skip, int n, hipStream_t s) {
 }
 
 void drop_graph(mt3_engine* e) {
-  for (int v = 0; v < 8; ++v)
+  for (int v = 0; v < 16; ++v)
     for (int n = 0; n < 9; ++n) {
       if (e->graph_exec[v][n]) (void)hipGraphExecDestroy(e->graph_exec[v][n]);
       if (e->graph[v][n]) (void)hipGraphDestroy(e->graph[v][n]);
@@ -599,6 +603,7 @@ int mt3_engine_finalize(mt3_engine* e) {
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->done), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->step), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->n_done), 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->forced), static_cast<size_t>(Bm) * L * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->beam_f), static_cast<size_t>(2) * Bm * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->beam_len), static_cast<size_t>(Bm) * 4))) return rc;
   {
@@ -651,14 +656,19 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
   return MT3_OK;
 }
 
-int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t* d_ids,
-                      float* d_first_logits, int32_t* h_steps_run, void* stream) {
+// shared body of mt3_engine_decode / mt3_engine_decode_forced
+static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, const int32_t* d_forced,
+                       float* d_step_logits, int32_t* d_ids, float* d_first_logits, int32_t* h_steps_run,
+                       void* stream) {
   if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: engine not finalized");
   if (batch <= 0 || batch != e->cur_batch)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: batch must equal the batch of the preceding encode");
   const mt3_engine_config& c = e->cfg;
   if (num_steps <= 0 || num_steps > c.max_decode_len || !d_ids)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: num_steps out of range or null ids");
+  const bool beam1 = (flags & MT3_DECODE_BEAM1) != 0;
+  if (d_forced && (beam1 || (flags & MT3_DECODE_EARLY_EXIT)))
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode_forced: not combinable with BEAM1 / EARLY_EXIT");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = c.max_decode_len;
   MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, static_cast<size_t>(batch) * 4, s));
@@ -666,26 +676,32 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
   MT3_HIP_CHECK(hipMemsetAsync(e->done, 0, static_cast<size_t>(batch) * 4, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->cur_tok, 0, static_cast<size_t>(batch) * 4, s));     // BOS = 0
   MT3_HIP_CHECK(hipMemsetAsync(e->ids, 0, static_cast<size_t>(batch) * L * 4, s));
+  if (d_forced)    // engine-owned copy: the step graph holds ITS address, whatever buffer the caller passes
+    MT3_HIP_CHECK(hipMemcpyAsync(e->forced, d_forced, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
   // decoder input of step 0: Embed(BOS) + FixedEmbed[0]; later steps get theirs from the argmax kernel
   MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y, e->y_ct, e->y_ss, batch, c.emb_dim,
                              s));
 
   // profiling-only variants: leave the self (1) / cross (2) attention launches out of the step, so that
   // their in-situ cost can be read as a DIFFERENCE of whole-decode times (results are garbage)
-  const bool beam1 = (flags & MT3_DECODE_BEAM1) != 0;
   const int skip = ((flags & MT3_DECODE_SKIP_SELF_ATTN) ? 1 : 0) | ((flags & MT3_DECODE_SKIP_CROSS_ATTN) ? 2 : 0) |
-                   (beam1 ? 4 : 0);
+                   (beam1 ? 4 : 0) | (d_forced ? 8 : 0);
   if (beam1) {
     // t5x beam_search(alpha = 0.6): live log-prob 0, nothing finished; the loop bound uses the brevity
-    // penalty of max_decode_len + 1 (the dummy start token extends the length by one)
-    const float bp_max = brevity_penalty(num_steps + 1);
-    MT3_HIP_CHECK(hipMemcpyAsync(e->beam_cfg, &bp_max, 4, hipMemcpyHostToDevice, s));
+    // penalty of max_decode_len + 1 (the dummy start token extends the length by one).  The value travels as a
+    // kernel argument: no host buffer has to stay alive behind an asynchronous copy.
+    MT3_TRY(mt3k::launch_set_float(e->beam_cfg, brevity_penalty(num_steps + 1), s));
     MT3_HIP_CHECK(hipMemsetAsync(e->beam_f, 0, static_cast<size_t>(2) * c.max_batch * 4, s));
     MT3_HIP_CHECK(hipMemsetAsync(e->beam_len, 0xFF, static_cast<size_t>(c.max_batch) * 4, s));   // -1
   }
   bool use_graph = !(flags & MT3_DECODE_NO_GRAPH);
   const int chains = chains_for(e, batch, (flags >> 8) & 0xF);
-  if (use_graph && ensure_graph(e, batch, skip, chains) != MT3_OK) use_graph = false;   // fall back to direct launches
+  if (use_graph && ensure_graph(e, batch, skip, chains) != MT3_OK) {
+    // direct launches give the same ids; the fallback is RECORDED (mt3_engine_status), never silent
+    use_graph = false;
+    ++e->graph_fallbacks;
+  }
+  e->last_used_graph = use_graph ? 1 : 0;
   int ran = 0;
   for (int t = 0; t < num_steps; ++t) {
     if (use_graph) MT3_HIP_CHECK(hipGraphLaunch(e->graph_exec[skip][chains], s));
@@ -694,6 +710,9 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
     if (t == 0 && d_first_logits)
       MT3_HIP_CHECK(hipMemcpyAsync(d_first_logits, e->logits, static_cast<size_t>(batch) * c.vocab_size * 4,
                                    hipMemcpyDeviceToDevice, s));
+    if (d_step_logits)
+      MT3_HIP_CHECK(hipMemcpyAsync(d_step_logits + static_cast<size_t>(t) * batch * c.vocab_size, e->logits,
+                                   static_cast<size_t>(batch) * c.vocab_size * 4, hipMemcpyDeviceToDevice, s));
     if ((flags & MT3_DECODE_EARLY_EXIT) && (t % 32 == 31)) {
       MT3_HIP_CHECK(hipMemcpyAsync(e->h_pinned, e->n_done, 4, hipMemcpyDeviceToHost, s));
       MT3_HIP_CHECK(hipStreamSynchronize(s));
@@ -704,6 +723,27 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
   MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
   if (h_steps_run) *h_steps_run = ran;
   return MT3_OK;
+}
+
+int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t* d_ids,
+                      float* d_first_logits, int32_t* h_steps_run, void* stream) {
+  return decode_impl(e, batch, num_steps, flags, nullptr, nullptr, d_ids, d_first_logits, h_steps_run, stream);
+}
+
+int mt3_engine_decode_forced(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags,
+                             const int32_t* d_forced_ids, float* d_step_logits, int32_t* d_ids, void* stream) {
+  if (!d_forced_ids) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode_forced: null forced ids");
+  return decode_impl(e, batch, num_steps, flags, d_forced_ids, d_step_logits, d_ids, nullptr, nullptr, stream);
+}
+
+int mt3_engine_status(const mt3_engine* e, int32_t what) {
+  if (!e) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_status: null engine");
+  switch (what) {
+    case MT3_STATUS_GRAPH_FALLBACKS: return e->graph_fallbacks;
+    case MT3_STATUS_LAST_DECODE_USED_GRAPH: return e->last_used_graph;
+    case MT3_STATUS_RESIDUAL_SPLIT: return e->y_split ? 1 : 0;
+    default: return mt3::fail(MT3_ERR_INVALID, "mt3_engine_status: unknown item");
+  }
 }
 
 }  // extern "C"

@@ -149,8 +149,12 @@ struct mt3_frontend {
   void* d_cnt = nullptr;
   void* d_off = nullptr;
   void* d_w = nullptr;
+  // per-call frame counts travel through a pre-sized ring (device + pinned host mirror): nothing is allocated on
+  // the call path, the copy is stream-ordered from pinned memory, and a later call on another stream takes the
+  // NEXT slot instead of overwriting counts an earlier launch may still be reading
   int* d_nframes = nullptr;
-  int nframes_cap = 0;
+  int* h_nframes = nullptr;
+  int ring_pos = 0;
   bool on_device = false;
 };
 
@@ -179,6 +183,7 @@ void mt3_frontend_destroy(mt3_frontend* fe) {
   void* ptrs[] = {fe->d_hann, fe->d_tw1024, fe->d_tw2048, fe->d_k0, fe->d_cnt, fe->d_off, fe->d_w, fe->d_nframes};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (fe->h_nframes) (void)hipHostFree(fe->h_nframes);
   delete fe;
 }
 
@@ -188,6 +193,8 @@ int mt3_frontend_mel_matrix(const mt3_frontend* fe, float* h_out, int64_t* nnz) 
   if (nnz) *nnz = fe->host.nnz;
   return MT3_OK;
 }
+
+constexpr int kNFramesRing = 1 << 16;   // segments' worth of frame counts that can be in flight at once
 
 static int ensure_device_tables(mt3_frontend* fe) {
   if (fe->on_device) return MT3_OK;
@@ -199,33 +206,14 @@ static int ensure_device_tables(mt3_frontend* fe) {
   if ((rc = upload(fe->host.cnt, &fe->d_cnt))) return rc;
   if ((rc = upload(fe->host.off, &fe->d_off))) return rc;
   if ((rc = upload(fe->host.w, &fe->d_w))) return rc;
+  MT3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&fe->d_nframes), sizeof(int) * kNFramesRing));
+  MT3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&fe->h_nframes), sizeof(int) * kNFramesRing, hipHostMallocDefault));
   fe->on_device = true;
   return MT3_OK;
 }
 
-int mt3_frontend_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segments, int32_t frames_per_segment,
-                        const int32_t* h_n_frames, float* d_logmel, void* stream) {
-  if (!fe || !d_audio || !d_logmel) return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_logmel: null argument");
-  if (n_segments <= 0) return MT3_OK;
-  if (frames_per_segment <= 0 || frames_per_segment % kFramesPerBlock != 0)
-    return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_logmel: frames_per_segment must be a positive multiple of 16");
-  int rc = ensure_device_tables(fe);
-  if (rc) return rc;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int* d_n = nullptr;
-  if (h_n_frames) {
-    for (int i = 0; i < n_segments; ++i)
-      if (h_n_frames[i] < 0 || h_n_frames[i] > frames_per_segment)
-        return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_logmel: n_frames out of range");
-    if (fe->nframes_cap < n_segments) {
-      if (fe->d_nframes) MT3_HIP_CHECK(hipFree(fe->d_nframes));
-      fe->d_nframes = nullptr;
-      MT3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&fe->d_nframes), sizeof(int) * n_segments));
-      fe->nframes_cap = n_segments;
-    }
-    MT3_HIP_CHECK(hipMemcpyAsync(fe->d_nframes, h_n_frames, sizeof(int) * n_segments, hipMemcpyHostToDevice, s));
-    d_n = fe->d_nframes;
-  }
+static int launch_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segments, int32_t frames_per_segment,
+                         const int* d_n, float* d_logmel, hipStream_t s) {
   FrontendDev t{static_cast<const float*>(fe->d_hann), static_cast<const cpx*>(fe->d_tw1024),
                 static_cast<const cpx*>(fe->d_tw2048), static_cast<const int*>(fe->d_k0),
                 static_cast<const int*>(fe->d_cnt),    static_cast<const int*>(fe->d_off),
@@ -235,6 +223,48 @@ int mt3_frontend_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segmen
                      d_logmel);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
+}
+
+static int check_logmel_args(mt3_frontend* fe, const float* d_audio, int32_t frames_per_segment, float* d_logmel) {
+  if (!fe || !d_audio || !d_logmel) return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_logmel: null argument");
+  if (frames_per_segment <= 0 || frames_per_segment % kFramesPerBlock != 0)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_logmel: frames_per_segment must be a positive multiple of 16");
+  return MT3_OK;
+}
+
+int mt3_frontend_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segments, int32_t frames_per_segment,
+                        const int32_t* h_n_frames, float* d_logmel, void* stream) {
+  int rc = check_logmel_args(fe, d_audio, frames_per_segment, d_logmel);
+  if (rc) return rc;
+  if (n_segments <= 0) return MT3_OK;
+  if ((rc = ensure_device_tables(fe))) return rc;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int* d_n = nullptr;
+  if (h_n_frames) {
+    if (n_segments > kNFramesRing)
+      return mt3::fail(MT3_ERR_CAPACITY, "mt3_frontend_logmel: more than 65536 ragged segments in one call; split "
+                                         "the call or pass device counts to mt3_frontend_logmel_dev");
+    for (int i = 0; i < n_segments; ++i)
+      if (h_n_frames[i] < 0 || h_n_frames[i] > frames_per_segment)
+        return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_logmel: n_frames out of range");
+    const int at = fe->ring_pos + n_segments <= kNFramesRing ? fe->ring_pos : 0;
+    fe->ring_pos = at + n_segments;
+    std::memcpy(fe->h_nframes + at, h_n_frames, sizeof(int) * n_segments);      // the caller's buffer is free again
+    MT3_HIP_CHECK(hipMemcpyAsync(fe->d_nframes + at, fe->h_nframes + at, sizeof(int) * n_segments,
+                                 hipMemcpyHostToDevice, s));
+    d_n = fe->d_nframes + at;
+  }
+  return launch_logmel(fe, d_audio, n_segments, frames_per_segment, d_n, d_logmel, s);
+}
+
+int mt3_frontend_logmel_dev(mt3_frontend* fe, const float* d_audio, int32_t n_segments, int32_t frames_per_segment,
+                            const int32_t* d_n_frames, float* d_logmel, void* stream) {
+  int rc = check_logmel_args(fe, d_audio, frames_per_segment, d_logmel);
+  if (rc) return rc;
+  if (n_segments <= 0) return MT3_OK;
+  if ((rc = ensure_device_tables(fe))) return rc;
+  return launch_logmel(fe, d_audio, n_segments, frames_per_segment, d_n_frames, d_logmel,
+                       static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

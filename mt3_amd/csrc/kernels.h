@@ -63,10 +63,13 @@ struct BeamState {
   const float* cfg;
   int rows;
 };
-// token pick + bookkeeping for one decode step (see decode_ops.hip); beam == nullptr: greedy
+// token pick + bookkeeping for one decode step (see decode_ops.hip); beam == nullptr: greedy;
+// forced != nullptr (greedy only): teacher forcing, the next input token is forced[b * forced_stride + t]
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
-                       float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam, hipStream_t s);
+                       float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam,
+                       const int* forced, int forced_stride, hipStream_t s);
+int launch_set_float(float* dst, float v, hipStream_t s);
 int launch_beam1_finalize(int* ids, int L, const int* beam_len, int B, hipStream_t s);
 int launch_ids_to_tokens(const int* ids, int B, int L, int num_regular, int* out, hipStream_t s);
 

@@ -121,9 +121,16 @@ class Transformer:
                                config.num_encoder_layers, config.num_decoder_layers, config.input_depth,
                                input_length, max_decode_length, max_batch,
                                _lib.MT3_BF16 if config.dtype == "bfloat16" else _lib.MT3_F32, decode_chains)
+        self._ec = ec
+        self._h = None
+        self._create()
+
+    def _create(self):
         h = C.c_void_p()
-        _lib.check(self._lib.mt3_engine_create(C.byref(ec), C.byref(h)))
-        self._h = h
+        _lib.check(self._lib.mt3_engine_create(C.byref(self._ec), C.byref(h)))
+        old, self._h = self._h, h
+        if old:
+            self._lib.mt3_engine_destroy(old)
         self._loaded = False
 
     def __del__(self):
@@ -132,8 +139,25 @@ class Transformer:
             self._lib.mt3_engine_destroy(h)
 
     def load_params(self, params: Dict[str, np.ndarray]):
-        """`params`: flat dict in the reference's names/orientation (f32)."""
-        for name, arr in params.items():
+        """`params`: flat dict in the reference's names/orientation (f32).  Names outside the network's
+        parameter tree (optimizer state, other heads of a larger checkpoint) are ignored; kernels stored with
+        split head axes ([in, heads, head_dim] / [heads, head_dim, out]) are flattened to the 2-D DenseGeneral
+        form; a second call re-restores (the engine is rebuilt), as the reference's restore_from_checkpoint allows."""
+        if self._loaded:
+            self._create()
+        want = param_shapes(self.config)
+        missing = [n for n in want if n not in params]
+        if missing:
+            raise _lib.Mt3Error(_lib.MT3_ERR_MISSING, "weights missing from the checkpoint: %s%s"
+                                % (", ".join(missing[:4]), " ..." if len(missing) > 4 else ""))
+        for name, shape in want.items():
+            arr = np.asarray(params[name])
+            if arr.shape != shape:
+                if arr.size == int(np.prod(shape)) and arr.ndim == 3:
+                    arr = arr.reshape(shape)            # (in, heads, head_dim) or (heads, head_dim, out)
+                else:
+                    raise _lib.Mt3Error(_lib.MT3_ERR_INVALID, "weight %s has shape %s, expected %s"
+                                        % (name, tuple(arr.shape), shape))
             a = np.ascontiguousarray(arr, dtype=np.float32)
             shape = (C.c_int64 * a.ndim)(*a.shape)
             _lib.check(self._lib.mt3_engine_load_weight(self._h, name.encode(), a.ctypes.data, shape, a.ndim))
@@ -179,3 +203,33 @@ class Transformer:
                                                torch.cuda.current_stream().cuda_stream))
         self.steps_run = ran.value
         return (ids, logits) if return_first_logits else ids
+
+    def decode_forced(self, forced_ids, num_steps: Optional[int] = None, use_graph: bool = True,
+                      return_logits: bool = True, chains: int = 0):
+        """Teacher-forced cached decode (network.Transformer.decode on given decoder inputs, one token per cached
+        step): step 0 is fed BOS, step t+1 is fed forced_ids[:, t].  forced_ids: int32 [B, <= L].
+        Returns (argmax ids int32 CUDA [B, L], logits f32 CUDA [num_steps, B, V] or None)."""
+        import torch
+        B, L = self._batch, self.max_decode_length
+        f = torch.zeros((B, L), device="cuda", dtype=torch.int32)
+        src = torch.as_tensor(forced_ids).to(device="cuda", dtype=torch.int32)
+        if src.dim() != 2 or src.shape[0] != B or src.shape[1] > L:
+            raise ValueError(f"forced_ids must be [B={B}, <= {L}], got {tuple(src.shape)}")
+        f[:, : src.shape[1]] = src
+        n = num_steps or L
+        ids = torch.empty((B, L), device="cuda", dtype=torch.int32)
+        logits = torch.empty((n, B, self.config.vocab_size), device="cuda", dtype=torch.float32) \
+            if return_logits else None
+        flags = (0 if use_graph else _lib.DECODE_NO_GRAPH) | ((chains & 0xF) << 8)
+        _lib.check(self._lib.mt3_engine_decode_forced(self._h, B, n, flags, f.data_ptr(),
+                                                      logits.data_ptr() if logits is not None else None,
+                                                      ids.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.current_stream().synchronize()          # `f` must outlive the copy the call enqueued
+        return ids, logits
+
+    def status(self, what: int) -> int:
+        """mt3_engine_status: _lib.STATUS_GRAPH_FALLBACKS / STATUS_LAST_DECODE_USED_GRAPH / STATUS_RESIDUAL_SPLIT."""
+        rc = int(self._lib.mt3_engine_status(self._h, what))
+        if rc < 0:
+            _lib.check(rc)
+        return rc
