@@ -11,16 +11,21 @@ batch's launches and is joined before the clock stops).
 Workload at N=1: BASELINE.json configs[2] ("MT3-base full encoder-decoder greedy decode, batch=256
 synthetic segments, 1xMI355X with hipGraph") -- the largest single-GPU configuration and the only
 one that *transcribes* (configs[1] is encoder-only and would leave the decoder out of the timed
-region).  Scaling is weak: every rank processes `--batch` segments.
+region; it is reported as the driver-timed extra `configs1`).  Default scaling is weak: every rank
+processes `--batch` segments per step.  `--corpus N` is BASELINE configs[3]: a fixed N-segment corpus
+sharded over the ranks (strong scaling, 10 000 segments = 1250 per GPU at 8 GPUs).
 
-Launch:  python bench.py [--gpus 1] [--steps K] [--warmup W]
+Launch:  python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: spawns N ranks itself)
          python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
                 --master-port P bench.py --gpus N --steps K --warmup W
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,37 +35,102 @@ if ROOT not in sys.path:
 
 SEG_SECONDS = 2.048          # 256 frames * 128 hop / 16 kHz  (mt3.gin:4, spectrograms.py:23-24)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_F32_PEAK_TFLOPS = 157.3
+ENC_GFLOP_PER_SEGMENT = 10.603 + 1.611     # encoder + the one-off cross-K/V projections of 8 layers
+FRONTEND_BYTES_PER_SEGMENT = 655360        # 131072 in + 524288 out
 
 
-def cpu_baseline(n_segments: int, decode_steps: int):
-    """The oracle (CPU restatement of the reference path: numpy frontend + torch-CPU f32 network +
-    pure-Python note decoding) timed on this box's host cores on a bounded sample."""
+def kernel_source_hash():
+    """Identity of the kernels a PMC file was collected from: sha256 over the device sources."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mt3_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int):
+    """The oracle (CPU restatement of the reference path: numpy frontend + torch-CPU f32 network + pure-Python
+    note decoding; NOT JAX -- SURVEY 8c: jax/t5x are not installable here) timed on this box's host cores on a
+    bounded sample: (a) the full path on `n_segments` segments as ONE batch (reduced configs[2]), (b) configs[1]:
+    log-mel + encoder only on `enc_segments` segments."""
     import numpy as np
     import torch
     from mt3_amd import network
     from oracle import frontend as OF, network as ON, symbolic as OS
-    # the oracle's decode step is a chain of tiny matmuls: more than ~16 threads only adds sync cost
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
+    nproc = os.cpu_count() or 1
     cfg = network.T5Config(dtype="float32")
     params = network.init_random_params(cfg, seed=0)
-    audio = OF.synth_audio(n_segments, seed=0)
+    audio = OF.synth_audio(max(n_segments, enc_segments), seed=0)
     orc = ON.Oracle(params, ON.T5Config())
-    t0 = time.perf_counter()
-    lm = np.stack([OF.compute_logmel(a, np.float32) for a in audio])
-    enc = orc.encode(lm)
-    ids = orc.greedy_decode(enc, decode_steps)
-    vocab = OS.GenericTokenVocabulary(1388, extra_ids=100)
-    toks = vocab.decode_tf(ids)
-    codec = OS.build_codec(OS.VocabularyConfig(num_velocity_bins=1))
-    preds = [{"est_tokens": OS.trim_eos(t), "start_time": OS.floor_start_time(i * SEG_SECONDS, 100)}
-             for i, t in enumerate(toks)]
-    OS.event_predictions_to_ns(preds, codec, "ties")
-    dt = time.perf_counter() - t0
-    return {"value": n_segments * SEG_SECONDS / dt, "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": "%d segments (%.1f s of audio), same path: log-mel + encoder + %d greedy steps + note "
-                      "decoding; oracle restatement (numpy/torch-CPU f32), not JAX; %.1f s wall"
-                      % (n_segments, n_segments * SEG_SECONDS, decode_steps, dt)}
+    # thread count: the decode step is a chain of batch-8 GEMVs whose speed peaks well below a 256-core host's
+    # nproc; pick the fastest of a few candidates on 6 real decode steps each (the probe is not part of the
+    # timed sample) and say which one was used
+    with torch.no_grad():
+        lm_probe = np.stack([OF.compute_logmel(a, np.float32) for a in audio[:n_segments]])
+        torch.set_num_threads(min(nproc, 16))
+        enc_probe = orc.encode(lm_probe)
+        best = (None, 1e30)
+        for th in sorted({min(nproc, c) for c in (8, 16, 32, 64, nproc)}):
+            torch.set_num_threads(th)
+            orc.greedy_decode(enc_probe, 2)
+            t0 = time.perf_counter()
+            orc.greedy_decode(enc_probe, 6)
+            dt = time.perf_counter() - t0
+            if dt < best[1]:
+                best = (th, dt)
+        threads = best[0]
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        lm = np.stack([OF.compute_logmel(a, np.float32) for a in audio[:n_segments]])
+        enc = orc.encode(lm)
+        ids = orc.greedy_decode(enc, decode_steps)
+        vocab = OS.GenericTokenVocabulary(1388, extra_ids=100)
+        toks = vocab.decode_tf(ids)
+        codec = OS.build_codec(OS.VocabularyConfig(num_velocity_bins=1))
+        preds = [{"est_tokens": OS.trim_eos(t), "start_time": OS.floor_start_time(i * SEG_SECONDS, 100)}
+                 for i, t in enumerate(toks)]
+        OS.event_predictions_to_ns(preds, codec, "ties")
+        dt = time.perf_counter() - t0
+        # (b) encoder-only (configs[1]) at all cores: big GEMMs, this one does scale with threads
+        torch.set_num_threads(nproc)
+        t1 = time.perf_counter()
+        lm2 = np.stack([OF.compute_logmel(a, np.float32) for a in audio[:enc_segments]])
+        orc.encode(lm2)
+        dt2 = time.perf_counter() - t1
+    return {"value": n_segments * SEG_SECONDS / dt, "unit": "audio-s/s", "cores": threads, "nproc": nproc,
+            "kind": "port",
+            "sample": "%d segments as one batch (%.1f s of audio), same path: log-mel + encoder + %d greedy steps + "
+                      "note decoding; oracle restatement (numpy/torch-CPU f32), not JAX; %d torch threads (fastest of "
+                      "8/16/32/64/nproc=%d on a 6-step probe); %.1f s wall"
+                      % (n_segments, n_segments * SEG_SECONDS, decode_steps, threads, nproc, dt),
+            "encoder_only": {"value": enc_segments * SEG_SECONDS / dt2, "unit": "audio-s/s",
+                             "segments_per_s": enc_segments / dt2, "cores": nproc,
+                             "sample": "configs[1] on the CPU: log-mel + encoder, %d segments, %d torch threads, "
+                                       "%.1f s wall" % (enc_segments, nproc, dt2)}}
+
+
+# ----------------------------------------------------------------------------------------- rank spawning
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run N ranks (one per GPU) under torch.distributed.run."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d but this node exposes %d GPU(s); not faking a multi-GPU line\n" % (n, have))
+        return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this driver (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -73,18 +143,26 @@ def main():
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
     ap.add_argument("--chains", type=int, default=1,
                     help="independent row groups run as parallel branches of the step graph (measured on "
-                         "MI355X/ROCm 7.2 at batch 256: 1 -> 758, 2 -> 744 audio-s/s; "
-                         "two chains were +6 %% while the decode GEMMs were 2 us slower)")
+                         "MI355X/ROCm 7.2 at batch 256: 1 -> 758, 2 -> 744 audio-s/s)")
     ap.add_argument("--decoding", default="greedy", choices=["greedy", "beam1"],
                     help="token selection: plain greedy (what BASELINE configs[2] names) or the rule of t5x "
                          "beam_search with one beam (what the reference's InferenceModel runs; ~1 %% slower)")
+    ap.add_argument("--corpus", type=int, default=0,
+                    help="BASELINE configs[3]: a fixed corpus of this many segments sharded over the ranks (strong "
+                         "scaling; 10000 = 1250 per GPU at 8 GPUs); one step = one pass over the corpus")
+    ap.add_argument("--corpus-batch", type=int, default=1250, help="segments per engine call in --corpus mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-segments", type=int, default=2)
+    ap.add_argument("--no-extras", action="store_true", help="skip the f32 line and the stage (frontend/encoder) extras")
+    ap.add_argument("--cpu-segments", type=int, default=8)
+    ap.add_argument("--cpu-enc-segments", type=int, default=64)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print("CPU_BASELINE " + json.dumps(cpu_baseline(args.cpu_segments, args.decode_steps)), flush=True)
-        return
+        print("CPU_BASELINE " + json.dumps(cpu_baseline(args.cpu_segments, args.decode_steps, args.cpu_enc_segments)),
+              flush=True)
+        return 0
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
     import numpy as np
     import torch
@@ -93,24 +171,36 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
-    from mt3_amd import distributed, metrics_utils, network, note_sequences, spectrograms, synthetic, vocabularies
+    from mt3_amd import _lib, distributed, metrics_utils, network, note_sequences, spectrograms, synthetic, vocabularies
 
-    B, L = args.batch, 1024
+    L = 1024
+    corpus = args.corpus
+    if corpus:
+        lo, hi = distributed.shard_range(corpus, rank, world)
+        n_local = hi - lo
+        B = max(1, min(args.corpus_batch, n_local))
+    else:
+        lo, n_local, B = rank * args.batch, args.batch, args.batch
+    n_global = corpus if corpus else args.batch * world
     cfg = network.T5Config(dtype=args.dtype)
     eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, decode_chains=args.chains)
     eng.load_params(network.init_random_params(cfg, seed=0))
     codec = vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1))
     vocab = vocabularies.vocabulary_from_codec(codec)
-    audio = synthetic.synth_audio(B, seed=1000 + rank)                    # [B, 32768] f32 in HBM
+    # this rank's shard of the synthetic corpus, resident in HBM before the clock starts
+    audio = torch.cat([synthetic.synth_audio(min(1024, n_local - s), seed=1000 + lo + s) for s in range(0, n_local, 1024)])
     stream = torch.cuda.Stream()                                          # a real (capturable) stream
-    start_times = [s * SEG_SECONDS - (s * SEG_SECONDS) % 0.01 for s in range(B * world)]
+    start_times = [s * SEG_SECONDS - (s * SEG_SECONDS) % 0.01 for s in range(n_global)]
 
     # rank 0's host stage (EOS trim + run-length / note decoding in libmt3hip.so) runs on a worker thread, so the
     # NEXT batch's GPU work is already being launched while the previous batch's tokens become notes; every
@@ -118,21 +208,32 @@ def main():
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=1)
     pending = []
+    gather_events = []
 
     def host_stage(host):
         eos = host == vocabularies.DECODED_EOS_ID
         n_tok = np.where(eos.any(1), eos.argmax(1), host.shape[1])
         rows = [r[:n] for r, n in zip(host, n_tok)]
-        ns, inv, drop = metrics_utils._run(codec, note_sequences.NoteEncodingWithTiesSpec.spec_id, rows, start_times)
+        ns, inv, drop = metrics_utils._run(codec, note_sequences.NoteEncodingWithTiesSpec.spec_id, rows,
+                                           start_times[: len(rows)])
         return len(ns.notes)
 
     def step():
         with torch.cuda.stream(stream):
-            logmel = spectrograms.compute_spectrogram_batch(audio, None)
-            eng.encode(logmel)
-            ids = eng.decode(num_steps=args.decode_steps, beam1=args.decoding == "beam1")
-            tokens = vocab.decode_tf(ids)                                  # CUDA int32 [B, L]
-            tokens = distributed.gather_token_rows(tokens, world * B)   # RCCL all-gather (identity at N=1)
+            parts = []
+            for s in range(0, n_local, B):
+                chunk = audio[s:s + B]
+                logmel = spectrograms.compute_spectrogram_batch(chunk, None)
+                eng.encode(logmel)
+                ids = eng.decode(num_steps=args.decode_steps, beam1=args.decoding == "beam1")
+                parts.append(vocab.decode_tf(ids))                         # CUDA int32 [b, L]
+            tokens = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+            if world > 1:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                tokens = distributed.gather_token_rows(tokens, n_global)   # ONE RCCL all-gather of int32 token rows
+                e1.record(stream)
+                gather_events.append((e0, e1))
             if rank == 0:
                 host = tokens.cpu().numpy()                                # syncs the stream
                 pending.append(pool.submit(host_stage, host))
@@ -152,65 +253,91 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
+    gather_events.clear()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     n_notes = drain()
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0                 # this rank's own time to finish its K steps
     sync_all()
     dt = time.perf_counter() - t0
+    per_rank_ms, gather_ms = [dt_own * 1e3 / args.steps], None
     if world > 1:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        mine = torch.tensor([dt_own * 1e3 / args.steps], device="cuda", dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(t.item()) for t in allr]
+        gather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / max(1, len(gather_events))
+    graph_fallbacks = eng.status(_lib.STATUS_GRAPH_FALLBACKS)
+    used_graph = eng.status(_lib.STATUS_LAST_DECODE_USED_GRAPH)
 
     # ---- roofline of the dominant kernel (decode self-attention: HBM streaming of the K/V cache).
     # In-situ and live: HIP events (recorded on the stream the graphs are launched on) around the whole
     # graph-replayed decode, once as it ships and once with that kernel's launches left out of the step
     # graph; the difference / launches = the kernel's average duration inside the real decode loop.
-    roof = None
+    roof, extras = None, {}
     if rank == 0:
-        def decode_ms(**kw):
+        Br = min(B, n_local)
+
+        def timed(fn, reps=1):
             with torch.cuda.stream(stream):
-                kw["chains"] = 1      # the kernel at full-GPU width, one launch at a time (as rocprofv3 sees it)
-                eng.decode(num_steps=2, **kw)                         # capture / warm this graph variant
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
-                eng.decode(num_steps=args.decode_steps, **kw)
+                for _ in range(reps):
+                    fn()
                 e1.record(stream)
             e1.synchronize()
-            return e0.elapsed_time(e1)
+            return e0.elapsed_time(e1) / reps
+
+        def decode_ms(engine=eng, **kw):
+            kw["chains"] = 1      # the kernel at full-GPU width, one launch at a time (as rocprofv3 sees it)
+            with torch.cuda.stream(stream):
+                engine.decode(num_steps=2, **kw)                      # capture / warm this graph variant
+            return timed(lambda: engine.decode(num_steps=args.decode_steps, **kw))
 
         with torch.cuda.stream(stream):
-            eng.encode(spectrograms.compute_spectrogram_batch(audio, None))
+            eng.encode(spectrograms.compute_spectrogram_batch(audio[:Br], None))
         t_full = min(decode_ms(), decode_ms())
         t_noself = min(decode_ms(skip_self_attn=True), decode_ms(skip_self_attn=True))
         t_nocross = min(decode_ms(skip_cross_attn=True), decode_ms(skip_cross_attn=True))
         esize = 2 if args.dtype == "bfloat16" else 4
         H, S, nl = cfg.num_heads, args.decode_steps, cfg.num_decoder_layers
-        kv_row = 2.0 * B * H * 64 * esize                            # K+V bytes of one cache position, all rows
+        kv_row = 2.0 * Br * H * 64 * esize                           # K+V bytes of one cache position, all rows
         launches = S * nl
         # algorithmic bytes: read the t+1 cached K/V rows + q, write the new row + the output
-        self_bytes = nl * sum(kv_row * (t + 1) + kv_row + 2.0 * B * H * 64 * esize for t in range(S))
-        cross_bytes = launches * (kv_row * 256 + 2.0 * B * H * 64 * esize)
+        self_bytes = nl * sum(kv_row * (t + 1) + kv_row + 2.0 * Br * H * 64 * esize for t in range(S))
+        cross_bytes = launches * (kv_row * 256 + 2.0 * Br * H * 64 * esize)
         self_us = (t_full - t_noself) * 1e3 / launches
         cross_us = (t_full - t_nocross) * 1e3 / launches
         ach = self_bytes / launches / (self_us * 1e-6) / 1e9
         # HBM traffic of that kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-        # passes, FETCH_SIZE x2 on gfx950 -- calibrated on a 1 GiB copy): collected by tools/gpu_pmc.sh at this
-        # exact shape, committed as profiles/r1_pmc_summary.json (a bench run cannot wrap itself in rocprofv3)
-        traffic, traffic_src = None, None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
-                pmc = json.load(f)
-            if pmc["shape"]["B"] == B and args.dtype == "bfloat16" and args.decode_steps == 1024:
-                ratio = pmc["dec_attn_self_append"]["n_keys_513"]["traffic_over_algorithmic"]
-                traffic = ratio * self_bytes / launches
-                traffic_src = "profiles/r1_pmc_summary.json (measured traffic/algorithmic = %.4f at the mean launch)" % ratio
-        except (OSError, KeyError, ValueError):
-            pass
-        roof = {"bound": "hbm", "kernel": "mt3k::dec_attn_kernel<bf16, APPEND=true> (decode self-attention over the "
-                                          "K/V cache)",
+        # passes, FETCH_SIZE x2 on gfx950 -- calibrated on a 1 GiB copy): a bench run cannot wrap itself in
+        # rocprofv3, so tools/gpu_pmc.sh collects them at this exact shape and tools/pmc_summary.py stamps the
+        # summary with the hash of the kernel sources it was collected from; a summary from OTHER sources is
+        # refused (traffic = null) instead of silently carrying an old ratio over a kernel change
+        traffic, traffic_src = None, "no PMC summary for these kernel sources (run tools/gpu_pmc.sh)"
+        for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_summary.json")),
+                           reverse=True):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pmc = json.load(f)
+                if pmc.get("kernel_source_hash") != kernel_source_hash():
+                    continue
+                if pmc["shape"]["B"] == Br and args.dtype == "bfloat16" and args.decode_steps == 1024:
+                    ratio = pmc["dec_attn_self_append"]["n_keys_513"]["traffic_over_algorithmic"]
+                    traffic = ratio * self_bytes / launches
+                    traffic_src = "profiles/%s (kernel sources %s; measured traffic/algorithmic = %.4f at the mean " \
+                                  "launch)" % (name, pmc["kernel_source_hash"], ratio)
+                    break
+            except (OSError, KeyError, ValueError):
+                continue
+        roof = {"bound": "hbm", "kernel": "mt3k::dec_attn_kernel<%s, APPEND=true> (decode self-attention over the "
+                                          "K/V cache)" % ("bf16" if esize == 2 else "f32"),
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src,
                 "avg_launch_us": self_us, "algorithmic_bytes_per_launch": self_bytes / launches, "launches": launches,
@@ -218,48 +345,125 @@ def main():
                           "without this kernel in the step graph; (difference)/launches",
                 "decode_ms_single_chain": t_full, "decode_ms_without_self_attn": t_noself,
                 "decode_ms_without_cross_attn": t_nocross,
+                "whole_step_hbm_frac": (self_bytes + cross_bytes) / (t_full * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "cross_attn": {"achieved": cross_bytes / launches / (cross_us * 1e-6) / 1e9, "avg_launch_us": cross_us,
                                "algorithmic_bytes_per_launch": cross_bytes / launches}}
 
+        if not args.no_extras and not corpus:
+            # ---- stage extras, driver-timed (HIP events on the launch stream, inputs in HBM)
+            peak = MFMA_BF16_PEAK_TFLOPS if esize == 2 else MFMA_F32_PEAK_TFLOPS
+            a256 = audio[:Br]
+            lm256 = spectrograms.compute_spectrogram_batch(a256, None)
+            fe_ms = timed(lambda: spectrograms.compute_spectrogram_batch(a256, None), reps=20)
+            enc_ms = min(timed(lambda: eng.encode(lm256), reps=5) for _ in range(2))
+            fe_gbs = FRONTEND_BYTES_PER_SEGMENT * Br / (fe_ms * 1e-3) / 1e9
+            extras["frontend"] = {"kernel": "mt3::logmel_kernel", "segments": Br, "ms": fe_ms, "bound": "hbm",
+                                  "achieved": fe_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fe_gbs / HBM_PEAK_GBS,
+                                  "algorithmic_bytes_per_segment": FRONTEND_BYTES_PER_SEGMENT}
+            enc_tf = ENC_GFLOP_PER_SEGMENT * Br / (enc_ms * 1e-3) / 1e3
+            extras["encoder"] = {"segments": Br, "ms": enc_ms, "bound": "mfma", "achieved": enc_tf, "peak": peak,
+                                 "unit": "TFLOP/s", "frac": enc_tf / peak,
+                                 "algorithmic_gflop_per_segment": ENC_GFLOP_PER_SEGMENT}
+            # BASELINE configs[1]: batch 64, log-mel + encoder (+ cross-K/V), encoder-only throughput
+            n1 = min(64, Br)
+            a64 = audio[:n1]
+
+            def c1():
+                eng.encode(spectrograms.compute_spectrogram_batch(a64, None))
+            c1()
+            c1_ms = min(timed(c1, reps=10) for _ in range(2))
+            c1_tf = ENC_GFLOP_PER_SEGMENT * n1 / (c1_ms * 1e-3) / 1e3
+            extras["configs1"] = {"workload": "BASELINE configs[1]: batch=%d synthetic segments, log-mel + encoder "
+                                              "(+ cross-K/V projections), no decode" % n1,
+                                  "segments_per_s": n1 / (c1_ms * 1e-3), "audio_s_per_s": n1 * SEG_SECONDS / (c1_ms * 1e-3),
+                                  "ms": c1_ms, "achieved": c1_tf, "peak": peak, "unit": "TFLOP/s", "frac": c1_tf / peak}
+            with torch.cuda.stream(stream):
+                eng.encode(lm256)                                    # leave the engine at the bench batch
+
+            # ---- the same workload at the reference's own precision (f32 MFMA operands, f32 K/V cache): one
+            # warm-up + one timed step, printed beside the bf16 value (precision ruling)
+            if args.dtype == "bfloat16" and world == 1:
+                try:
+                    cfg32 = network.T5Config(dtype="float32")
+                    e32 = network.Transformer(cfg32, input_length=256, max_decode_length=L, max_batch=Br)
+                    e32.load_params(network.init_random_params(cfg32, seed=0))
+
+                    def f32_step():
+                        with torch.cuda.stream(stream):
+                            e32.encode(spectrograms.compute_spectrogram_batch(a256, None))
+                            ids = e32.decode(num_steps=args.decode_steps)
+                            host = vocab.decode_tf(ids).cpu().numpy()
+                        return host_stage(host)
+                    with torch.cuda.stream(stream):
+                        e32.encode(lm256)
+                        e32.decode(num_steps=2)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    f32_step()
+                    torch.cuda.synchronize()
+                    d32 = time.perf_counter() - t1
+                    extras["f32"] = {"value": Br * SEG_SECONDS / d32, "unit": "audio-s/s", "ms_per_step": d32 * 1e3,
+                                     "steps": 1, "dtype": "f32",
+                                     "note": "same workload, reference precision (model.gin:50 dtype float32): f32 "
+                                             "MFMA operands, f32 K/V cache; token-exact vs the oracle "
+                                             "(tests/test_gpu_parity_deep.py)"}
+                    del e32
+                except Exception as ex:                              # the bf16 line must not die with the extra
+                    extras["f32"] = {"value": None, "error": repr(ex)[:300]}
+
     if rank == 0:
-        segs = B * world * args.steps
+        segs = n_global * args.steps
         value = segs * SEG_SECONDS / dt
+        if corpus:
+            workload = ("BASELINE configs[3]: MT3 (model.gin) random-init, %d-segment synthetic corpus sharded over "
+                        "%d GPU(s) (%d segments on rank 0, %d per engine call), full encoder-decoder %s decode, %d "
+                        "decode steps (no early exit), one RCCL all-gather of the token rows per pass, host note "
+                        "decoding included" % (corpus, world, n_local, B, args.decoding, args.decode_steps))
+        else:
+            workload = ("BASELINE configs[2]: MT3 (model.gin) random-init, full encoder-decoder %s "
+                        "decode, batch=%d synthetic 2.048 s segments per GPU, %d decode steps (no early "
+                        "exit), hipGraph step replay, ids->tokens + host note decoding included"
+                        % ("greedy" if args.decoding == "greedy" else "beam-1 (t5x beam_search, one beam)",
+                           B, args.decode_steps))
         out = {
             "metric": "audio-seconds transcribed/sec (whole node), MT3-base, 1/2/4/8 MI355X",
             "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if corpus else "weak",
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: MT3 (model.gin) random-init, full encoder-decoder %s "
-                                   "decode, batch=%d synthetic 2.048 s segments per GPU, %d decode steps (no early "
-                                   "exit), hipGraph step replay, ids->tokens + host note decoding included"
-                                   % ("greedy" if args.decoding == "greedy" else "beam-1 (t5x beam_search, one beam)",
-                                      B, args.decode_steps),
-                       "segments_per_gpu": B, "decode_steps": args.decode_steps, "segment_seconds": SEG_SECONDS,
-                       "decode_chains": args.chains, "decoding": args.decoding,
+            "config": {"workload": workload,
+                       "segments_per_gpu": n_local, "segments_total": n_global, "decode_steps": args.decode_steps,
+                       "segment_seconds": SEG_SECONDS, "decode_chains": args.chains, "decoding": args.decoding,
                        "parallelism": "dp%d (segments sharded, weights replicated, RCCL all-gather of token rows)"
                                       % world if world > 1 else "single GPU",
+                       "step_graph": "hipGraph replay" if used_graph else "DIRECT LAUNCHES (graph capture failed)",
+                       "graph_fallbacks": graph_fallbacks,
                        "notes_decoded_last_step": n_notes},
             "segments_per_s": segs / dt,
+            "rccl_world": dist.get_world_size() if world > 1 else 1,
+            "per_rank_ms_per_step": per_rank_ms, "gather_ms": gather_ms,
+            "f32_value": extras.get("f32", {}).get("value"),
             "roofline": roof,
+            "extra": extras,
         }
         if not args.no_cpu_baseline and world == 1:
             # separate process, hard wall-clock bound: the bench must finish in minutes on any host
-            import subprocess
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-segments",
-                                    str(args.cpu_segments), "--decode-steps", str(args.decode_steps)],
-                                   capture_output=True, text=True, timeout=300)
+                                    str(args.cpu_segments), "--cpu-enc-segments", str(args.cpu_enc_segments),
+                                    "--decode-steps", str(args.decode_steps)],
+                                   capture_output=True, text=True, timeout=420)
                 line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
                 out["cpu_baseline"] = json.loads(line[-1][len("CPU_BASELINE "):]) if line else \
                     {"value": None, "unit": "audio-s/s", "cores": 0, "kind": "port", "sample": "failed: " + r.stderr[-300:]}
             except subprocess.TimeoutExpired:
                 out["cpu_baseline"] = {"value": None, "unit": "audio-s/s", "cores": 0, "kind": "port",
-                                       "sample": "oracle did not finish %d segments in 300 s" % args.cpu_segments}
+                                       "sample": "oracle did not finish %d segments in 420 s" % args.cpu_segments}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -36,34 +36,22 @@
 namespace mt3k {
 
 // ------------------------------------------------------------------------ encoder attention
-template <typename CT, int T>
-__global__ __launch_bounds__(256) void enc_attn_kernel(const CT* __restrict__ qkv, CT* __restrict__ out, int H) {
+// stage keys [key0, key0 + TK) of one head into LDS: K row-major [TK][ROWK], V transposed [64][ROWV]
+template <typename CT, int TK, int ROWK, int ROWV>
+__device__ __forceinline__ void enc_stage_kv(const CT* base, int RS, int HD, int key0, CT* Ks, CT* Vt, int tid) {
   constexpr int KPL = CTraits<CT>::KPL;
-  constexpr int KG = CTraits<CT>::KGROUP;       // head-dim / key elements per chunk-MFMA
   constexpr int D = 64;
-  constexpr int ROWK = D + 2 * KPL;             // K tile row (elements): stride 32 mod 64 bytes, conflict-free b128 reads
-  constexpr int ROWV = T + 8;                   // V^T row (elements): keeps 8/16-byte alignment
   constexpr int CH = D / KPL;                   // chunks per K/V row
-  constexpr int NC = D / KG;                    // K-groups across the head dim
-
-  __shared__ __attribute__((aligned(16))) CT Ks[T * ROWK];
-  __shared__ __attribute__((aligned(16))) CT Vt[D * ROWV];
-
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int RS = 3 * H * D;                     // qkv row stride (elements)
-  const CT* base = qkv + static_cast<size_t>(b) * T * RS + h * D;
-
-  // ---- stage K (row-major) : chunk c -> row c / CH, piece c % CH
-  for (int c = tid; c < T * CH; c += 256) {
+  // ---- K (row-major) : chunk c -> row c / CH, piece c % CH
+  for (int c = tid; c < TK * CH; c += 256) {
     const int row = c / CH, ch = c % CH;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(base + static_cast<size_t>(row) * RS + H * D + ch * KPL);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(base + static_cast<size_t>(key0 + row) * RS + HD + ch * KPL);
     *reinterpret_cast<u32x4*>(&Ks[row * ROWK + ch * KPL]) = v;
   }
-  // ---- stage V transposed: work item = (key pair, piece); a wave takes 64 consecutive key pairs
-  for (int w = tid; w < (T / 2) * CH; w += 256) {
-    const int rp = w % (T / 2), ch = w / (T / 2);
-    const CT* src = base + static_cast<size_t>(2 * rp) * RS + 2 * H * D + ch * KPL;
+  // ---- V transposed: work item = (key pair, piece); a wave takes 64 consecutive key pairs
+  for (int w = tid; w < (TK / 2) * CH; w += 256) {
+    const int rp = w % (TK / 2), ch = w / (TK / 2);
+    const CT* src = base + static_cast<size_t>(key0 + 2 * rp) * RS + 2 * HD + ch * KPL;
     const u32x4 v0 = *reinterpret_cast<const u32x4*>(src);
     const u32x4 v1 = *reinterpret_cast<const u32x4*>(src + RS);
     if constexpr (KPL == 8) {
@@ -81,6 +69,119 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const CT* __restrict__ qk
         *reinterpret_cast<float2*>(&Vt[(ch * 4 + j) * ROWV + 2 * rp]) = make_float2(a[j], c[j]);
     }
   }
+}
+
+// one 64-key chunk (keys k64*64 .. +63 of the STAGED range) folded into the online-softmax state (m, l, o) of
+// the wave's 16-query tile whose Q^T fragments are qf
+template <typename CT, int ROWK, int ROWV>
+__device__ __forceinline__ void enc_attn_chunk(const CT* Ks, const CT* Vt, int k64,
+                                               const u32x4 (&qf)[64 / CTraits<CT>::KGROUP], float& m, float& l,
+                                               f32x4 (&o)[4], int fr, int fg) {
+  constexpr int KPL = CTraits<CT>::KPL;
+  constexpr int KG = CTraits<CT>::KGROUP;
+  constexpr int NC = 64 / KG;
+  // S^T block j: rows = keys (k64*4 + j)*16 + fg*4 + r, col = query fr
+  f32x4 sc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const u32x4 kf = *reinterpret_cast<const u32x4*>(&Ks[((k64 * 4 + j) * 16 + fr) * ROWK + c * KG + fg * KPL]);
+      mfma_chunk<CT>(kf, qf[c], sc[j]);
+    }
+  }
+  float cm = -3.0e38f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cm = fmaxf(cm, sc[j][r]);
+  cm = fmaxf(cm, __shfl_xor(cm, 16));
+  cm = fmaxf(cm, __shfl_xor(cm, 32));
+  const float mn = fmaxf(m, cm);
+  const float alpha = expf(m - mn);          // 0 on the first chunk
+  m = mn;
+  float ls = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float p = expf(sc[j][r] - mn);
+      sc[j][r] = p;
+      ls += p;
+    }
+  l = l * alpha + ls;
+  // rescale O: its rows are queries fg*4 + r, whose alpha lives in lane fg*4 + r
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float ar = __shfl(alpha, fg * 4 + r);
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) o[nb][r] *= ar;
+  }
+  // O += P V : A = P (row = query fr, K-slots = this lane's keys), B = V^T rows (col = d)
+  if constexpr (KPL == 8) {
+#pragma unroll
+    for (int kc = 0; kc < 2; ++kc) {
+      const float pv[8] = {sc[2 * kc][0],     sc[2 * kc][1],     sc[2 * kc][2],     sc[2 * kc][3],
+                           sc[2 * kc + 1][0], sc[2 * kc + 1][1], sc[2 * kc + 1][2], sc[2 * kc + 1][3]};
+      const u32x4 pa = pack_bf16x8(pv);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const CT* vrow = &Vt[(nb * 16 + fr) * ROWV + k64 * 64 + fg * 4];
+        const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (2 * kc) * 16);
+        const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (2 * kc + 1) * 16);
+        const u32x4 vb = u32x4{lo.x, lo.y, hi.x, hi.y};
+        mfma_chunk<CT>(pa, vb, o[nb]);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32x4 pa = pack_f32x4(sc[j][0], sc[j][1], sc[j][2], sc[j][3]);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const u32x4 vb = *reinterpret_cast<const u32x4*>(&Vt[(nb * 16 + fr) * ROWV + (k64 * 4 + j) * 16 + fg * 4]);
+        mfma_chunk<CT>(pa, vb, o[nb]);
+      }
+    }
+  }
+}
+
+// normalise and store the wave's 16-query output tile: O fragment row = query fg*4 + r, col = d = nb*16 + fr;
+// 1/l of that query lives in lane fg*4 + r
+template <typename CT>
+__device__ __forceinline__ void enc_attn_store(CT* out, size_t row0, int HD, int h, float l, const f32x4 (&o)[4],
+                                               int fr, int fg) {
+  l += __shfl_xor(l, 16);
+  l += __shfl_xor(l, 32);
+  const float linv = 1.f / l;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float li = __shfl(linv, fg * 4 + r);
+    CT* dst = out + (row0 + fg * 4 + r) * HD + h * 64 + fr;
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) dst[nb * 16] = to_ct<CT>(o[nb][r] * li);
+  }
+}
+
+template <typename CT, int T>
+__global__ __launch_bounds__(256) void enc_attn_kernel(const CT* __restrict__ qkv, CT* __restrict__ out, int H) {
+  constexpr int KPL = CTraits<CT>::KPL;
+  constexpr int KG = CTraits<CT>::KGROUP;       // head-dim / key elements per chunk-MFMA
+  constexpr int D = 64;
+  constexpr int ROWK = D + 2 * KPL;             // K tile row (elements): stride 32 mod 64 bytes, conflict-free b128 reads
+  constexpr int ROWV = T + 8;                   // V^T row (elements): keeps 8/16-byte alignment
+  constexpr int NC = D / KG;                    // K-groups across the head dim
+
+  __shared__ __attribute__((aligned(16))) CT Ks[T * ROWK];
+  __shared__ __attribute__((aligned(16))) CT Vt[D * ROWV];
+
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int RS = 3 * H * D;                     // qkv row stride (elements)
+  const CT* base = qkv + static_cast<size_t>(b) * T * RS + h * D;
+
+  enc_stage_kv<CT, T, ROWK, ROWV>(base, RS, H * D, 0, Ks, Vt, tid);
   __syncthreads();
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -99,86 +200,67 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const CT* __restrict__ qk
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) o[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int k64 = 0; k64 < T / 64; ++k64) {
-      // S^T block j: rows = keys (k64*4 + j)*16 + fg*4 + r, col = query fr
-      f32x4 sc[4];
+    for (int k64 = 0; k64 < T / 64; ++k64) enc_attn_chunk<CT, ROWK, ROWV>(Ks, Vt, k64, qf, m, l, o, fr, fg);
+    enc_attn_store<CT>(out, static_cast<size_t>(b) * T + q0, H * D, h, l, o, fr, fg);
+  }
+}
+
+// The same attention when K and V^T of a whole head do not fit the 160 KB of LDS (f32 operands at T = 512: 280 KB):
+// the keys are staged in KH parts, the workgroup owns only T / QS queries (grid = B * H * QS) so that the
+// online-softmax state of ALL its query tiles (TPW per wave) stays in registers across the parts.  Same chunk
+// order per query as the one-pass kernel, i.e. the same arithmetic.
+template <typename CT, int T, int KH, int QS>
+__global__ __launch_bounds__(256) void enc_attn_split_kernel(const CT* __restrict__ qkv, CT* __restrict__ out, int H) {
+  constexpr int KPL = CTraits<CT>::KPL;
+  constexpr int KG = CTraits<CT>::KGROUP;
+  constexpr int D = 64;
+  constexpr int TK = T / KH;                    // keys staged at a time
+  constexpr int ROWK = D + 2 * KPL;
+  constexpr int ROWV = TK + 8;
+  constexpr int NC = D / KG;
+  constexpr int TPW = T / QS / 16 / 4;          // query tiles per wave
+  static_assert(TPW >= 1 && TK % 64 == 0, "split attention: tile/part sizes");
+
+  __shared__ __attribute__((aligned(16))) CT Ks[TK * ROWK];
+  __shared__ __attribute__((aligned(16))) CT Vt[D * ROWV];
+
+  const int bh = blockIdx.x / QS, qs = blockIdx.x % QS;
+  const int b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int RS = 3 * H * D;
+  const CT* base = qkv + static_cast<size_t>(b) * T * RS + h * D;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  u32x4 qf[TPW][NC];
+  float m[TPW], l[TPW];
+  f32x4 o[TPW][4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        sc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int q0 = qs * (T / QS) + (ti * 4 + wave) * 16;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const u32x4 kf =
-              *reinterpret_cast<const u32x4*>(&Ks[((k64 * 4 + j) * 16 + fr) * ROWK + c * KG + fg * KPL]);
-          mfma_chunk<CT>(kf, qf[c], sc[j]);
-        }
-      }
-      float cm = -3.0e38f;
+    for (int c = 0; c < NC; ++c)
+      qf[ti][c] = *reinterpret_cast<const u32x4*>(base + static_cast<size_t>(q0 + fr) * RS + c * KG + fg * KPL);
+    m[ti] = -3.0e38f;
+    l[ti] = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+    for (int nb = 0; nb < 4; ++nb) o[ti][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll 1
+  for (int part = 0; part < KH; ++part) {
+    if (part) __syncthreads();                  // every wave is done with the previous part
+    enc_stage_kv<CT, TK, ROWK, ROWV>(base, RS, H * D, part * TK, Ks, Vt, tid);
+    __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cm = fmaxf(cm, sc[j][r]);
-      cm = fmaxf(cm, __shfl_xor(cm, 16));
-      cm = fmaxf(cm, __shfl_xor(cm, 32));
-      const float mn = fmaxf(m, cm);
-      const float alpha = expf(m - mn);          // 0 on the first chunk
-      m = mn;
-      float ls = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = expf(sc[j][r] - mn);
-          sc[j][r] = p;
-          ls += p;
-        }
-      l = l * alpha + ls;
-      // rescale O: its rows are queries fg*4 + r, whose alpha lives in lane fg*4 + r
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float ar = __shfl(alpha, fg * 4 + r);
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) o[nb][r] *= ar;
-      }
-      // O += P V : A = P (row = query fr, K-slots = this lane's keys), B = V^T rows (col = d)
-      if constexpr (KPL == 8) {
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-          const float pv[8] = {sc[2 * kc][0],     sc[2 * kc][1],     sc[2 * kc][2],     sc[2 * kc][3],
-                               sc[2 * kc + 1][0], sc[2 * kc + 1][1], sc[2 * kc + 1][2], sc[2 * kc + 1][3]};
-          const u32x4 pa = pack_bf16x8(pv);
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb) {
-            const CT* vrow = &Vt[(nb * 16 + fr) * ROWV + k64 * 64 + fg * 4];
-            const u32x2 lo = *reinterpret_cast<const u32x2*>(vrow + (2 * kc) * 16);
-            const u32x2 hi = *reinterpret_cast<const u32x2*>(vrow + (2 * kc + 1) * 16);
-            const u32x4 vb = u32x4{lo.x, lo.y, hi.x, hi.y};
-            mfma_chunk<CT>(pa, vb, o[nb]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const u32x4 pa = pack_f32x4(sc[j][0], sc[j][1], sc[j][2], sc[j][3]);
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb) {
-            const u32x4 vb =
-                *reinterpret_cast<const u32x4*>(&Vt[(nb * 16 + fr) * ROWV + (k64 * 4 + j) * 16 + fg * 4]);
-            mfma_chunk<CT>(pa, vb, o[nb]);
-          }
-        }
-      }
+    for (int ti = 0; ti < TPW; ++ti) {
+#pragma unroll 1
+      for (int k64 = 0; k64 < TK / 64; ++k64)
+        enc_attn_chunk<CT, ROWK, ROWV>(Ks, Vt, k64, qf[ti], m[ti], l[ti], o[ti], fr, fg);
     }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
-    const float linv = 1.f / l;
-    // O fragment: row = query fg*4 + r, col = d = nb*16 + fr.  1/l of that query lives in lane fg*4 + r.
+  }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float li = __shfl(linv, fg * 4 + r);
-      CT* dst = out + (static_cast<size_t>(b) * T + q0 + fg * 4 + r) * (H * D) + h * D + fr;
-#pragma unroll
-      for (int nb = 0; nb < 4; ++nb) dst[nb * 16] = to_ct<CT>(o[nb][r] * li);
-    }
+  for (int ti = 0; ti < TPW; ++ti) {
+    const int q0 = qs * (T / QS) + (ti * 4 + wave) * 16;
+    enc_attn_store<CT>(out, static_cast<size_t>(b) * T + q0, H * D, h, l[ti], o[ti], fr, fg);
   }
 }
 
@@ -194,9 +276,12 @@ int launch_encoder_attention(int dtype, const void* qkv, void* out, int B, int T
   } else if (dtype == MT3_F32 && T == 256) {
     hipLaunchKernelGGL((enc_attn_kernel<float, 256>), grid, block, 0, s, static_cast<const float*>(qkv),
                        static_cast<float*>(out), H);
+  } else if (dtype == MT3_F32 && T == 512) {
+    // ismir2021 preset at the reference's precision: keys in two parts, four query quarters per (batch, head)
+    hipLaunchKernelGGL((enc_attn_split_kernel<float, 512, 2, 4>), dim3(B * H * 4), block, 0, s,
+                       static_cast<const float*>(qkv), static_cast<float*>(out), H);
   } else {
-    return mt3::fail(MT3_ERR_INVALID,
-                     "encoder_attention: supported (dtype, T) are (bf16, 256), (bf16, 512), (f32, 256)");
+    return mt3::fail(MT3_ERR_INVALID, "encoder_attention: supported T are 256 and 512 (bf16 and f32)");
   }
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;

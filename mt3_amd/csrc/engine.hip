@@ -460,8 +460,6 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: compute_dtype must be MT3_BF16 or MT3_F32");
   if (cfg->input_length != 256 && cfg->input_length != 512)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: input_length must be 256 (mt3) or 512 (ismir2021)");
-  if (cfg->compute_dtype == MT3_F32 && cfg->input_length != 256)
-    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the f32 parity path supports input_length 256 only");
   if (cfg->emb_dim % 128 || cfg->mlp_dim % 128 || cfg->vocab_size % 128 || cfg->input_depth % 64 ||
       (cfg->num_heads * 64) % 128)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: emb/mlp/vocab/heads*64 must be multiples of 128");

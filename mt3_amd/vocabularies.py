@@ -81,23 +81,38 @@ class GenericTokenVocabulary:
         return toks[: toks.index(DECODED_EOS_ID) + 1] if DECODED_EOS_ID in toks else toks
 
     def decode_tf(self, ids):
-        """Batch path on the GPU (`mt3_ids_to_tokens`).  Accepts a CUDA int32 torch
-        tensor (returned as a tensor, no sync) or anything array-like (returned
-        as numpy, like `vocabulary.decode_tf(x).numpy()` in the notebook)."""
-        import torch
-        was_tensor = isinstance(ids, torch.Tensor)
-        t = ids if was_tensor else torch.as_tensor(np.asarray(ids))
-        shape, orig_dtype = t.shape, t.dtype
-        t2 = t.reshape(-1, shape[-1]).to(device="cuda", dtype=torch.int32).contiguous()
-        out = torch.empty_like(t2)
-        _lib.check(_lib.load().mt3_ids_to_tokens(t2.data_ptr(), t2.shape[0], t2.shape[1], self._num_regular_tokens,
-                                                  out.data_ptr(), torch.cuda.current_stream().cuda_stream))
-        out = out.reshape(shape)
-        if was_tensor:
-            return out.to(orig_dtype) if orig_dtype != torch.int32 else out
-        res = out.cpu().numpy()
+        """`_decode_tf` (mt3/vocabularies.py:241-271).  A CUDA int32 torch tensor goes through the
+        `mt3_ids_to_tokens` kernel (returned as a tensor, no sync: the hot path).  Anything host-side (numpy,
+        lists, CPU tensors: the `vocabulary.decode_tf(x).numpy()` use of the notebook and the t5x write_fn in
+        inference.py) is remapped on the host with the same three-line rule, so host-only postprocessing needs
+        no GPU and empty rows are fine."""
+        try:
+            import torch
+            if isinstance(ids, torch.Tensor) and ids.is_cuda:
+                shape, orig_dtype = ids.shape, ids.dtype
+                if ids.numel() == 0:
+                    return ids.clone()
+                t2 = ids.reshape(-1, shape[-1]).to(dtype=torch.int32).contiguous()
+                out = torch.empty_like(t2)
+                _lib.check(_lib.load().mt3_ids_to_tokens(t2.data_ptr(), t2.shape[0], t2.shape[1],
+                                                          self._num_regular_tokens, out.data_ptr(),
+                                                          torch.cuda.current_stream().cuda_stream))
+                out = out.reshape(shape)
+                return out.to(orig_dtype) if orig_dtype != torch.int32 else out
+            if isinstance(ids, torch.Tensor):
+                return torch.from_numpy(self._decode_host(ids.numpy()))
+        except ImportError:
+            pass
+        return self._decode_host(np.asarray(ids))
+
+    def _decode_host(self, ids: np.ndarray) -> np.ndarray:
         src = np.asarray(ids)
-        return res.astype(src.dtype) if np.issubdtype(src.dtype, np.integer) else res
+        a = src.astype(np.int64)
+        eos = a == self.eos_id
+        after = np.cumsum(eos, axis=-1) > 0                     # from the first EOS to the end of the row
+        ok = (a >= self._num_special_tokens) & (a < self._base_vocab_size)
+        out = np.where(after, DECODED_EOS_ID, np.where(ok, a - self._num_special_tokens, DECODED_INVALID_ID))
+        return out.astype(src.dtype if np.issubdtype(src.dtype, np.integer) else np.int32)
 
     def __eq__(self, other):
         return (self.extra_ids == other.extra_ids and self._num_regular_tokens == other._num_regular_tokens)

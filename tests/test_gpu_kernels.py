@@ -138,7 +138,7 @@ def test_gemm_pos_and_heads(dtype, small):
 
 
 # ------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("dtype,T", [(BF16, 256), (BF16, 512), (F32, 256)])
+@pytest.mark.parametrize("dtype,T", [(BF16, 256), (BF16, 512), (F32, 256), (F32, 512)])
 def test_encoder_attention(dtype, T):
     B, H = 2, 6
     g = torch.Generator(device="cuda").manual_seed(T)

@@ -65,3 +65,17 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
                 assert "oracle/" not in src or f.endswith(".py") is False or "oracle/" not in src.split('"""')[0]
+
+
+def test_bench_refuses_to_fake_ranks_it_cannot_place():
+    """`python bench.py --gpus N` without a launcher spawns N ranks itself; with fewer than N GPUs visible it exits
+    non-zero with a message instead of printing an n_gpus=1 line under an N-GPU flag (missing #2)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box could really place 2 ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "GPU" in r.stderr and "{" not in r.stdout

@@ -42,4 +42,12 @@ for l in range(8):
     _lib.check(lib.mt3_op_decode_attention(_lib.MT3_BF16, q.data_ptr(), H * 64, ck[l, 0].data_ptr(), ck[l, 1].data_ptr(),
                                            256, None, None, 0, None, 256, out.data_ptr(), B, H, s))
 torch.cuda.synchronize()
+# log-mel frontend at the bench shape (256 full segments), 3 launches on fresh inputs (north_star: rocprof counters
+# report the frontend's HBM traffic; algorithmic = 655,360 B per segment)
+from mt3_amd import spectrograms, synthetic  # noqa: E402
+for i in range(3):
+    au = synthetic.synth_audio(256, seed=50 + i)
+    torch.cuda.synchronize()
+    lm = spectrograms.compute_spectrogram_batch(au, None)
+    torch.cuda.synchronize()
 print("pmc_attn done")

@@ -1,7 +1,9 @@
-"""Reduce the two rocprofv3 --pmc passes of tools/pmc_attn.py (tools/gpu_pmc.sh) to profiles/r1_pmc_summary.json:
+"""Reduce the two rocprofv3 --pmc passes of tools/pmc_attn.py (tools/gpu_pmc.sh) to profiles/<round>_pmc_summary.json
+(stamped with the hash of the kernel sources the counters were collected from; bench.py refuses a summary whose
+hash differs from the sources it runs):
 HBM traffic per decode-attention launch = FETCH_SIZE x 2 (gfx950 tallies 128-byte requests as 64: calibrated on
 the 1 GiB copy of the same run) + WRITE_SIZE, against the algorithmic bytes of the launch.
-Usage: python tools/pmc_summary.py gpurun_out/pmc profiles"""
+Usage: python tools/pmc_summary.py gpurun_out/pmc profiles [round-prefix, default r2]"""
 import csv
 import glob
 import json
@@ -10,6 +12,9 @@ import shutil
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+RND = sys.argv[3] if len(sys.argv) > 3 else "r2"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
 B, H, D, ES, CAP = 256, 6, 64, 2, 1024
 
 
@@ -17,7 +22,7 @@ def rows(counter):
     fs = glob.glob(os.path.join(src, "**", "%s_counter_collection.csv" % counter), recursive=True)
     if not fs:
         raise SystemExit("no %s csv under %s" % (counter, src))
-    shutil.copy(fs[0], os.path.join(dst, "r1_pmc_%s_counter_collection.csv" % counter))
+    shutil.copy(fs[0], os.path.join(dst, "%s_pmc_%s_counter_collection.csv" % (RND, counter)))
     out = []
     for r in csv.DictReader(open(fs[0])):
         if r["Counter_Name"] == counter:
@@ -43,7 +48,8 @@ af, aw = pick(fetch, is_attn), pick(write, is_attn)
 assert len(af) == 32 and len(aw) == 32, (len(af), len(aw))
 summary = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python tools/pmc_attn.py "
-              "(tools/gpu_pmc.sh, reduced by tools/pmc_summary.py), MI355X, round 1",
+              "(tools/gpu_pmc.sh, reduced by tools/pmc_summary.py), MI355X, " + RND,
+    "kernel_source_hash": kernel_source_hash(),
     "units": "counter values are KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B: "
              "MI355X_MICROARCH.md, HBM section), WRITE_SIZE is used as is",
     "calibration_1GiB_copy": {"FETCH_SIZE_KiB": cal_f, "WRITE_SIZE_KiB": cal_w, "read_bytes_true": 1 << 30,
@@ -66,6 +72,15 @@ for i, n_keys in enumerate((1024, 513, 129)):
     summary["dec_attn_self_append"]["n_keys_%d" % n_keys] = entry(
         sum(af[j] for j in sel) / 4, sum(aw[j] for j in sel) / 4, n_keys, True)
 summary["dec_attn_cross_256_keys"] = entry(sum(af[24:]) / 8, sum(aw[24:]) / 8, 256, False)
-with open(os.path.join(dst, "r1_pmc_summary.json"), "w") as f:
+# log-mel frontend: 3 launches of 256 full segments (4096 workgroups of 256 threads)
+is_fe = lambda n, g: "logmel_kernel" in n
+ff, fw = pick(fetch, is_fe), pick(write, is_fe)
+if ff and fw:
+    f_kib, w_kib = sum(ff[-3:]) / len(ff[-3:]), sum(fw[-3:]) / len(fw[-3:])
+    alg = 256 * 655360
+    tr = f_kib * 1024 * 2 + w_kib * 1024
+    summary["logmel_kernel_256_segments"] = {"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib, "traffic_bytes": tr,
+                                             "algorithmic_bytes": alg, "traffic_over_algorithmic": tr / alg}
+with open(os.path.join(dst, "%s_pmc_summary.json" % RND), "w") as f:
     json.dump(summary, f, indent=1)
-print(json.dumps({k: v for k, v in summary.items() if k.startswith("dec_attn") or k.startswith("calib")}, indent=1))
+print(json.dumps({k: v for k, v in summary.items() if k.startswith(("dec_attn", "calib", "logmel", "kernel_source"))}, indent=1))
