@@ -141,6 +141,11 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="segments per GPU per step (c3: 256)")
     ap.add_argument("--decode-steps", type=int, default=1024)
     ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--kv-dtype", default="", choices=["", "fp8_e4m3"],
+                    help="K/V cache format: '' = the compute dtype; fp8_e4m3 = OCP e4m3 rows + per-row scales "
+                         "(BASELINE configs[4]'s fp8 path; NOT the default line: the headline stays bf16)")
+    ap.add_argument("--model", default="mt3", choices=["mt3", "base"],
+                    help="mt3 = gin/model.gin (configs[1..3]); base = gin/ismir2022/base.gin shape (configs[4])")
     ap.add_argument("--chains", type=int, default=1,
                     help="independent row groups run as parallel branches of the step graph (measured on "
                          "MI355X/ROCm 7.2 at batch 256: 1 -> 758, 2 -> 744 audio-s/s)")
@@ -192,7 +197,9 @@ def main():
     else:
         lo, n_local, B = rank * args.batch, args.batch, args.batch
     n_global = corpus if corpus else args.batch * world
-    cfg = network.T5Config(dtype=args.dtype)
+    import dataclasses
+    shape = network.MT3_BASE if args.model == "base" else network.MT3_SMALL
+    cfg = dataclasses.replace(shape, dtype=args.dtype, kv_dtype=args.kv_dtype)
     eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, decode_chains=args.chains)
     eng.load_params(network.init_random_params(cfg, seed=0))
     codec = vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1))
@@ -307,7 +314,8 @@ def main():
         t_nocross = min(decode_ms(skip_cross_attn=True), decode_ms(skip_cross_attn=True))
         esize = 2 if args.dtype == "bfloat16" else 4
         H, S, nl = cfg.num_heads, args.decode_steps, cfg.num_decoder_layers
-        kv_row = 2.0 * Br * H * 64 * esize                           # K+V bytes of one cache position, all rows
+        # K+V bytes of one cache position, all rows (fp8: 64 e4m3 bytes each + the {k, v} f32 scale pair of the row)
+        kv_row = Br * H * (2.0 * 64 + 8.0) if args.kv_dtype else 2.0 * Br * H * 64 * esize
         launches = S * nl
         # algorithmic bytes: read the t+1 cached K/V rows + q, write the new row + the output
         self_bytes = nl * sum(kv_row * (t + 1) + kv_row + 2.0 * Br * H * 64 * esize for t in range(S))
@@ -328,7 +336,8 @@ def main():
                     pmc = json.load(f)
                 if pmc.get("kernel_source_hash") != kernel_source_hash():
                     continue
-                if pmc["shape"]["B"] == Br and args.dtype == "bfloat16" and args.decode_steps == 1024:
+                if pmc["shape"]["B"] == Br and args.dtype == "bfloat16" and args.decode_steps == 1024 and \
+                        not args.kv_dtype and args.model == "mt3":
                     ratio = pmc["dec_attn_self_append"]["n_keys_513"]["traffic_over_algorithmic"]
                     traffic = ratio * self_bytes / launches
                     traffic_src = "profiles/%s (kernel sources %s; measured traffic/algorithmic = %.4f at the mean " \
@@ -336,8 +345,10 @@ def main():
                     break
             except (OSError, KeyError, ValueError):
                 continue
-        roof = {"bound": "hbm", "kernel": "mt3k::dec_attn_kernel<%s, APPEND=true> (decode self-attention over the "
-                                          "K/V cache)" % ("bf16" if esize == 2 else "f32"),
+        roof = {"bound": "hbm", "kernel": "mt3k::dec_attn_fp8_kernel<APPEND=true> (decode self-attention over the e4m3 "
+                                          "K/V cache)" if args.kv_dtype else
+                "mt3k::dec_attn_kernel<%s, APPEND=true> (decode self-attention over the K/V cache)"
+                % ("bf16" if esize == 2 else "f32"),
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "traffic_source": traffic_src,
                 "avg_launch_us": self_us, "algorithmic_bytes_per_launch": self_bytes / launches, "launches": launches,
@@ -349,7 +360,7 @@ def main():
                 "cross_attn": {"achieved": cross_bytes / launches / (cross_us * 1e-6) / 1e9, "avg_launch_us": cross_us,
                                "algorithmic_bytes_per_launch": cross_bytes / launches}}
 
-        if not args.no_extras and not corpus:
+        if not args.no_extras and not corpus and args.model == "mt3" and not args.kv_dtype:
             # ---- stage extras, driver-timed (HIP events on the launch stream, inputs in HBM)
             peak = MFMA_BF16_PEAK_TFLOPS if esize == 2 else MFMA_F32_PEAK_TFLOPS
             a256 = audio[:Br]
@@ -411,6 +422,37 @@ def main():
                 except Exception as ex:                              # the bf16 line must not die with the extra
                     extras["f32"] = {"value": None, "error": repr(ex)[:300]}
 
+            # ---- BASELINE configs[4] ingredients, one warm-up + one timed step each (not the headline):
+            #   fp8_kv : this workload with e4m3 K/V caches (half the bytes of the HBM-bound decode stream)
+            #   configs4: the ismir2022/base.gin shape (emb 768, 12 heads, 12+12 layers, mlp 2048) with e4m3 K/V caches
+            if args.dtype == "bfloat16" and world == 1:
+                for key, shp, label in (("fp8_kv", network.MT3_SMALL, "MT3 (model.gin) shape"),
+                                        ("configs4", network.MT3_BASE, "ismir2022/base.gin shape")):
+                    try:
+                        c8 = dataclasses.replace(shp, dtype="bfloat16", kv_dtype="fp8_e4m3")
+                        e8 = network.Transformer(c8, input_length=256, max_decode_length=L, max_batch=Br)
+                        e8.load_params(network.init_random_params(c8, seed=0))
+                        with torch.cuda.stream(stream):
+                            e8.encode(lm256)
+                            e8.decode(num_steps=2)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        with torch.cuda.stream(stream):
+                            e8.encode(spectrograms.compute_spectrogram_batch(a256, None))
+                            ids = e8.decode(num_steps=args.decode_steps)
+                            host = vocab.decode_tf(ids).cpu().numpy()
+                        host_stage(host)
+                        torch.cuda.synchronize()
+                        d8 = time.perf_counter() - t1
+                        extras[key] = {"value": Br * SEG_SECONDS / d8, "unit": "audio-s/s", "ms_per_step": d8 * 1e3,
+                                       "steps": 1, "dtype": "bf16 compute + fp8 (e4m3) K/V caches",
+                                       "workload": "%s, batch=%d, %d greedy steps, same pipeline as the headline"
+                                                   % (label, Br, args.decode_steps),
+                                       "device_bytes": e8.device_bytes}
+                        del e8
+                    except Exception as ex:
+                        extras[key] = {"value": None, "error": repr(ex)[:300]}
+
     if rank == 0:
         segs = n_global * args.steps
         value = segs * SEG_SECONDS / dt
@@ -421,6 +463,8 @@ def main():
                         "decoding included" % (corpus, world, n_local, B, args.decoding, args.decode_steps))
         else:
             workload = ("BASELINE configs[2]: MT3 (model.gin) random-init, full encoder-decoder %s "
+                        if args.model == "mt3" else
+                        "BASELINE configs[4] shape: ismir2022/base.gin random-init, full encoder-decoder %s "
                         "decode, batch=%d synthetic 2.048 s segments per GPU, %d decode steps (no early "
                         "exit), hipGraph step replay, ids->tokens + host note decoding included"
                         % ("greedy" if args.decoding == "greedy" else "beam-1 (t5x beam_search, one beam)",
@@ -429,7 +473,9 @@ def main():
             "metric": "audio-seconds transcribed/sec (whole node), MT3-base, 1/2/4/8 MI355X",
             "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if corpus else "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.dtype == "bfloat16" else "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": ("bf16" if args.dtype == "bfloat16" else "f32") + ("+fp8kv" if args.kv_dtype else ""),
+            "data": "synthetic",
             "config": {"workload": workload,
                        "segments_per_gpu": n_local, "segments_total": n_global, "decode_steps": args.decode_steps,
                        "segment_seconds": SEG_SECONDS, "decode_chains": args.chains, "decoding": args.decoding,

@@ -85,7 +85,7 @@ int mt3_frontend_logmel_dev(mt3_frontend* fe, const float* d_audio, int32_t n_se
  * models.ContinuousInputsEncoderDecoderModel (mt3/models.py:121-152):
  * encode once, cross-K/V once, then up to `max_decode_len` cached decode steps.
  */
-typedef enum mt3_dtype { MT3_BF16 = 0, MT3_F32 = 1 } mt3_dtype;
+typedef enum mt3_dtype { MT3_BF16 = 0, MT3_F32 = 1, MT3_FP8_E4M3 = 2 /* K/V caches only: OCP e4m3fn */ } mt3_dtype;
 
 typedef struct mt3_engine_config {   /* network.T5Config (network.py:25-41), model.gin:47-59 */
   int32_t vocab_size;           /* 1536 (mt3) / 1664 (ismir2021): vocabularies.num_embeddings */
@@ -102,6 +102,10 @@ typedef struct mt3_engine_config {   /* network.T5Config (network.py:25-41), mod
   int32_t compute_dtype;        /* mt3_dtype: MFMA operand type; accumulation is always f32 */
   int32_t decode_chains;        /* 0/1: one chain; n <= 8: the decode batch is dealt to n independent row groups
                                    that run as parallel branches of the step graph (same results, bit for bit) */
+  int32_t kv_cache_dtype;       /* 0: K/V caches in the compute dtype.  MT3_FP8_E4M3 (with MT3_BF16 compute): self- and
+                                   cross-attention K/V rows are cached as OCP e4m3 bytes + one power-of-two scale per
+                                   (row, head, position) -- half the bytes the HBM-bound decode step streams
+                                   (BASELINE configs[4] "fp8 path"; tolerances in DESIGN.md section 4) */
 } mt3_engine_config;
 
 typedef struct mt3_engine mt3_engine;
@@ -167,7 +171,8 @@ int mt3_engine_decode_forced(mt3_engine* e, int32_t batch, int32_t num_steps, in
  * ran as direct launches (same ids, slower) -- the fallback is counted, never silent;
  * LAST_DECODE_USED_GRAPH: 1/0 for the most recent decode; RESIDUAL_SPLIT: 1 if the bf16 decode loop carries the
  * residual rows as f32 + bf16 copy + partial sums of squares. */
-enum { MT3_STATUS_GRAPH_FALLBACKS = 0, MT3_STATUS_LAST_DECODE_USED_GRAPH = 1, MT3_STATUS_RESIDUAL_SPLIT = 2 };
+enum { MT3_STATUS_GRAPH_FALLBACKS = 0, MT3_STATUS_LAST_DECODE_USED_GRAPH = 1, MT3_STATUS_RESIDUAL_SPLIT = 2,
+       MT3_STATUS_KV_FP8 = 3 };
 int mt3_engine_status(const mt3_engine* e, int32_t what);
 
 /* GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271): -1 from the
@@ -195,6 +200,15 @@ int mt3_op_encoder_attention(int32_t dtype, const void* d_qkv, void* d_out, int3
 int mt3_op_decode_attention(int32_t dtype, const void* d_q, int32_t q_stride, void* d_kcache, void* d_vcache,
                             int32_t cap, const void* d_new_k, const void* d_new_v, int32_t kv_stride,
                             const int32_t* d_step, int32_t n_keys, void* d_out, int32_t B, int32_t H, void* stream);
+/* The same over an fp8 cache (kv_cache_dtype MT3_FP8_E4M3): d_kcache / d_vcache hold OCP e4m3 bytes [B, H, cap, 64],
+ * d_kv_scale [B, H, cap] pairs of f32 {k_scale, v_scale} (row value = byte value * scale); q, the new rows and
+ * out are bf16.  An appended row is quantised by the kernel (power-of-two scale from the row's amax per head). */
+int mt3_op_decode_attention_fp8(const void* d_q, int32_t q_stride, void* d_kcache, void* d_vcache, void* d_kv_scale,
+                                int32_t cap, const void* d_new_k, const void* d_new_v, int32_t kv_stride,
+                                const int32_t* d_step, int32_t n_keys, void* d_out, int32_t B, int32_t H,
+                                void* stream);
+/* d_src bf16 [2][rows][64] (K rows, then V rows) -> d_dst e4m3 [2][rows][64] + d_scales [rows] f32 pairs */
+int mt3_op_kv_quantize_fp8(const void* d_src, void* d_dst, void* d_scales, int32_t rows, void* stream);
 
 /* --------------------------------------------------- symbolic stage (host CPU)
  * Replaces metrics_utils.event_predictions_to_ns (mt3/metrics_utils.py:59-146) =

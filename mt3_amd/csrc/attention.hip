@@ -468,6 +468,259 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------- decode attention, fp8 (OCP e4m3fn) K/V cache
+// The decode step is HBM-bound on the K/V stream, so the cache is the one place where fp8 pays directly: rows are
+// stored as 64 e4m3 bytes plus ONE power-of-two scale per (row, head, position) for K and for V (float2
+// {k_scale, v_scale} in a side array [B][H][cap]): half the bytes of the bf16 cache (+6 % for the scales).
+// A power-of-two scale only moves the exponent, so quantisation error is the pure 3-bit-mantissa rounding of e4m3.
+// 4 lanes share a key (16 bytes = 16 elements each), a wave covers 16 consecutive keys per load (1 KiB
+// contiguous); q, the probabilities and the accumulators are f32, activations in memory stay bf16.
+// The new row of the step is quantised HERE (per-head amax over the quad), written to the cache, and attended in
+// its DEQUANTISED form, so a position contributes the same values in the step that creates it and in every later one.
+__device__ __forceinline__ void fp8x16_to_f32(const u32x4& c, float* out) {
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(c[w]), false);
+    const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(static_cast<int>(c[w]), true);
+    out[4 * w + 0] = lo[0];
+    out[4 * w + 1] = lo[1];
+    out[4 * w + 2] = hi[0];
+    out[4 * w + 3] = hi[1];
+  }
+}
+__device__ __forceinline__ u32x4 f32x16_to_fp8(const float* v) {
+  u32x4 c;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    int d = 0;
+    d = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * w + 0], v[4 * w + 1], d, false);
+    d = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * w + 2], v[4 * w + 3], d, true);
+    c[w] = static_cast<unsigned>(d);
+  }
+  return c;
+}
+// power-of-two scale s with amax / s in [128, 256) (e4m3fn finite max = 448); amax = 0 -> 1
+__device__ __forceinline__ float fp8_row_scale(float amax) {
+  const unsigned e = (__builtin_bit_cast(unsigned, amax) >> 23) & 0xffu;      // biased exponent of amax
+  const unsigned se = e > 8u ? e - 7u : 1u;                                    // 2^(exp - 7), clamped to normal f32
+  return amax > 0.f ? __builtin_bit_cast(float, se << 23) : 1.f;
+}
+__device__ __forceinline__ float quad_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  return v;
+}
+// quantise 16 f32 values of a 64-wide row held by a quad (4 lanes x 16): returns the chunk, the row scale, and
+// leaves the DEQUANTISED values in v
+__device__ __forceinline__ u32x4 fp8_quantize_quad(float* v, float* scale_out) {
+  float am = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) am = fmaxf(am, fabsf(v[j]));
+  am = quad_max(am);
+  const float sc = fp8_row_scale(am), inv = 1.f / sc;                          // exact: powers of two
+  float t[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) t[j] = v[j] * inv;
+  const u32x4 c = f32x16_to_fp8(t);
+  fp8x16_to_f32(c, t);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = t[j] * sc;
+  *scale_out = sc;
+  return c;
+}
+
+template <bool APPEND, int NW>
+__global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
+  constexpr int D = 64, EPL = 16;         // elements (= bytes) per lane
+  constexpr int LPK = 4;                  // lanes sharing one key
+  constexpr int KPW = 16;                 // keys per wave per load
+  constexpr int STRIDE = NW * KPW;
+  constexpr int UNROLL = 4;
+  constexpr float kLog2e = 1.4426950408889634f;
+
+  __shared__ float s_m[NW][LPK], s_l[NW][LPK], s_acc[NW][LPK][EPL];
+
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane & 3, slot = lane >> 2;
+  const int n_keys = a.step ? (a.step[b] + 1) : a.n_keys;
+  const int pos = n_keys - 1;
+  const int n_cache = APPEND ? pos : n_keys;
+
+  const size_t head = (static_cast<size_t>(b) * a.H + h) * a.cap;
+  const uint8_t* kc = static_cast<const uint8_t*>(a.kcache) + head * D;
+  const uint8_t* vc = static_cast<const uint8_t*>(a.vcache) + head * D;
+  const float2* sc2 = a.kv_scale + head;
+
+  // q: 16 bf16 of this lane's slice -> f32, pre-multiplied by log2(e) (base-2 softmax)
+  float q[EPL];
+  {
+    const __bf16* qp = static_cast<const __bf16*>(a.q) + static_cast<size_t>(b) * a.q_stride + h * D + sub * EPL;
+    const u32x4 q0 = *reinterpret_cast<const u32x4*>(qp), q1 = *reinterpret_cast<const u32x4*>(qp + 8);
+    unpack_chunk<__bf16>(q0, q);
+    unpack_chunk<__bf16>(q1, q + 8);
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) q[j] *= kLog2e;
+  }
+  float nk[EPL], nv[EPL];
+  if constexpr (APPEND) {
+    const __bf16* kp = static_cast<const __bf16*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
+    const __bf16* vp = static_cast<const __bf16*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
+    unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(kp), nk);
+    unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(kp + 8), nk + 8);
+    unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(vp), nv);
+    unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(vp + 8), nv + 8);
+    float ks, vs;
+    const u32x4 kq = fp8_quantize_quad(nk, &ks), vq = fp8_quantize_quad(nv, &vs);     // nk / nv now dequantised
+    if (tid < LPK) {
+      const size_t at = (head + pos) * D + sub * EPL;
+      *reinterpret_cast<u32x4*>(static_cast<uint8_t*>(a.kcache) + at) = kq;
+      *reinterpret_cast<u32x4*>(static_cast<uint8_t*>(a.vcache) + at) = vq;
+      if (tid == 0) const_cast<float2*>(sc2)[pos] = make_float2(ks, vs);
+    }
+  }
+
+  float m = -1.0e30f, l = 0.f, acc[EPL];
+#pragma unroll
+  for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
+
+  for (int base = wave * KPW; base < n_cache; base += STRIDE * UNROLL) {
+    u32x4 kv[UNROLL], vv[UNROLL];
+    float2 ss[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int key = min(base + slot + u * STRIDE, n_cache - 1);
+      kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + static_cast<size_t>(key) * D + sub * EPL));
+      vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + static_cast<size_t>(key) * D + sub * EPL));
+      ss[u] = sc2[key];
+    }
+    float sc[UNROLL];
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      float kf[EPL];
+      fp8x16_to_f32(kv[u], kf);
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < EPL; j += 2) {
+        d0 = __builtin_fmaf(q[j], kf[j], d0);
+        d1 = __builtin_fmaf(q[j + 1], kf[j + 1], d1);
+      }
+      float d = d0 + d1;
+      d = dpp_add<0xB1>(d);
+      d = dpp_add<0x4E>(d);
+      sc[u] = d * ss[u].x;
+      if (base + slot + u * STRIDE < n_cache) mn = fmaxf(mn, sc[u]);
+    }
+    const float rs = __builtin_amdgcn_exp2f(m - mn);
+    float psum = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc[j] *= rs;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const float p = base + slot + u * STRIDE < n_cache ? __builtin_amdgcn_exp2f(sc[u] - mn) : 0.f;
+      psum += p;
+      const float pv = p * ss[u].y;
+      float vf[EPL];
+      fp8x16_to_f32(vv[u], vf);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) acc[j] = __builtin_fmaf(pv, vf[j], acc[j]);
+    }
+    l = l * rs + psum;
+    m = mn;
+  }
+  if constexpr (APPEND) {
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) d = __builtin_fmaf(q[j], nk[j], d);
+    d = dpp_add<0xB1>(d);
+    d = dpp_add<0x4E>(d);
+    const bool mine = tid < LPK;
+    const float mn = mine ? fmaxf(m, d) : m;
+    const float rs = __builtin_amdgcn_exp2f(m - mn);
+    const float p = mine ? __builtin_amdgcn_exp2f(d - mn) : 0.f;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) acc[j] = __builtin_fmaf(p, nv[j], acc[j] * rs);
+    l = l * rs + p;
+    m = mn;
+  }
+#pragma unroll
+  for (int o = LPK; o < 64; o <<= 1) {
+    const float mo = __shfl_xor(m, o), lo = __shfl_xor(l, o);
+    const float mn = fmaxf(m, mo);
+    const float ca = __builtin_amdgcn_exp2f(m - mn), cb = __builtin_amdgcn_exp2f(mo - mn);
+    l = l * ca + lo * cb;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+      const float ao = __shfl_xor(acc[j], o);
+      acc[j] = acc[j] * ca + ao * cb;
+    }
+    m = mn;
+  }
+  if (lane < LPK) {
+    s_m[wave][lane] = m;
+    s_l[wave][lane] = l;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) s_acc[wave][lane][j] = acc[j];
+  }
+  __syncthreads();
+  if (tid < LPK) {
+    float M = s_m[0][tid];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, s_m[w][tid]);
+    float Lsum = 0.f, o[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) o[j] = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float c = __builtin_amdgcn_exp2f(s_m[w][tid] - M);
+      Lsum += s_l[w][tid] * c;
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) o[j] += s_acc[w][tid][j] * c;
+    }
+    const float inv = 1.f / Lsum;
+    __bf16* dst = static_cast<__bf16*>(a.out) + static_cast<size_t>(b) * a.H * D + h * D + tid * EPL;
+    float r0[8], r1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      r0[j] = o[j] * inv;
+      r1[j] = o[8 + j] * inv;
+    }
+    *reinterpret_cast<u32x4*>(dst) = pack_bf16x8(r0);
+    *reinterpret_cast<u32x4*>(dst + 8) = pack_bf16x8(r1);
+  }
+}
+
+// bf16 rows [rows][64] (K rows then V rows, `rows` each, e.g. the cross-attention [2][B][H][T][64] of one layer)
+// -> e4m3 rows + float2 {k_scale, v_scale} per row; one quad per (K row, V row) pair
+__global__ __launch_bounds__(256) void kv_quantize_fp8_kernel(const __bf16* __restrict__ src, uint8_t* __restrict__ dst,
+                                                               float2* __restrict__ scales, int rows) {
+  const int r = blockIdx.x * 64 + (threadIdx.x >> 2), sub = threadIdx.x & 3;
+  if (r >= rows) return;
+  float k[16], v[16];
+  const __bf16* kp = src + static_cast<size_t>(r) * 64 + sub * 16;
+  const __bf16* vp = kp + static_cast<size_t>(rows) * 64;
+  unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(kp), k);
+  unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(kp + 8), k + 8);
+  unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(vp), v);
+  unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(vp + 8), v + 8);
+  float ks, vs;
+  const u32x4 kq = fp8_quantize_quad(k, &ks), vq = fp8_quantize_quad(v, &vs);
+  *reinterpret_cast<u32x4*>(dst + static_cast<size_t>(r) * 64 + sub * 16) = kq;
+  *reinterpret_cast<u32x4*>(dst + (static_cast<size_t>(rows) + r) * 64 + sub * 16) = vq;
+  if (sub == 0) scales[r] = make_float2(ks, vs);
+}
+
+int launch_kv_quantize_fp8(const void* src_bf16, void* dst_fp8, void* scales, int rows, hipStream_t s) {
+  if (!src_bf16 || !dst_fp8 || !scales || rows <= 0) return mt3::fail(MT3_ERR_INVALID, "kv_quantize_fp8: bad arguments");
+  hipLaunchKernelGGL(kv_quantize_fp8_kernel, dim3((rows + 63) / 64), dim3(256), 0, s,
+                     static_cast<const __bf16*>(src_bf16), static_cast<uint8_t*>(dst_fp8),
+                     static_cast<float2*>(scales), rows);
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+
 int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
   if (!a.q || !a.kcache || !a.vcache || !a.out || a.B <= 0 || a.H <= 0 || a.cap <= 0)
     return mt3::fail(MT3_ERR_INVALID, "decode_attention: bad arguments");
@@ -482,6 +735,29 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
     const int n = v ? atoi(v) : 3;
     return (n == 2 || n == 3 || n == 4) ? n : 3;
   }();
+  if (a.kv_scale) {
+    // 128 VGPRs -> 4 waves per SIMD: two-wave workgroups keep all B*H = 1536 groups co-resident (8 per CU)
+    static const int nw8 = [] {
+      const char* v = getenv("MT3_DEC_ATTN_FP8_WAVES");
+      const int n = v ? atoi(v) : 2;
+      return (n == 2 || n == 3 || n == 4) ? n : 2;
+    }();
+    const int nw = nw8;
+    const dim3 grid(a.B * a.H), block(nw * 64);
+    // fp8 (e4m3) K/V cache; activations (q, new rows, out) are bf16
+    if (dtype != MT3_BF16) return mt3::fail(MT3_ERR_INVALID, "decode_attention: the fp8 K/V cache needs bf16 activations");
+#define MT3_LAUNCH_FP8(AP)                                                                       \
+  do {                                                                                           \
+    if (nw == 2) hipLaunchKernelGGL((dec_attn_fp8_kernel<AP, 2>), grid, block, 0, s, a);         \
+    else if (nw == 3) hipLaunchKernelGGL((dec_attn_fp8_kernel<AP, 3>), grid, block, 0, s, a);    \
+    else hipLaunchKernelGGL((dec_attn_fp8_kernel<AP, 4>), grid, block, 0, s, a);                 \
+  } while (0)
+    if (append) MT3_LAUNCH_FP8(true);
+    else MT3_LAUNCH_FP8(false);
+#undef MT3_LAUNCH_FP8
+    MT3_HIP_CHECK(hipGetLastError());
+    return MT3_OK;
+  }
   const dim3 grid(a.B * a.H), block(nw * 64);
 #define MT3_LAUNCH_DEC(CT, AP)                                                                    \
   do {                                                                                            \
@@ -530,6 +806,33 @@ int mt3_op_decode_attention(int32_t dtype, const void* d_q, int32_t q_stride, vo
   a.B = B;
   a.H = H;
   return mt3k::launch_decode_attention(dtype, a, static_cast<hipStream_t>(stream));
+}
+
+int mt3_op_decode_attention_fp8(const void* d_q, int32_t q_stride, void* d_kcache, void* d_vcache, void* d_kv_scale,
+                                int32_t cap, const void* d_new_k, const void* d_new_v, int32_t kv_stride,
+                                const int32_t* d_step, int32_t n_keys, void* d_out, int32_t B, int32_t H,
+                                void* stream) {
+  if (!d_kv_scale) return mt3::fail(MT3_ERR_INVALID, "decode_attention_fp8: null scale array");
+  mt3k::DecAttnArgs a{};
+  a.q = d_q;
+  a.q_stride = q_stride;
+  a.kcache = d_kcache;
+  a.vcache = d_vcache;
+  a.kv_scale = static_cast<float2*>(d_kv_scale);
+  a.cap = cap;
+  a.new_k = d_new_k;
+  a.new_v = d_new_v;
+  a.kv_stride = kv_stride;
+  a.step = d_step;
+  a.n_keys = n_keys;
+  a.out = d_out;
+  a.B = B;
+  a.H = H;
+  return mt3k::launch_decode_attention(MT3_BF16, a, static_cast<hipStream_t>(stream));
+}
+
+int mt3_op_kv_quantize_fp8(const void* d_src, void* d_dst, void* d_scales, int32_t rows, void* stream) {
+  return mt3k::launch_kv_quantize_fp8(d_src, d_dst, d_scales, rows, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

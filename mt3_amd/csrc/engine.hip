@@ -67,6 +67,9 @@ struct LayerDev {
   void* self_k = nullptr;    // decoder [Bm][H][L][64]
   void* self_v = nullptr;
   void* cross_kv = nullptr;  // decoder [2][B][H][T][64]
+  // fp8 (e4m3) K/V caches only: {k_scale, v_scale} per cached row
+  float2* self_scale = nullptr;    // [Bm][H][L]
+  float2* cross_scale = nullptr;   // [B][H][T]
 };
 
 }  // namespace
@@ -78,6 +81,9 @@ struct mt3_engine {
   int64_t device_bytes = 0;
   bool finalized = false;
   int esize = 2;
+  int kv_esize = 2;              // bytes per cached K/V element: esize, or 1 with the fp8 (e4m3) caches
+  bool kv_fp8 = false;
+  void* cross_stage = nullptr;   // fp8 caches: bf16 [2][Bm][H][T][64] landing buffer of the cross-K/V GEMM (one layer)
 
   void* enc_in = nullptr;        // [emb][input_depth]
   float* enc_norm = nullptr;     // [emb] f32
@@ -280,7 +286,7 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   const mt3_engine_config& c = e->cfg;
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), H = c.num_heads, T = c.input_length;
   const int Lmax = c.max_decode_len;
-  const size_t es = e->esize;
+  const size_t es = e->esize, kes = e->kv_esize;
   const bool small = true;
   // the decoder input row of this step (Embed(tok) + FixedEmbed[t]) is already in `y`: written by the
   // embed launch before the first step and by the previous step's argmax kernel afterwards
@@ -329,8 +335,9 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
       mt3k::DecAttnArgs a{};
       a.q = qkv_d;
       a.q_stride = 3 * hd;
-      a.kcache = static_cast<char*>(L.self_k) + static_cast<size_t>(row0) * H * Lmax * 64 * es;
-      a.vcache = static_cast<char*>(L.self_v) + static_cast<size_t>(row0) * H * Lmax * 64 * es;
+      a.kcache = static_cast<char*>(L.self_k) + static_cast<size_t>(row0) * H * Lmax * 64 * kes;
+      a.vcache = static_cast<char*>(L.self_v) + static_cast<size_t>(row0) * H * Lmax * 64 * kes;
+      a.kv_scale = e->kv_fp8 ? L.self_scale + static_cast<size_t>(row0) * H * Lmax : nullptr;
       a.cap = Lmax;
       a.new_k = qkv_d + static_cast<size_t>(hd) * es;
       a.new_v = qkv_d + static_cast<size_t>(2 * hd) * es;
@@ -350,8 +357,9 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
       mt3k::DecAttnArgs x{};
       x.q = q_d;
       x.q_stride = hd;
-      x.kcache = static_cast<char*>(L.cross_kv) + static_cast<size_t>(row0) * H * T * 64 * es;
-      x.vcache = static_cast<char*>(L.cross_kv) + (static_cast<size_t>(B_total) + row0) * H * T * 64 * es;
+      x.kcache = static_cast<char*>(L.cross_kv) + static_cast<size_t>(row0) * H * T * 64 * kes;
+      x.vcache = static_cast<char*>(L.cross_kv) + (static_cast<size_t>(B_total) + row0) * H * T * 64 * kes;
+      x.kv_scale = e->kv_fp8 ? L.cross_scale + static_cast<size_t>(row0) * H * T : nullptr;
       x.cap = T;
       x.n_keys = T;
       x.out = attn_d;
@@ -468,10 +476,16 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->max_batch <= 0 || cfg->max_decode_len <= 0 || cfg->max_decode_len > kMaxPos ||
       cfg->num_encoder_layers <= 0 || cfg->num_decoder_layers <= 0)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: bad sizes");
+  if (cfg->kv_cache_dtype != 0 && cfg->kv_cache_dtype != MT3_FP8_E4M3)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: kv_cache_dtype must be 0 (= compute dtype) or MT3_FP8_E4M3");
+  if (cfg->kv_cache_dtype == MT3_FP8_E4M3 && cfg->compute_dtype != MT3_BF16)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the fp8 K/V caches go with compute_dtype MT3_BF16");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
   e->cfg = *cfg;
   e->esize = cfg->compute_dtype == MT3_BF16 ? 2 : 4;
+  e->kv_fp8 = cfg->kv_cache_dtype == MT3_FP8_E4M3;
+  e->kv_esize = e->kv_fp8 ? 1 : e->esize;
   *out = e;
   return MT3_OK;
 }
@@ -551,12 +565,21 @@ int mt3_engine_finalize(mt3_engine* e) {
     if ((rc = build_attention(e, P + "/self_attention", s1, false, &e->dec[l]))) return rc;
     if ((rc = build_attention(e, P + "/encoder_decoder_attention", s2, true, &e->dec[l]))) return rc;
     if ((rc = build_mlp(e, P + "/mlp", s3, &e->dec[l]))) return rc;
-    const size_t kvb = static_cast<size_t>(Bm) * c.num_heads * L * 64 * e->esize;
+    const size_t kvb = static_cast<size_t>(Bm) * c.num_heads * L * 64 * e->kv_esize;
     if ((rc = dmalloc(e, &e->dec[l].self_k, kvb))) return rc;
     if ((rc = dmalloc(e, &e->dec[l].self_v, kvb))) return rc;
-    if ((rc = dmalloc(e, &e->dec[l].cross_kv, static_cast<size_t>(2) * Bm * c.num_heads * T * 64 * e->esize)))
+    if ((rc = dmalloc(e, &e->dec[l].cross_kv, static_cast<size_t>(2) * Bm * c.num_heads * T * 64 * e->kv_esize)))
       return rc;
+    if (e->kv_fp8) {
+      if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->dec[l].self_scale),
+                        static_cast<size_t>(Bm) * c.num_heads * L * sizeof(float2))))
+        return rc;
+      if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->dec[l].cross_scale),
+                        static_cast<size_t>(Bm) * c.num_heads * T * sizeof(float2))))
+        return rc;
+    }
   }
+  if (e->kv_fp8 && (rc = dmalloc(e, &e->cross_stage, static_cast<size_t>(2) * Bm * c.num_heads * T * 64 * 2))) return rc;
   {
     const float* sn = scale_of(e, "decoder/decoder_norm/scale");
     const HostWeight* w = find(e, "decoder/logits_dense/kernel", emb, c.vocab_size);
@@ -586,7 +609,7 @@ int mt3_engine_finalize(mt3_engine* e) {
   if ((rc = dmalloc(e, &e->hbuf, M * c.mlp_dim * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->enc_out, M * emb * e->esize))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y), static_cast<size_t>(Bm) * emb * 4))) return rc;
-  e->y_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && emb <= 512 && !getenv("MT3_NO_Y_SPLIT");
+  e->y_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && (emb <= 512 || emb == 768) && !getenv("MT3_NO_Y_SPLIT");
   if (e->y_split) {
     if ((rc = dmalloc(e, &e->y_ct, static_cast<size_t>(Bm) * emb * 2))) return rc;
     if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y_ss), static_cast<size_t>(Bm) * (emb / 16) * 4))) return rc;
@@ -646,9 +669,13 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
   }
   MT3_TRY(mt3k::launch_rmsnorm(dt, e->x, e->enc_norm, e->enc_out, d_encoded_f32, M, emb, s));
   for (int l = 0; l < c.num_decoder_layers; ++l) {
-    mt3k::GemmArgs g = gemm_args(e->enc_out, e->dec[l].wkv_x, e->dec[l].cross_kv, M, 2 * hd, emb, 2 * hd);
+    mt3k::GemmArgs g = gemm_args(e->enc_out, e->dec[l].wkv_x, e->kv_fp8 ? e->cross_stage : e->dec[l].cross_kv, M,
+                                 2 * hd, emb, 2 * hd);
     g.seq_len = T;
     MT3_TRY(mt3k::launch_gemm(dt, g, false, false, MT3_EPI_HEADS, small, s));
+    if (e->kv_fp8)     // bf16 [2][B][H][T][64] -> e4m3 rows + one power-of-two scale per (row, head, position)
+      MT3_TRY(mt3k::launch_kv_quantize_fp8(e->cross_stage, e->dec[l].cross_kv, e->dec[l].cross_scale,
+                                           batch * c.num_heads * T, s));
   }
   e->cur_batch = batch;
   return MT3_OK;
@@ -740,6 +767,7 @@ int mt3_engine_status(const mt3_engine* e, int32_t what) {
     case MT3_STATUS_GRAPH_FALLBACKS: return e->graph_fallbacks;
     case MT3_STATUS_LAST_DECODE_USED_GRAPH: return e->last_used_graph;
     case MT3_STATUS_RESIDUAL_SPLIT: return e->y_split ? 1 : 0;
+    case MT3_STATUS_KV_FP8: return e->kv_fp8 ? 1 : 0;
     default: return mt3::fail(MT3_ERR_INVALID, "mt3_engine_status: unknown item");
   }
 }

@@ -98,7 +98,7 @@ __device__ __forceinline__ void gemm_load_tiles(u32x4 (&a_reg)[A_PASSES], u32x4 
   }
 }
 
-template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI>
+template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   constexpr int NT = WM * WN * 64;
   constexpr int KPL = CTraits<CT>::KPL;
@@ -142,15 +142,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
 
   const int ld_row = tid / CPR, ld_chunk = tid % CPR;
-  // norm == 2: the K/16 (<= 32) exact partial sums of squares of this thread's tile row, requested up front and
-  // folded only after the operand loads have been issued (the fold must not delay them)
-  float4 pv[8];
+  // norm == 2: the K/16 (<= 4 * NPV) exact partial sums of squares of this thread's tile row, requested up front
+  // and folded only after the operand loads have been issued (the fold must not delay them)
+  float4 pv[NPV];
   const bool scale_rows = !NORM && gAss != nullptr && tid < BM;
   if constexpr (!NORM) {
     const int prow = m0 + tid < gM ? m0 + tid : gM - 1;
     const float4* p4 = reinterpret_cast<const float4*>(gAss + static_cast<size_t>(prow) * (gK >> 4));
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < NPV; ++u)
       pv[u] = (scale_rows && u < (gK >> 6)) ? p4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   u32x4 a_reg[A_PASSES], b_reg[B_PASSES];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
     if (scale_rows) {
       float t = 0.f;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t = (((t + pv[u].x) + pv[u].y) + pv[u].z) + pv[u].w;      // fixed order per row
+      for (int u = 0; u < NPV; ++u) t = (((t + pv[u].x) + pv[u].y) + pv[u].z) + pv[u].w;    // fixed order per row
       rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);                               // read after the K loop's barriers
     }
   }
@@ -373,12 +373,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
 }
 
 // ------------------------------------------------------------------ dispatch
-template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI>
+template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   if (g.N % BN != 0 || g.K % BK != 0) return mt3::fail(MT3_ERR_INVALID, "gemm: N/K not a multiple of the tile");
+  if (g.a_ss && g.K > 64 * NPV) return mt3::fail(MT3_ERR_INVALID, "gemm: K too large for this tile's partial-sum registers");
   const int grid = ((g.M + BM - 1) / BM) * (g.N / BN);
-  hipLaunchKernelGGL((gemm_kernel<CT, BM, BN, BK, WM, WN, A_F32, NORM, EPI>), dim3(grid), dim3(WM * WN * 64), 0, s,
-                     g);
+  hipLaunchKernelGGL((gemm_kernel<CT, BM, BN, BK, WM, WN, A_F32, NORM, EPI, NPV>), dim3(grid), dim3(WM * WN * 64), 0,
+                     s, g);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }
@@ -395,6 +396,14 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
   constexpr int KG = CTraits<CT>::KGROUP;
   if (small) {
     const bool deep = g.K % (16 * KG) == 0;
+    if constexpr (!NORM && !A_F32 && KG == 32 && EPI != MT3_EPI_HEADS && EPI != MT3_EPI_POS) {
+      // ismir2022/base.gin shape (emb = heads * 64 = 768): K = 768 as ONE slice too, with room for its 48 partial
+      // sums of squares when the rows arrive as the bf16 residual copy (norm 2)
+      if (g.K == 24 * KG) {
+        if constexpr (EPI == MT3_EPI_GEGLU) return launch_cfg<CT, 32, 64, 24 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
+        else return launch_cfg<CT, 32, 32, 24 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
+      }
+    }
     if constexpr (EPI == MT3_EPI_GEGLU) {
       if (deep) return launch_cfg<CT, 32, 64, 16 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 64, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
@@ -415,8 +424,8 @@ template <typename CT>
 static int launch_typed(const GemmArgs& g, bool a_f32, int norm, int epi, bool small, hipStream_t s) {
   // Only the combinations the engine uses are instantiated.
   if (norm == 2) {
-    if (a_f32 || !g.a_ss || g.K % 64 || g.K > 512)
-      return mt3::fail(MT3_ERR_INVALID, "gemm: norm 2 needs a compute-type A, a_ss and K = 64n <= 512");
+    if (a_f32 || !g.a_ss || g.K % 64 || (g.K > 512 && g.K != 768))
+      return mt3::fail(MT3_ERR_INVALID, "gemm: norm 2 needs a compute-type A, a_ss and K = 64n <= 512 (or 768)");
     switch (epi) {
       case MT3_EPI_STORE: return launch_tile<CT, false, false, MT3_EPI_STORE>(g, small, s);
       case MT3_EPI_GEGLU: return launch_tile<CT, false, false, MT3_EPI_GEGLU>(g, small, s);

@@ -44,7 +44,12 @@ struct DecAttnArgs {
   int n_keys;
   void* out;            // [B, H*64] compute type
   int B, H;
+  // non-null: the cache holds OCP e4m3 bytes [B, H, cap, 64] and this is its side array [B, H, cap] of
+  // {k_scale, v_scale} (power-of-two row scales); q / new rows / out are bf16
+  float2* kv_scale;
 };
+// bf16 K rows then V rows ([2][rows][64]) -> e4m3 [2][rows][64] + float2 scales [rows]
+int launch_kv_quantize_fp8(const void* src_bf16, void* dst_fp8, void* scales, int rows, hipStream_t s);
 int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s);
 
 // out_ct[row] = x[row] * rsqrt(mean(x^2)+eps) * scale ; optional f32 copy

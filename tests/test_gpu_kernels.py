@@ -205,6 +205,95 @@ def test_decode_attention_cross(dtype):
     assert rel_err(out, ref) < (5e-3 if dtype == BF16 else 2e-5)
 
 
+# ------------------------------------------------------------------ fp8 (e4m3) K/V cache
+def _fp8_quant_ref(x):
+    """rows [..., 64] (any float dtype) -> (uint8 e4m3fn bytes, power-of-two scale, dequantised f64): the rule of
+    fp8_quantize_quad: scale = 2^(exponent(amax) - 7) so that amax / scale is in [128, 256)."""
+    x = x.float()
+    amax = x.abs().amax(-1, keepdim=True)
+    e = torch.frexp(amax)[1].float() - 1                      # amax = m * 2^e, m in [1, 2)
+    scale = torch.where(amax > 0, torch.exp2(e - 7), torch.ones_like(amax))
+    q = (x / scale).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale.squeeze(-1), q.float().double() * scale.double()
+
+
+def test_kv_quantize_fp8_bit_exact():
+    rows = 2 * 3 * 37
+    g = torch.Generator(device="cuda").manual_seed(12)
+    src = (torch.randn(2, rows, 64, device="cuda", generator=g) * torch.logspace(-3, 2, rows, device="cuda")[None, :, None])
+    src[0, 5] = 0.0                                           # an all-zero row: scale 1, bytes 0
+    src = src.to(torch.bfloat16)
+    dst = torch.zeros(2, rows, 64, device="cuda", dtype=torch.uint8)
+    sc = torch.zeros(rows, 2, device="cuda")
+    _lib.check(lib().mt3_op_kv_quantize_fp8(src.data_ptr(), dst.data_ptr(), sc.data_ptr(), rows, stream()))
+    torch.cuda.synchronize()
+    qk, sk, _ = _fp8_quant_ref(src[0])
+    qv, sv, _ = _fp8_quant_ref(src[1])
+    assert torch.equal(sc[:, 0], sk) and torch.equal(sc[:, 1], sv)
+    # e4m3 has +0 / -0: compare as values
+    assert torch.equal(dst[0].view(torch.float8_e4m3fn).float(), qk.view(torch.float8_e4m3fn).float())
+    assert torch.equal(dst[1].view(torch.float8_e4m3fn).float(), qv.view(torch.float8_e4m3fn).float())
+
+
+@pytest.mark.parametrize("n_keys", [1, 2, 17, 49, 257, 1024])
+def test_decode_attention_fp8_append(n_keys):
+    """fp8 cache: the kernel's result equals exact attention over the DEQUANTISED cache (incl. the row it appends
+    and quantises itself); the cache bytes / scales of the new row follow the quantisation rule, others untouched."""
+    B, H, cap = 5, 6, 1024
+    g = torch.Generator(device="cuda").manual_seed(100 + n_keys)
+    kb, ks, kd = _fp8_quant_ref(torch.randn(B, H, cap, 64, device="cuda", generator=g) * 1.3)
+    vb, vs, vd = _fp8_quant_ref(torch.randn(B, H, cap, 64, device="cuda", generator=g) * 0.7)
+    kc, vc = kb.clone(), vb.clone()
+    sc = torch.stack([ks, vs], -1).contiguous()               # [B, H, cap, 2]
+    qkv = torch.randn(B, 3 * H * 64, device="cuda", generator=g)
+    qkv[:, : H * 64] *= 0.35
+    qkv = qkv.to(torch.bfloat16)
+    step = torch.full((B,), n_keys - 1, device="cuda", dtype=torch.int32)
+    out = torch.zeros(B, H * 64, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib().mt3_op_decode_attention_fp8(qkv.data_ptr(), 3 * H * 64, kc.data_ptr(), vc.data_ptr(), sc.data_ptr(),
+                                                 cap, qkv.data_ptr() + H * 64 * 2, qkv.data_ptr() + 2 * H * 64 * 2,
+                                                 3 * H * 64, step.data_ptr(), 0, out.data_ptr(), B, H, stream()))
+    torch.cuda.synchronize()
+    q = qkv[:, : H * 64].view(B, H, 64).double()
+    nkb, nks, nkd = _fp8_quant_ref(qkv[:, H * 64: 2 * H * 64].view(B, H, 64))
+    nvb, nvs, nvd = _fp8_quant_ref(qkv[:, 2 * H * 64:].view(B, H, 64))
+    pos = n_keys - 1
+    f8 = lambda t: t.view(torch.float8_e4m3fn).float()
+    assert torch.equal(f8(kc[:, :, pos]), f8(nkb)) and torch.equal(f8(vc[:, :, pos]), f8(nvb))
+    assert torch.equal(sc[:, :, pos, 0], nks) and torch.equal(sc[:, :, pos, 1], nvs)
+    keep = torch.ones(cap, dtype=torch.bool, device="cuda")
+    keep[pos] = False
+    assert torch.equal(kc[:, :, keep], kb[:, :, keep]) and torch.equal(vc[:, :, keep], vb[:, :, keep])
+    K, V = kd.clone(), vd.clone()
+    K[:, :, pos], V[:, :, pos] = nkd, nvd
+    w = torch.softmax(torch.einsum("bhd,bhkd->bhk", q, K[:, :, :n_keys]), -1)
+    ref = torch.einsum("bhk,bhkd->bhd", w, V[:, :, :n_keys]).reshape(B, H * 64)
+    assert rel_err(out, ref) < 5e-3, f"rel err {rel_err(out, ref)}"          # bf16 output rounding only
+
+
+def test_decode_attention_fp8_cross_and_error_vs_unquantised():
+    B, H, T = 4, 6, 256
+    g = torch.Generator(device="cuda").manual_seed(4)
+    kv = torch.randn(2, B * H * T, 64, device="cuda", generator=g).to(torch.bfloat16)
+    q = (torch.randn(B, H * 64, device="cuda", generator=g) * 0.35).to(torch.bfloat16)
+    dst = torch.zeros(2, B * H * T, 64, device="cuda", dtype=torch.uint8)
+    sc = torch.zeros(B * H * T, 2, device="cuda")
+    _lib.check(lib().mt3_op_kv_quantize_fp8(kv.data_ptr(), dst.data_ptr(), sc.data_ptr(), B * H * T, stream()))
+    out = torch.zeros(B, H * 64, device="cuda", dtype=torch.bfloat16)
+    _lib.check(lib().mt3_op_decode_attention_fp8(q.data_ptr(), H * 64, dst[0].data_ptr(), dst[1].data_ptr(),
+                                                 sc.data_ptr(), T, None, None, 0, None, T, out.data_ptr(), B, H, stream()))
+    torch.cuda.synchronize()
+    _, _, kd = _fp8_quant_ref(kv[0])
+    _, _, vd = _fp8_quant_ref(kv[1])
+    qd = q.view(B, H, 64).double()
+    att = lambda K, V: torch.einsum("bhk,bhkd->bhd", torch.softmax(torch.einsum(
+        "bhd,bhkd->bhk", qd, K.view(B, H, T, 64)), -1), V.view(B, H, T, 64)).reshape(B, H * 64)
+    assert rel_err(out, att(kd, vd)) < 5e-3
+    # what e4m3 storage costs against the unquantised bf16 cache (3-bit mantissa, averaged by the dot products)
+    e = rel_err(out, att(kv[0].double(), kv[1].double()))
+    assert e < 4e-2, e
+
+
 # ------------------------------------------------------------------ ids -> tokens
 def test_ids_to_tokens_bit_exact():
     from oracle import symbolic as S
