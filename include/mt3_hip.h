@@ -190,6 +190,18 @@ enum { MT3_EPI_STORE = 0, MT3_EPI_RESID = 1, MT3_EPI_GEGLU = 2, MT3_EPI_POS = 3,
 int mt3_op_gemm(int32_t dtype, const void* d_A, int32_t a_is_f32, int32_t norm, const void* d_Wt,
                 void* d_out, int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* d_aux,
                 int32_t seq_len, int32_t small, void* stream);
+/* The same with the split residual stream: norm = 2 takes A as the COMPUTE-TYPE copy of the
+ * rows plus d_a_ss [M][K/16], the exact f32 sums of squares of each 16-column group (what the producer of the rows
+ * left), instead of accumulating statistics from an f32 A; with EPI_RESID, d_out_ct / d_out_ss (both or neither)
+ * receive the compute-type copy [M][N] and the partial sums [M][N/16] of the updated rows.  small = 0 with bf16
+ * operands in memory selects the LDS-DMA staged 128x128x64 tile. */
+int mt3_op_gemm_ex(int32_t dtype, const void* d_A, int32_t a_is_f32, int32_t norm, const void* d_Wt,
+                   void* d_out, int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* d_aux,
+                   int32_t seq_len, int32_t small, const float* d_a_ss, void* d_out_ct, float* d_out_ss,
+                   void* stream);
+/* x f32 [rows][dim] -> compute-type copy [rows][dim] + per-16-column sums of squares [rows][dim/16] */
+int mt3_op_residual_split(int32_t dtype, const float* d_x, void* d_x_ct, float* d_x_ss, int32_t rows, int32_t dim,
+                          void* stream);
 /* encoder self-attention over qkv [B, T, 3, H, 64] -> out [B, T, H*64]; unscaled logits, softmax f32 */
 int mt3_op_encoder_attention(int32_t dtype, const void* d_qkv, void* d_out, int32_t B, int32_t T, int32_t H,
                              void* stream);

@@ -77,6 +77,9 @@ SIGNATURES = {
     "mt3_ids_to_tokens": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mt3_op_gemm": (C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                               C.c_int32, _P, C.c_int32, C.c_int32, _P]),
+    "mt3_op_gemm_ex": (C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "mt3_op_residual_split": (C.c_int, [C.c_int32, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     "mt3_op_encoder_attention": (C.c_int, [C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "mt3_op_decode_attention": (C.c_int, [C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, _P, _P, C.c_int32, _P,
                                           C.c_int32, _P, C.c_int32, C.c_int32, _P]),

@@ -79,6 +79,32 @@ __device__ __forceinline__ void put_row_piece(float4 v, float* y, void* y_ct, fl
   }
 }
 
+// the split form of residual rows that did not come out of a RESID epilogue (the encoder's input projection):
+// f32 rows -> bf16 copy + exact per-16-column sums of squares; one float4 per thread, a quad per 16-column group
+__global__ __launch_bounds__(256) void residual_split_kernel(const float* __restrict__ x, void* __restrict__ x_ct,
+                                                              float* __restrict__ x_ss, size_t n4, int dim) {
+  const size_t i4 = static_cast<size_t>(blockIdx.x) * 256 + threadIdx.x;
+  const bool in = i4 < n4;
+  const float4 v = in ? reinterpret_cast<const float4*>(x)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float t = __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
+  t = quad_sum(t);
+  if (!in) return;
+  if ((threadIdx.x & 3) == 0) x_ss[i4 >> 2] = t;         // [row][dim/16] == flat index / 16
+  uint2 pk;
+  pk.x = pack_bf16x2(v.x, v.y);
+  pk.y = pack_bf16x2(v.z, v.w);
+  reinterpret_cast<uint2*>(x_ct)[i4] = pk;
+}
+
+int launch_residual_split(const float* x, void* x_ct, float* x_ss, int rows, int dim, hipStream_t s) {
+  if (!x || !x_ct || !x_ss || rows <= 0 || dim % 16) return mt3::fail(MT3_ERR_INVALID, "residual_split: bad arguments");
+  const size_t n4 = static_cast<size_t>(rows) * dim / 4;
+  hipLaunchKernelGGL(residual_split_kernel, dim3(static_cast<unsigned>((n4 + 255) / 256)), dim3(256), 0, s, x, x_ct,
+                     x_ss, n4, dim);
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+
 __global__ __launch_bounds__(128) void embed_kernel(const float* __restrict__ table, const float* __restrict__ pos,
                                                      const int* __restrict__ tok, const int* __restrict__ step,
                                                      float* __restrict__ y, void* __restrict__ y_ct,
@@ -327,6 +353,12 @@ int launch_ids_to_tokens(const int* ids, int B, int L, int num_regular, int* out
 }
 
 }  // namespace mt3k
+
+extern "C" int mt3_op_residual_split(int32_t dtype, const float* d_x, void* d_x_ct, float* d_x_ss, int32_t rows,
+                                     int32_t dim, void* stream) {
+  if (dtype != MT3_BF16) return mt3::fail(MT3_ERR_INVALID, "residual_split: the split stream is a bf16-path format");
+  return mt3k::launch_residual_split(d_x, d_x_ct, d_x_ss, rows, dim, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int mt3_ids_to_tokens(const int32_t* d_ids, int32_t batch, int32_t length, int32_t num_regular,
                                  int32_t* d_tokens, void* stream) {

@@ -94,6 +94,11 @@ struct mt3_engine {
 
   // encoder workspaces
   float* x = nullptr;
+  // bf16 path: the encoder's residual rows also travel split (bf16 copy + partial sums of squares), so that every
+  // encoder GEMM reads bf16 operands through the LDS-DMA staged tile
+  void* x_ct = nullptr;          // [max_batch * T][emb] bf16
+  float* x_ss = nullptr;         // [max_batch * T][emb / 16]
+  bool x_split = false;
   void* qkv = nullptr;
   void* attn = nullptr;
   void* hbuf = nullptr;
@@ -604,6 +609,11 @@ int mt3_engine_finalize(mt3_engine* e) {
   // ---- workspaces
   const size_t M = static_cast<size_t>(Bm) * T;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x), M * emb * 4))) return rc;
+  e->x_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && emb <= 1024 && !getenv("MT3_NO_X_SPLIT");
+  if (e->x_split) {
+    if ((rc = dmalloc(e, &e->x_ct, M * emb * 2))) return rc;
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x_ss), M * (emb / 16) * 4))) return rc;
+  }
   if ((rc = dmalloc(e, &e->qkv, M * 3 * hd * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->attn, M * hd * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->hbuf, M * c.mlp_dim * e->esize))) return rc;
@@ -655,17 +665,28 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
     g.seq_len = T;
     MT3_TRY(mt3k::launch_gemm(dt, g, true, false, MT3_EPI_POS, small, s));
   }
+  const bool xs = e->x_split;
+  if (xs) MT3_TRY(mt3k::launch_residual_split(e->x, e->x_ct, e->x_ss, M, emb, s));
+  auto normed = [&](const void* Wt, void* out, int N, int ldo) {
+    mt3k::GemmArgs g = gemm_args(xs ? static_cast<const void*>(e->x_ct) : static_cast<const void*>(e->x), Wt, out, M,
+                                 N, emb, ldo);
+    g.a_ss = xs ? e->x_ss : nullptr;
+    return g;
+  };
+  auto resid = [&](const void* A, const void* Wt, int K) {
+    mt3k::GemmArgs g = gemm_args(A, Wt, e->x, M, emb, K, emb);
+    g.out_ct = xs ? e->x_ct : nullptr;
+    g.out_ss = xs ? e->x_ss : nullptr;
+    return g;
+  };
+  const int nrm = xs ? 2 : 1;
   for (int l = 0; l < c.num_encoder_layers; ++l) {
     LayerDev& L = e->enc[l];
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->x, L.wqkv, e->qkv, M, 3 * hd, emb, 3 * hd), true, true, MT3_EPI_STORE,
-                              small, s));
+    MT3_TRY(mt3k::launch_gemm(dt, normed(L.wqkv, e->qkv, 3 * hd, 3 * hd), !xs, nrm, MT3_EPI_STORE, small, s));
     MT3_TRY(mt3k::launch_encoder_attention(dt, e->qkv, e->attn, batch, T, c.num_heads, s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->attn, L.wo, e->x, M, emb, hd, emb), false, false, MT3_EPI_RESID, small,
-                              s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->x, L.wi, e->hbuf, M, 2 * c.mlp_dim, emb, c.mlp_dim), true, true,
-                              MT3_EPI_GEGLU, small, s));
-    MT3_TRY(mt3k::launch_gemm(dt, gemm_args(e->hbuf, L.wo_mlp, e->x, M, emb, c.mlp_dim, emb), false, false,
-                              MT3_EPI_RESID, small, s));
+    MT3_TRY(mt3k::launch_gemm(dt, resid(e->attn, L.wo, hd), false, 0, MT3_EPI_RESID, small, s));
+    MT3_TRY(mt3k::launch_gemm(dt, normed(L.wi, e->hbuf, 2 * c.mlp_dim, c.mlp_dim), !xs, nrm, MT3_EPI_GEGLU, small, s));
+    MT3_TRY(mt3k::launch_gemm(dt, resid(e->hbuf, L.wo_mlp, c.mlp_dim), false, 0, MT3_EPI_RESID, small, s));
   }
   MT3_TRY(mt3k::launch_rmsnorm(dt, e->x, e->enc_norm, e->enc_out, d_encoded_f32, M, emb, s));
   for (int l = 0; l < c.num_decoder_layers; ++l) {

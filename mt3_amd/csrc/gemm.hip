@@ -98,6 +98,154 @@ __device__ __forceinline__ void gemm_load_tiles(u32x4 (&a_reg)[A_PASSES], u32x4 
   }
 }
 
+// ------------------------------------------------------------------ epilogues (shared by the tile kernels below)
+struct EpiCtx {
+  void* out;
+  const float* aux;
+  int M, N, ldo, seq;
+  void* out_ct;
+  float* out_ss;
+};
+
+// acc[i][j]: the wave's (wm, wn) sub-tile as FM x FN 16x16 C fragments of the workgroup tile at (m0, n0);
+// row_rs(lrow) = 1 / rms of tile row lrow (or 1)
+template <typename CT, int EPI, int FM, int FN, typename RowRs>
+__device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm, int wn, int lane, int m0, int n0,
+                                              const EpiCtx& c, RowRs row_rs) {
+  const int frag_row = lane & 15, frag_g = lane >> 4;
+  // ---- epilogue: C fragment (i, j): rows (lane>>4)*4 + r, col lane & 15
+  // 2-byte outputs are never stored one element at a time (a sub-dword store costs a read-modify-write in the
+  // cache: the bf16 STORE epilogue of a decode GEMM took 2.5 us against 0.7 us for the f32 RESID one): lanes l
+  // and l^1 hold adjacent columns, so they swap over DPP and the even lane stores rows r = 0, 1, the odd lane
+  // rows r = 2, 3 of the pair as whole dwords.
+  constexpr bool PAIRED = sizeof(CT) == 2 && (EPI == MT3_EPI_STORE || EPI == MT3_EPI_GEGLU || EPI == MT3_EPI_HEADS);
+  if constexpr (PAIRED) {
+    const int odd = frag_row & 1;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int lrow0 = wm * FM * 16 + i * 16 + frag_g * 4;
+#pragma unroll
+      for (int j = 0; j < FN; j += (EPI == MT3_EPI_GEGLU ? 2 : 1)) {
+        float mine[4], other[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float rs = row_rs(lrow0 + r);
+          if constexpr (EPI == MT3_EPI_GEGLU) mine[r] = gelu_tanh(acc[i][j][r] * rs) * (acc[i][j + 1][r] * rs);
+          else mine[r] = acc[i][j][r] * rs;
+          other[r] = lane_xor1(mine[r]);
+        }
+        // logical output column of this lane's element, and of the pair's even element
+        const int col = EPI == MT3_EPI_GEGLU ? ((n0 + wn * FN * 16 + j * 16) >> 1) + frag_row
+                                             : n0 + wn * FN * 16 + j * 16 + frag_row;
+        const int col_even = col - odd;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int r = odd * 2 + h;
+          const int row = m0 + lrow0 + r;
+          if (row >= c.M) continue;
+          // (selects, not mine[r]: a runtime index would put the arrays in scratch memory)
+          const float lo = odd ? other[2 + h] : mine[h], hi = odd ? mine[2 + h] : other[h];
+          const unsigned pair = pack_bf16x2(lo, hi);
+          size_t dst;
+          if constexpr (EPI == MT3_EPI_HEADS) {   // col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
+            const int hd = c.N >> 1;               // H * 64
+            const int kv = col_even / hd, hh = (col_even % hd) >> 6, d = col_even & 63;
+            const int bb = row / c.seq, t = row % c.seq, H = hd >> 6, B = c.M / c.seq;
+            dst = ((((static_cast<size_t>(kv) * B + bb) * H + hh) * c.seq) + t) * 64 + d;
+          } else {
+            dst = static_cast<size_t>(row) * c.ldo + col_even;
+          }
+          *reinterpret_cast<unsigned*>(static_cast<CT*>(c.out) + dst) = pair;
+        }
+      }
+    }
+  } else if constexpr (EPI == MT3_EPI_RESID && sizeof(CT) == 2) {
+    // residual update; on request also the compute-type copy of the new rows (dword stores of column pairs) and
+    // the sum of squares of each row over this fragment's 16 columns (exact f32, reduced on the DPP row)
+    const int odd = frag_row & 1;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int lrow0 = wm * FM * 16 + i * 16 + frag_g * 4;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = n0 + wn * FN * 16 + j * 16 + frag_row;
+        float vnew[4], other[4], part[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + lrow0 + r;
+          const size_t at = static_cast<size_t>(row < c.M ? row : c.M - 1) * c.ldo + col;
+          vnew[r] = static_cast<float*>(c.out)[at] + acc[i][j][r];
+          if (row < c.M) static_cast<float*>(c.out)[at] = vnew[r];
+        }
+        if (c.out_ct) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            other[r] = lane_xor1(vnew[r]);
+            part[r] = row16_sum(vnew[r] * vnew[r]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + lrow0 + r;
+            if (frag_row == 0 && row < c.M)
+              c.out_ss[static_cast<size_t>(row) * (c.N >> 4) + ((n0 + wn * FN * 16 + j * 16) >> 4)] = part[r];
+          }
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int row = m0 + lrow0 + odd * 2 + h;
+            if (row >= c.M) continue;
+            const float lo = odd ? other[2 + h] : vnew[h], hi = odd ? vnew[2 + h] : other[h];
+            *reinterpret_cast<unsigned*>(static_cast<CT*>(c.out_ct) + static_cast<size_t>(row) * c.ldo + col - odd) =
+                pack_bf16x2(lo, hi);
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lrow = wm * FM * 16 + i * 16 + frag_g * 4 + r;
+        const int row = m0 + lrow;
+        if (row >= c.M) continue;
+        const float rs = row_rs(lrow);
+        if constexpr (EPI == MT3_EPI_GEGLU) {
+          CT* out = static_cast<CT*>(c.out);
+#pragma unroll
+          for (int j = 0; j < FN; j += 2) {
+            const int col = n0 + wn * FN * 16 + j * 16;                  // multiple of 32
+            const float gate = acc[i][j][r] * rs, lin = acc[i][j + 1][r] * rs;
+            out[static_cast<size_t>(row) * c.ldo + (col >> 1) + frag_row] = to_ct<CT>(gelu_tanh(gate) * lin);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int col = n0 + wn * FN * 16 + j * 16 + frag_row;
+            const float v = acc[i][j][r] * rs;
+            if constexpr (EPI == MT3_EPI_STORE) {
+              static_cast<CT*>(c.out)[static_cast<size_t>(row) * c.ldo + col] = to_ct<CT>(v);
+            } else if constexpr (EPI == MT3_EPI_RESID) {
+              float* o = static_cast<float*>(c.out) + static_cast<size_t>(row) * c.ldo + col;
+              *o = *o + v;
+            } else if constexpr (EPI == MT3_EPI_POS) {
+              static_cast<float*>(c.out)[static_cast<size_t>(row) * c.ldo + col] =
+                  v + c.aux[static_cast<size_t>(row % c.seq) * c.N + col];
+            } else if constexpr (EPI == MT3_EPI_F32) {
+              static_cast<float*>(c.out)[static_cast<size_t>(row) * c.ldo + col] = v;
+            } else {  // MT3_EPI_HEADS: col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
+              const int hd = c.N >> 1;                       // H * 64
+              const int kv = col / hd, h = (col % hd) >> 6, d = col & 63;
+              const int b = row / c.seq, t = row % c.seq, H = hd >> 6, B = c.M / c.seq;
+              const size_t dst = ((((static_cast<size_t>(kv) * B + b) * H + h) * c.seq) + t) * 64 + d;
+              static_cast<CT*>(c.out)[dst] = to_ct<CT>(v);
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   constexpr int NT = WM * WN * 64;
@@ -238,138 +386,235 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
     return rsqrtf(t / static_cast<float>(gK) + 1e-6f);
   };
   MT3_PROF_MARK(5);
-  // ---- epilogue: C fragment (i, j): rows (lane>>4)*4 + r, col lane & 15
-  // 2-byte outputs are never stored one element at a time (a sub-dword store costs a read-modify-write in the
-  // cache: the bf16 STORE epilogue of a decode GEMM took 2.5 us against 0.7 us for the f32 RESID one): lanes l
-  // and l^1 hold adjacent columns, so they swap over DPP and the even lane stores rows r = 0, 1, the odd lane
-  // rows r = 2, 3 of the pair as whole dwords.
-  constexpr bool PAIRED = sizeof(CT) == 2 && (EPI == MT3_EPI_STORE || EPI == MT3_EPI_GEGLU || EPI == MT3_EPI_HEADS);
-  if constexpr (PAIRED) {
-    const int odd = frag_row & 1;
+  const EpiCtx ec{gO, gAux, gM, gN, gLdo, gSeq, gOutCt, gOutSs};
+  gemm_epilogue<CT, EPI, FM, FN>(acc, wm, wn, lane, m0, n0, ec, row_rs);
+  MT3_PROF_MARK(4);
+}
+
+// ------------------------------------------------------------------ encoder-sized tile, LDS-DMA staged (bf16)
+// 128x128x32 tile, 2x2 waves of 64x64 (4x4 MFMA fragments), both operands bf16 in memory.  The encoder GEMMs have
+// SHORT K (384 .. 1024) and operands that come from L2 / MALL at 1-2 us: with one K slice of look-ahead (the
+// register-staged tile, and this kernel's first form) every K step costs a full memory latency and the matrix pipe
+// idles 80 % of the time (measured: 27 us per 128x128x512 tile against 1.7 us of MFMA work).  So the staging is an
+// LDS-DMA RING: `global_load_lds_dwordx4` moves 64 lanes x 16 B = 16 tile rows x 64 B straight into LDS (no staging
+// VGPRs, no ds_write pass), 4 stages of 16 KB, THREE K slices in flight per workgroup, counted `s_waitcnt vmcnt(N)`
+// (never 0 in steady state) and a raw `s_barrier` so that the DMAs stay in flight across the barrier; two
+// workgroups per CU overlap one's prologue / epilogue with the other's K loop.
+// A DMA's LDS image is lane-linear, so rows cannot be padded; bank conflicts are removed by an XOR swizzle applied on
+// the SOURCE side: lane (row r, slot c) of a DMA fetches global chunk c ^ ((r >> 2) & 3) of its row, and a fragment
+// read of logical chunk q of row r looks at slot q ^ ((r >> 2) & 3) -- the 16 rows of a ds_read_b128 lane group
+// then cover all 16 sixteen-byte bank slots.  The fused RMSNorm comes from the producer's partial sums of squares
+// (norm 2), folded after the K loop.
+template <int EPI, int NPV>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
+  using CT = __bf16;
+  constexpr int BM = 128, BN = 128, BK = 32, FM = 4, FN = 4;
+  constexpr int ROWB = BK * 2;                       // 64 bytes per tile row (4 chunks)
+  constexpr int STAGE_B = (BM + BN) * ROWB;          // 16 KB per stage: A rows, then W rows
+  constexpr int NS = 4, DEPTH = 3;                   // ring stages / K slices in flight
+  constexpr int PPW = 4;                             // 1 KB pieces (16 rows) per wave per stage
+  // ONE shared object (a second one makes hipcc drain the DMA queue before every k-step's first ds_read)
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE_B + BM * 4];
+  float* const rs_x = reinterpret_cast<float*>(smem + NS * STAGE_B);
+
+  const void* const gA = g.A;
+  const void* const gW = g.Wt;
+  const int gM = g.M, gN = g.N, gK = g.K, gLda = g.lda;
+  const float* const gAss = g.a_ss;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = gN / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+
+  // norm 2: request this thread's tile row's partial sums now, fold them after the K loop
+  // (unconditional loads from always-valid addresses: a per-element "load or zero" select makes hipcc branch around
+  // every load and wait for each one)
+  float4 pv[NPV];
+  const bool scale_rows = gAss != nullptr && tid < BM;
+  const int npv = gAss ? (gK >> 6) : 1;
+  {
+    const int prow = m0 + (tid & (BM - 1)) < gM ? m0 + (tid & (BM - 1)) : gM - 1;
+    const float4* p4 = gAss ? reinterpret_cast<const float4*>(gAss + static_cast<size_t>(prow) * (gK >> 4))
+                            : reinterpret_cast<const float4*>(gW);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int lrow0 = wm * FM * 16 + i * 16 + frag_g * 4;
+    for (int u = 0; u < NPV; ++u) pv[u] = p4[u < npv ? u : npv - 1];
+  }
+
+  // ---- DMA plan: a stage is 16 one-KB pieces (8 of A, 8 of W).  Waves 0,1 bring A rows 0-63 / 64-127, waves 2,3
+  // W rows 0-63 / 64-127, 4 pieces each; lane i of a piece: row = 16 * piece + (i >> 2), slot = i & 3.
+  const bool is_a = wave < 2;
+  const int half = wave & 1;
+  const unsigned char* src[PPW];
 #pragma unroll
-      for (int j = 0; j < FN; j += (EPI == MT3_EPI_GEGLU ? 2 : 1)) {
-        float mine[4], other[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float rs = row_rs(lrow0 + r);
-          if constexpr (EPI == MT3_EPI_GEGLU) mine[r] = gelu_tanh(acc[i][j][r] * rs) * (acc[i][j + 1][r] * rs);
-          else mine[r] = acc[i][j][r] * rs;
-          other[r] = lane_xor1(mine[r]);
-        }
-        // logical output column of this lane's element, and of the pair's even element
-        const int col = EPI == MT3_EPI_GEGLU ? ((n0 + wn * FN * 16 + j * 16) >> 1) + frag_row
-                                             : n0 + wn * FN * 16 + j * 16 + frag_row;
-        const int col_even = col - odd;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int r = odd * 2 + h;
-          const int row = m0 + lrow0 + r;
-          if (row >= gM) continue;
-          // (selects, not mine[r]: a runtime index would put the arrays in scratch memory)
-          const float lo = odd ? other[2 + h] : mine[h], hi = odd ? mine[2 + h] : other[h];
-          const unsigned pair = pack_bf16x2(lo, hi);
-          size_t dst;
-          if constexpr (EPI == MT3_EPI_HEADS) {   // col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
-            const int hd = gN >> 1;               // H * 64
-            const int kv = col_even / hd, hh = (col_even % hd) >> 6, d = col_even & 63;
-            const int bb = row / gSeq, t = row % gSeq, H = hd >> 6, B = gM / gSeq;
-            dst = ((((static_cast<size_t>(kv) * B + bb) * H + hh) * gSeq) + t) * 64 + d;
-          } else {
-            dst = static_cast<size_t>(row) * gLdo + col_even;
-          }
-          *reinterpret_cast<unsigned*>(static_cast<CT*>(gO) + dst) = pair;
-        }
-      }
+  for (int j = 0; j < PPW; ++j) {
+    const int r = half * 64 + j * 16 + (lane >> 2);                      // row inside the operand tile
+    const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+    if (is_a) {
+      int row = m0 + r;
+      row = row < gM ? row : gM - 1;                                     // clamp: such rows are never stored
+      src[j] = static_cast<const unsigned char*>(gA) + (static_cast<size_t>(row) * gLda + chunk * 8) * 2;
+    } else {
+      src[j] = static_cast<const unsigned char*>(gW) + (static_cast<size_t>(n0 + r) * gK + chunk * 8) * 2;
     }
-  } else if constexpr (EPI == MT3_EPI_RESID && sizeof(CT) == 2) {
-    // residual update; on request also the compute-type copy of the new rows (dword stores of column pairs) and
-    // the sum of squares of each row over this fragment's 16 columns (exact f32, reduced on the DPP row)
-    const int odd = frag_row & 1;
+  }
+  const int piece0 = (is_a ? 0 : 8) + half * 4;
+  auto issue = [&](int kt, int stage) {
+    const int dst0 = __builtin_amdgcn_readfirstlane(stage * STAGE_B + piece0 * 1024);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int lrow0 = wm * FM * 16 + i * 16 + frag_g * 4;
+    for (int j = 0; j < PPW; ++j)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src[j] + static_cast<size_t>(kt) * ROWB),   // C-style: the
+          (__attribute__((address_space(3))) void*)(smem + dst0 + j * 1024), 16, 0, 0);               // only legal cast
+  };
+
+  f32x4 acc[FM][FN];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int col = n0 + wn * FN * 16 + j * 16 + frag_row;
-        float vnew[4], other[4], part[4];
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = m0 + lrow0 + r;
-          const size_t at = static_cast<size_t>(row < gM ? row : gM - 1) * gLdo + col;
-          vnew[r] = static_cast<float*>(gO)[at] + acc[i][j][r];
-          if (row < gM) static_cast<float*>(gO)[at] = vnew[r];
-        }
-        if (gOutCt) {
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frag_row = lane & 15, frag_g = lane >> 4;
+  // byte offsets of this lane's fragment pieces inside a stage: logical chunk frag_g of row frag_row (+ 16 i)
+  const int so = (frag_g ^ ((frag_row >> 2) & 3)) * 16;
+  const int a_off = (wm * 64 + frag_row) * ROWB + so, b_off = BM * ROWB + (wn * 64 + frag_row) * ROWB + so;
+
+  const int KT = gK / BK;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            other[r] = lane_xor1(vnew[r]);
-            part[r] = row16_sum(vnew[r] * vnew[r]);
-          }
+  for (int d = 0; d < DEPTH; ++d)
+    if (d < KT) issue(d, d);
+  for (int t = 0; t < KT; ++t) {
+    // slice t has landed once at most the (<= DEPTH - 1) younger slices' DMAs of this wave are still outstanding
+    const int ahead = KT - 1 - t < DEPTH - 1 ? KT - 1 - t : DEPTH - 1;
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // raw barrier (no fence: a __syncthreads() here would drain the DMA queue): after it every wave's pieces of
+    // slice t are in LDS, and nobody reads stage (t - 1) % NS any more -- the stage slice t + DEPTH goes to
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (t + DEPTH < KT) issue(t + DEPTH, (t + DEPTH) % NS);
+    const unsigned char* st = smem + (t % NS) * STAGE_B;
+    u32x4 af[FM], bf[FN];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = m0 + lrow0 + r;
-            if (frag_row == 0 && row < gM)
-              gOutSs[static_cast<size_t>(row) * (gN >> 4) + ((n0 + wn * FN * 16 + j * 16) >> 4)] = part[r];
-          }
+    for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(st + a_off + i * 16 * ROWB);
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int row = m0 + lrow0 + odd * 2 + h;
-            if (row >= gM) continue;
-            const float lo = odd ? other[2 + h] : vnew[h], hi = odd ? vnew[2 + h] : other[h];
-            *reinterpret_cast<unsigned*>(static_cast<CT*>(gOutCt) + static_cast<size_t>(row) * gLdo + col - odd) =
-                pack_bf16x2(lo, hi);
-          }
-        }
-      }
+    for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(st + b_off + j * 16 * ROWB);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) mfma_chunk<CT>(af[i], bf[j], acc[i][j]);
+  }
+  if (scale_rows) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) {
+      const float4 v = u < npv ? pv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      t = (((t + v.x) + v.y) + v.z) + v.w;                                                  // fixed order per row
     }
-  } else {
+    rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);
+  }
+  // ---- epilogue through LDS.  The C fragments (lane = 4 rows x 1 column) would reach memory as 32/64-byte pieces
+  // of many rows per instruction; the short-K encoder GEMMs move about as many output as operand bytes, so the tile
+  // is first transposed through the (now idle) ring: f32 [128][128], 16-float blocks of a row XOR-permuted by
+  // (row >> 2) & 3 so that the four lane groups of a fragment write hit disjoint banks; then every thread walks rows
+  // with float4s -- a wave instruction covers two whole 512-byte tile rows.
+  __syncthreads();                       // everyone is done with the ring (and rs_x is visible)
+  float* const tile = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int lrow = wm * FM * 16 + i * 16 + frag_g * 4 + r;
-        const int row = m0 + lrow;
-        if (row >= gM) continue;
-        const float rs = row_rs(lrow);
-        if constexpr (EPI == MT3_EPI_GEGLU) {
-          CT* out = static_cast<CT*>(gO);
+        const int row = wm * 64 + i * 16 + frag_g * 4 + r;          // (row >> 2) & 3 == frag_g
+        const int col = (wn * 64 + j * 16 + frag_row) ^ (frag_g << 4);
+        tile[row * BN + col] = acc[i][j][r];
+      }
+  __syncthreads();
+  const bool has_rs = gAss != nullptr;
+  auto tile4 = [&](int row, int col) -> float4 {                   // logical (row, col .. col + 3), col % 4 == 0
+    return *reinterpret_cast<const float4*>(&tile[row * BN + (col ^ (((row >> 2) & 3) << 4))]);
+  };
+  if constexpr (EPI == MT3_EPI_GEGLU) {
+    // tile columns [32q, 32q + 16) = gate, [32q + 16, 32q + 32) = linear of hidden units (n0 >> 1) + 16q + 0..15
+    CT* const out = static_cast<CT*>(g.out);
+    const int ldo = g.ldo, u4 = (tid & 15) * 4, q = u4 >> 4, s4 = u4 & 15;
 #pragma unroll
-          for (int j = 0; j < FN; j += 2) {
-            const int col = n0 + wn * FN * 16 + j * 16;                  // multiple of 32
-            const float gate = acc[i][j][r] * rs, lin = acc[i][j + 1][r] * rs;
-            out[static_cast<size_t>(row) * gLdo + (col >> 1) + frag_row] = to_ct<CT>(gelu_tanh(gate) * lin);
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < FN; ++j) {
-            const int col = n0 + wn * FN * 16 + j * 16 + frag_row;
-            const float v = acc[i][j][r] * rs;
-            if constexpr (EPI == MT3_EPI_STORE) {
-              static_cast<CT*>(gO)[static_cast<size_t>(row) * gLdo + col] = to_ct<CT>(v);
-            } else if constexpr (EPI == MT3_EPI_RESID) {
-              float* o = static_cast<float*>(gO) + static_cast<size_t>(row) * gLdo + col;
-              *o = *o + v;
-            } else if constexpr (EPI == MT3_EPI_POS) {
-              static_cast<float*>(gO)[static_cast<size_t>(row) * gLdo + col] =
-                  v + gAux[static_cast<size_t>(row % gSeq) * gN + col];
-            } else if constexpr (EPI == MT3_EPI_F32) {
-              static_cast<float*>(gO)[static_cast<size_t>(row) * gLdo + col] = v;
-            } else {  // MT3_EPI_HEADS: col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
-              const int hd = gN >> 1;                       // H * 64
-              const int kv = col / hd, h = (col % hd) >> 6, d = col & 63;
-              const int b = row / gSeq, t = row % gSeq, H = hd >> 6, B = gM / gSeq;
-              const size_t dst = ((((static_cast<size_t>(kv) * B + b) * H + h) * gSeq) + t) * 64 + d;
-              static_cast<CT*>(gO)[dst] = to_ct<CT>(v);
-            }
-          }
+    for (int p = 0; p < 8; ++p) {
+      const int row = (tid >> 4) + 16 * p;
+      if (m0 + row >= gM) continue;
+      const float rs = has_rs ? rs_x[row] : 1.f;
+      const float4 ga = tile4(row, 32 * q + s4), li = tile4(row, 32 * q + 16 + s4);
+      uint2 pk;
+      pk.x = pack_bf16x2(gelu_tanh(ga.x * rs) * (li.x * rs), gelu_tanh(ga.y * rs) * (li.y * rs));
+      pk.y = pack_bf16x2(gelu_tanh(ga.z * rs) * (li.z * rs), gelu_tanh(ga.w * rs) * (li.w * rs));
+      *reinterpret_cast<uint2*>(out + static_cast<size_t>(m0 + row) * ldo + (n0 >> 1) + u4) = pk;
+    }
+  } else {
+    const int c4 = (tid & 31) * 4;
+#pragma unroll 4
+    for (int p = 0; p < 16; ++p) {
+      const int row = (tid >> 5) + 8 * p;
+      const int grow = m0 + row;
+      if (grow >= gM) continue;                                     // (whole half-waves: the quad reductions below stay intact)
+      const float rs = has_rs ? rs_x[row] : 1.f;
+      float4 v = tile4(row, c4);
+      v.x *= rs, v.y *= rs, v.z *= rs, v.w *= rs;
+      const int col = n0 + c4;
+      if constexpr (EPI == MT3_EPI_RESID) {
+        float4* xp = reinterpret_cast<float4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col);
+        const float4 x = *xp;
+        v.x += x.x, v.y += x.y, v.z += x.z, v.w += x.w;
+        *xp = v;
+        if (g.out_ct) {
+          float t = __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
+          t = quad_sum(t);                                          // the 4 lanes of a quad hold one 16-column group
+          if ((tid & 3) == 0) g.out_ss[static_cast<size_t>(grow) * (gN >> 4) + (col >> 4)] = t;
+          uint2 pk;
+          pk.x = pack_bf16x2(v.x, v.y);
+          pk.y = pack_bf16x2(v.z, v.w);
+          *reinterpret_cast<uint2*>(static_cast<CT*>(g.out_ct) + static_cast<size_t>(grow) * g.ldo + col) = pk;
         }
+      } else if constexpr (EPI == MT3_EPI_F32) {
+        *reinterpret_cast<float4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col) = v;
+      } else {
+        uint2 pk;
+        pk.x = pack_bf16x2(v.x, v.y);
+        pk.y = pack_bf16x2(v.z, v.w);
+        size_t dst;
+        if constexpr (EPI == MT3_EPI_HEADS) {   // col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
+          const int hd = gN >> 1, seq = g.seq_len;
+          const int kv = col / hd, hh = (col % hd) >> 6, d = col & 63;
+          const int bb = grow / seq, tt = grow % seq, H = hd >> 6, B = gM / seq;
+          dst = ((((static_cast<size_t>(kv) * B + bb) * H + hh) * seq) + tt) * 64 + d;
+        } else {
+          dst = static_cast<size_t>(grow) * g.ldo + col;
+        }
+        *reinterpret_cast<uint2*>(static_cast<CT*>(g.out) + dst) = pk;
       }
     }
   }
-  MT3_PROF_MARK(4);
+}
+
+template <int EPI>
+static int launch_glds(const GemmArgs& g, hipStream_t s) {
+  const int grid = ((g.M + 127) / 128) * (g.N / 128);
+  if (g.a_ss && g.K > 512)
+    hipLaunchKernelGGL((gemm_glds_kernel<EPI, 16>), dim3(grid), dim3(256), 0, s, g);
+  else
+    hipLaunchKernelGGL((gemm_glds_kernel<EPI, 8>), dim3(grid), dim3(256), 0, s, g);
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+// big tile, bf16, both operands bf16 in memory, K a multiple of 64 (<= 1024 with norm 2), N of 128
+static bool glds_eligible(const GemmArgs& g, bool a_f32, int norm, int epi) {
+  static const bool off = getenv("MT3_NO_GLDS") != nullptr;
+  if (off || a_f32 || norm == 1 || g.K % 64 || g.N % 128 || g.lda % 8) return false;   // (K % 64: norm-2 partials)
+  if (norm == 2 && (!g.a_ss || g.K > 1024)) return false;
+  return epi == MT3_EPI_STORE || epi == MT3_EPI_RESID || epi == MT3_EPI_GEGLU || epi == MT3_EPI_HEADS ||
+         epi == MT3_EPI_F32;
 }
 
 // ------------------------------------------------------------------ dispatch
@@ -468,12 +713,45 @@ int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, int norm, int epi, boo
   if (epi == MT3_EPI_POS && (!g.aux || g.seq_len <= 0)) return mt3::fail(MT3_ERR_INVALID, "gemm: POS needs aux/seq_len");
   if (epi == MT3_EPI_HEADS && (g.seq_len <= 0 || g.M % g.seq_len != 0 || g.N % 128 != 0))
     return mt3::fail(MT3_ERR_INVALID, "gemm: HEADS needs M = B*T and N = 2*H*64");
+  if (dtype == MT3_BF16 && !small && glds_eligible(g, a_f32, norm, epi)) {
+    switch (epi) {
+      case MT3_EPI_STORE: return launch_glds<MT3_EPI_STORE>(g, s);
+      case MT3_EPI_RESID: return launch_glds<MT3_EPI_RESID>(g, s);
+      case MT3_EPI_GEGLU: return launch_glds<MT3_EPI_GEGLU>(g, s);
+      case MT3_EPI_HEADS: return launch_glds<MT3_EPI_HEADS>(g, s);
+      default: return launch_glds<MT3_EPI_F32>(g, s);
+    }
+  }
   if (dtype == MT3_BF16) return launch_typed<__bf16>(g, a_f32, norm, epi, small, s);
   if (dtype == MT3_F32) return launch_typed<float>(g, a_f32, norm, epi, small, s);
   return mt3::fail(MT3_ERR_INVALID, "gemm: unknown dtype");
 }
 
 }  // namespace mt3k
+
+extern "C" int mt3_op_gemm_ex(int32_t dtype, const void* d_A, int32_t a_is_f32, int32_t norm, const void* d_Wt,
+                              void* d_out, int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* d_aux,
+                              int32_t seq_len, int32_t small, const float* d_a_ss, void* d_out_ct, float* d_out_ss,
+                              void* stream) {
+  if (norm < 0 || norm > 2) return mt3::fail(MT3_ERR_INVALID, "gemm: norm must be 0, 1 or 2");
+  mt3k::GemmArgs g{};
+  g.A = d_A;
+  g.Wt = d_Wt;
+  g.out = d_out;
+  g.aux = d_aux;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.lda = K;
+  g.ldo = epilogue == MT3_EPI_GEGLU ? N / 2 : N;
+  g.seq_len = seq_len;
+  g.a_ss = norm == 2 ? d_a_ss : nullptr;
+  g.out_ct = d_out_ct;
+  g.out_ss = d_out_ss;
+  if ((d_out_ct != nullptr) != (d_out_ss != nullptr))
+    return mt3::fail(MT3_ERR_INVALID, "gemm: out_ct and out_ss come together");
+  return mt3k::launch_gemm(dtype, g, a_is_f32 != 0, norm, epilogue, small != 0, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int mt3_op_gemm(int32_t dtype, const void* d_A, int32_t a_is_f32, int32_t norm, const void* d_Wt,
                            void* d_out, int32_t M, int32_t N, int32_t K, int32_t epilogue, const float* d_aux,

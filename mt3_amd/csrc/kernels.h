@@ -55,6 +55,8 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s);
 // out_ct[row] = x[row] * rsqrt(mean(x^2)+eps) * scale ; optional f32 copy
 int launch_rmsnorm(int dtype, const float* x, const float* scale, void* out_ct, float* out_f32, int rows, int dim,
                    hipStream_t s);
+// x f32 [rows][dim] -> bf16 copy + per-16-column sums of squares (the split residual form, see GemmArgs)
+int launch_residual_split(const float* x, void* x_ct, float* x_ss, int rows, int dim, hipStream_t s);
 // y[b] = table[tok[b]] + pos[step[b]]
 // y_ct / y_ss (both or neither): bf16 copy of the rows and their per-16-column sums of squares (see GemmArgs)
 int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, void* y_ct,

@@ -137,6 +137,92 @@ def test_gemm_pos_and_heads(dtype, small):
     assert rel_err(o2, r2) < (6e-3 if dtype == BF16 else 2e-5)
 
 
+# ---------------------------------------------------- split residual stream + LDS-DMA staged tile (bf16, encoder)
+def _split(x):
+    """f32 rows -> (bf16 copy, per-16-column sums of squares) through mt3_op_residual_split"""
+    M, K = x.shape
+    ct = torch.empty(M, K, device="cuda", dtype=torch.bfloat16)
+    ss = torch.empty(M, K // 16, device="cuda")
+    _lib.check(lib().mt3_op_residual_split(BF16, x.data_ptr(), ct.data_ptr(), ss.data_ptr(), M, K, stream()))
+    torch.cuda.synchronize()
+    return ct, ss
+
+
+def run_gemm_ex(A, norm, Wt, out, M, N, K, epi, seq_len=0, small=False, a_ss=None, out_ct=None, out_ss=None):
+    p = lambda t: t.data_ptr() if t is not None else None
+    _lib.check(lib().mt3_op_gemm_ex(BF16, A.data_ptr(), 0, norm, Wt.data_ptr(), out.data_ptr(), M, N, K, epi, None,
+                                    seq_len, int(small), p(a_ss), p(out_ct), p(out_ss), stream()))
+    torch.cuda.synchronize()
+
+
+def test_residual_split_exact():
+    g = torch.Generator(device="cuda").manual_seed(21)
+    x = torch.randn(300, 512, device="cuda", generator=g) * 3
+    ct, ss = _split(x)
+    assert torch.equal(ct, x.to(torch.bfloat16))
+    ref = (x.double() ** 2).view(300, 32, 16).sum(-1)
+    assert float(((ss.double() - ref).abs() / ref).max()) < 1e-6
+
+
+@pytest.mark.parametrize("small", [False, True])
+@pytest.mark.parametrize("M,N,K", [(4096, 1152, 512), (777, 512, 512), (256, 2304, 768), (130, 128, 64)])
+def test_gemm_norm2_store_from_split_rows(small, M, N, K):
+    """RMSNorm-fused GEMM fed by the split rows (bf16 copy + partial sums): big = the LDS-DMA staged tile."""
+    if small and K not in (512, 768):
+        pytest.skip("decode tiles take K = 512 / 768 with norm 2")
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn(M, K, device="cuda", generator=g) * torch.rand(M, 1, device="cuda", generator=g) * 4
+    Wt = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    ct, ss = _split(x)
+    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    run_gemm_ex(ct, 2, Wt, out, M, N, K, _lib.EPI_STORE, small=small, a_ss=ss)
+    rs = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-6)
+    ref = (ct.double() @ Wt.double().T) * rs
+    assert rel_err(out, ref) < 6e-3, rel_err(out, ref)
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 512, 384), (1000, 512, 1024), (640, 768, 2048)])
+def test_gemm_glds_resid_updates_the_split_stream(M, N, K):
+    g = torch.Generator(device="cuda").manual_seed(K)
+    A = torch.randn(M, K, device="cuda", generator=g).to(torch.bfloat16)
+    Wt = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    x = torch.randn(M, N, device="cuda", generator=g)
+    x0 = x.clone()
+    ct = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    ss = torch.zeros(M, N // 16, device="cuda")
+    run_gemm_ex(A, 0, Wt, x, M, N, K, _lib.EPI_RESID, out_ct=ct, out_ss=ss)
+    ref = x0.double() + A.double() @ Wt.double().T
+    assert rel_err(x, ref) < 2e-5
+    assert torch.equal(ct, x.to(torch.bfloat16))                       # the copy is the rounding of the f32 rows
+    ssr = (x.double() ** 2).view(M, N // 16, 16).sum(-1)
+    assert float(((ss.double() - ssr).abs() / ssr).max()) < 1e-5
+
+
+def test_gemm_glds_geglu_and_heads():
+    M, K, F = 1536, 512, 1024
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(M, K, device="cuda", generator=g) * 2
+    w0 = (torch.randn(K, F, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    w1 = (torch.randn(K, F, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    Wt = torch.empty(2 * F, K, device="cuda", dtype=torch.bfloat16)
+    Wt.view(F // 16, 2, 16, K)[:, 0] = w0.T.reshape(F // 16, 16, K)
+    Wt.view(F // 16, 2, 16, K)[:, 1] = w1.T.reshape(F // 16, 16, K)
+    ct, ss = _split(x)
+    rs = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-6)
+    ref = gelu_tanh((ct.double() @ w0.double()) * rs) * ((ct.double() @ w1.double()) * rs)
+    out = torch.zeros(M, F, device="cuda", dtype=torch.bfloat16)
+    run_gemm_ex(ct, 2, Wt, out, M, 2 * F, K, _lib.EPI_GEGLU, a_ss=ss)
+    assert rel_err(out, ref) < 8e-3, rel_err(out, ref)
+    # HEADS: N = 2*H*64 -> [2][B][H][T][64]
+    B, T, H = 3, 256, 6
+    A = torch.randn(B * T, K, device="cuda", generator=g).to(torch.bfloat16)
+    W2 = (torch.randn(2 * H * 64, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    o2 = torch.zeros(2, B, H, T, 64, device="cuda", dtype=torch.bfloat16)
+    run_gemm_ex(A, 0, W2, o2, B * T, 2 * H * 64, K, _lib.EPI_HEADS, seq_len=T)
+    r2 = (A.double() @ W2.double().T).view(B, T, 2, H, 64).permute(2, 0, 3, 1, 4)
+    assert rel_err(o2, r2) < 6e-3
+
+
 # ------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dtype,T", [(BF16, 256), (BF16, 512), (F32, 256), (F32, 512)])
 def test_encoder_attention(dtype, T):
