@@ -6,7 +6,7 @@ import numpy as np
 CFG = dict(vocab_size=128, emb_dim=128, num_heads=2, head_dim=64, mlp_dim=128, num_encoder_layers=2,
            num_decoder_layers=2)
 INPUT_DEPTH, T, L, B, SEED = 64, 256, 24, 6, 11   # T = 256: the product engine can run it too
-EOS_BOOST = 1.6          # flattens the logits and lifts EOS so that beam search finishes rows at different lengths
+EOS_BOOST = 1.3          # flattens the logits and lifts EOS so that beam search finishes rows at different lengths
 
 
 def param_shapes():
