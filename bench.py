@@ -42,13 +42,13 @@ FRONTEND_BYTES_PER_SEGMENT = 655360        # 131072 in + 524288 out
 
 
 def kernel_source_hash():
-    """Identity of the kernels a PMC file was collected from: sha256 over the device sources."""
+    """Identity of the kernel a PMC file was collected from: sha256 over the sources the decode-attention kernels
+    are compiled from (a change to any of them invalidates a committed traffic ratio)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mt3_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            with open(os.path.join(d, f), "rb") as fh:
-                h.update(f.encode() + b"\0" + fh.read())
+    for f in ("attention.hip", "device.h", "kernels.h"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 
