@@ -736,13 +736,15 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
     return (n == 2 || n == 3 || n == 4) ? n : 3;
   }();
   if (a.kv_scale) {
-    // 128 VGPRs -> 4 waves per SIMD: two-wave workgroups keep all B*H = 1536 groups co-resident (8 per CU)
-    static const int nw8 = [] {
+    // waves per (row, head) workgroup, measured on MI355X at B = 256 (tools/gpu_fp8.sh): the growing self-attention
+    // cache streams best with 3 (22.8 us against 23.7 / 24.0 with 2 / 4 at the mean depth); the fixed 256-key
+    // cross-attention with 4 (one whole 64-key x 4 pass per wave: 12.4 us against 13.4 with 3)
+    static const int nw_env = [] {
       const char* v = getenv("MT3_DEC_ATTN_FP8_WAVES");
-      const int n = v ? atoi(v) : 2;
-      return (n == 2 || n == 3 || n == 4) ? n : 2;
+      const int n = v ? atoi(v) : 0;
+      return (n == 2 || n == 3 || n == 4) ? n : 0;
     }();
-    const int nw = nw8;
+    const int nw = nw_env ? nw_env : (append ? 3 : 4);
     const dim3 grid(a.B * a.H), block(nw * 64);
     // fp8 (e4m3) K/V cache; activations (q, new rows, out) are bf16
     if (dtype != MT3_BF16) return mt3::fail(MT3_ERR_INVALID, "decode_attention: the fp8 K/V cache needs bf16 activations");
