@@ -462,13 +462,12 @@ def main():
                         "decode steps (no early exit), one RCCL all-gather of the token rows per pass, host note "
                         "decoding included" % (corpus, world, n_local, B, args.decoding, args.decode_steps))
         else:
-            workload = ("BASELINE configs[2]: MT3 (model.gin) random-init, full encoder-decoder %s "
-                        if args.model == "mt3" else
-                        "BASELINE configs[4] shape: ismir2022/base.gin random-init, full encoder-decoder %s "
-                        "decode, batch=%d synthetic 2.048 s segments per GPU, %d decode steps (no early "
-                        "exit), hipGraph step replay, ids->tokens + host note decoding included"
-                        % ("greedy" if args.decoding == "greedy" else "beam-1 (t5x beam_search, one beam)",
-                           B, args.decode_steps))
+            head = ("BASELINE configs[2]: MT3 (model.gin) random-init" if args.model == "mt3" else
+                    "BASELINE configs[4] shape: ismir2022/base.gin random-init")
+            workload = ("%s, full encoder-decoder %s decode, batch=%d synthetic 2.048 s segments per GPU, %d decode "
+                        "steps (no early exit), hipGraph step replay, ids->tokens + host note decoding included%s"
+                        % (head, "greedy" if args.decoding == "greedy" else "beam-1 (t5x beam_search, one beam)",
+                           B, args.decode_steps, ", e4m3 K/V caches" if args.kv_dtype else ""))
         out = {
             "metric": "audio-seconds transcribed/sec (whole node), MT3-base, 1/2/4/8 MI355X",
             "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
