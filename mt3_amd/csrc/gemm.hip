@@ -33,6 +33,14 @@
 #ifndef MT3_PROF_MARK
 #define MT3_PROF_MARK(i)
 #endif
+// tools/micro/glds_probe.hip builds the LDS-DMA tile with parts left out to see what bounds it (0 in the product):
+// 1 = no fragment reads / MFMAs, 2 = no DMA after the prologue's DEPTH slices, 4 = no epilogue
+#ifndef MT3_GLDS_PROBE
+#define MT3_GLDS_PROBE 0
+#endif
+#ifndef MT3_GLDS_NS
+#define MT3_GLDS_NS 3      // ring stages of the LDS-DMA tile (3: 48.5 KB of LDS, three workgroups per CU; 4: two)
+#endif
 
 namespace mt3k {
 
@@ -130,7 +138,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float rs = row_rs(lrow0 + r);
-          if constexpr (EPI == MT3_EPI_GEGLU) mine[r] = gelu_tanh(acc[i][j][r] * rs) * (acc[i][j + 1][r] * rs);
+          if constexpr (EPI == MT3_EPI_GEGLU) mine[r] = gelu_tanh_fast(acc[i][j][r] * rs) * (acc[i][j + 1][r] * rs);   // (bf16 out)
           else mine[r] = acc[i][j][r] * rs;
           other[r] = lane_xor1(mine[r]);
         }
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   constexpr int BM = 128, BN = 128, BK = 32, FM = 4, FN = 4;
   constexpr int ROWB = BK * 2;                       // 64 bytes per tile row (4 chunks)
   constexpr int STAGE_B = (BM + BN) * ROWB;          // 16 KB per stage: A rows, then W rows
-  constexpr int NS = 4, DEPTH = 3;                   // ring stages / K slices in flight
+  constexpr int NS = MT3_GLDS_NS, DEPTH = NS - 1;    // ring stages / K slices in flight
   constexpr int PPW = 4;                             // 1 KB pieces (16 rows) per wave per stage
   // ONE shared object (a second one makes hipcc drain the DMA queue before every k-step's first ds_read)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE_B + BM * 4];
@@ -487,14 +495,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   for (int t = 0; t < KT; ++t) {
     // slice t has landed once at most the (<= DEPTH - 1) younger slices' DMAs of this wave are still outstanding
     const int ahead = KT - 1 - t < DEPTH - 1 ? KT - 1 - t : DEPTH - 1;
-    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (DEPTH > 2 && ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // raw barrier (no fence: a __syncthreads() here would drain the DMA queue): after it every wave's pieces of
     // slice t are in LDS, and nobody reads stage (t - 1) % NS any more -- the stage slice t + DEPTH goes to
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (t + DEPTH < KT) issue(t + DEPTH, (t + DEPTH) % NS);
+    if (!(MT3_GLDS_PROBE & 2) && t + DEPTH < KT) issue(t + DEPTH, (t + DEPTH) % NS);
+    if (MT3_GLDS_PROBE & 1) continue;
     const unsigned char* st = smem + (t % NS) * STAGE_B;
     u32x4 af[FM], bf[FN];
 #pragma unroll
@@ -515,84 +524,92 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     }
     rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);
   }
+  if ((MT3_GLDS_PROBE & 4) && gM > 0) return;
   // ---- epilogue through LDS.  The C fragments (lane = 4 rows x 1 column) would reach memory as 32/64-byte pieces
   // of many rows per instruction; the short-K encoder GEMMs move about as many output as operand bytes, so the tile
-  // is first transposed through the (now idle) ring: f32 [128][128], 16-float blocks of a row XOR-permuted by
-  // (row >> 2) & 3 so that the four lane groups of a fragment write hit disjoint banks; then every thread walks rows
-  // with float4s -- a wave instruction covers two whole 512-byte tile rows.
-  __syncthreads();                       // everyone is done with the ring (and rs_x is visible)
+  // is first transposed through the (now idle) ring, 64 rows at a time (a [64][128] f32 image = 32 KB, the rows of
+  // the wave pair wm = 0, then wm = 1): 16-float blocks of a row are XOR-permuted by (row >> 2) & 3 so that the four
+  // lane groups of a fragment write hit disjoint banks; then every thread walks rows with float4s -- a wave
+  // instruction covers two whole 512-byte tile rows.
   float* const tile = reinterpret_cast<float*>(smem);
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = wm * 64 + i * 16 + frag_g * 4 + r;          // (row >> 2) & 3 == frag_g
-        const int col = (wn * 64 + j * 16 + frag_row) ^ (frag_g << 4);
-        tile[row * BN + col] = acc[i][j][r];
-      }
-  __syncthreads();
   const bool has_rs = gAss != nullptr;
-  auto tile4 = [&](int row, int col) -> float4 {                   // logical (row, col .. col + 3), col % 4 == 0
+  auto tile4 = [&](int row, int col) -> float4 {                   // logical (half-local row, col .. col + 3), col % 4 == 0
     return *reinterpret_cast<const float4*>(&tile[row * BN + (col ^ (((row >> 2) & 3) << 4))]);
   };
-  if constexpr (EPI == MT3_EPI_GEGLU) {
-    // tile columns [32q, 32q + 16) = gate, [32q + 16, 32q + 32) = linear of hidden units (n0 >> 1) + 16q + 0..15
-    CT* const out = static_cast<CT*>(g.out);
-    const int ldo = g.ldo, u4 = (tid & 15) * 4, q = u4 >> 4, s4 = u4 & 15;
+#pragma unroll 1
+  for (int hm = 0; hm < 2; ++hm) {
+    __syncthreads();                     // the ring / the previous half's image is no longer read (rs_x is visible)
+    if (wm == hm) {
 #pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const int row = (tid >> 4) + 16 * p;
-      if (m0 + row >= gM) continue;
-      const float rs = has_rs ? rs_x[row] : 1.f;
-      const float4 ga = tile4(row, 32 * q + s4), li = tile4(row, 32 * q + 16 + s4);
-      uint2 pk;
-      pk.x = pack_bf16x2(gelu_tanh(ga.x * rs) * (li.x * rs), gelu_tanh(ga.y * rs) * (li.y * rs));
-      pk.y = pack_bf16x2(gelu_tanh(ga.z * rs) * (li.z * rs), gelu_tanh(ga.w * rs) * (li.w * rs));
-      *reinterpret_cast<uint2*>(out + static_cast<size_t>(m0 + row) * ldo + (n0 >> 1) + u4) = pk;
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = i * 16 + frag_g * 4 + r;                // (row >> 2) & 3 == frag_g
+            const int col = (wn * 64 + j * 16 + frag_row) ^ (frag_g << 4);
+            tile[row * BN + col] = acc[i][j][r];
+          }
     }
-  } else {
-    const int c4 = (tid & 31) * 4;
+    __syncthreads();
+    const int mh = m0 + hm * 64;                                     // first global row of this half
+    if constexpr (EPI == MT3_EPI_GEGLU) {
+      // tile columns [32q, 32q + 16) = gate, [32q + 16, 32q + 32) = linear of hidden units (n0 >> 1) + 16q + 0..15
+      CT* const out = static_cast<CT*>(g.out);
+      const int ldo = g.ldo, u4 = (tid & 15) * 4, q = u4 >> 4, s4 = u4 & 15;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int row = (tid >> 4) + 16 * p;
+        if (mh + row >= gM) continue;
+        const float rs = has_rs ? rs_x[hm * 64 + row] : 1.f;
+        const float4 ga = tile4(row, 32 * q + s4), li = tile4(row, 32 * q + 16 + s4);
+        uint2 pk;
+        pk.x = pack_bf16x2(gelu_tanh_fast(ga.x * rs) * (li.x * rs), gelu_tanh_fast(ga.y * rs) * (li.y * rs));
+        pk.y = pack_bf16x2(gelu_tanh_fast(ga.z * rs) * (li.z * rs), gelu_tanh_fast(ga.w * rs) * (li.w * rs));
+        *reinterpret_cast<uint2*>(out + static_cast<size_t>(mh + row) * ldo + (n0 >> 1) + u4) = pk;
+      }
+    } else {
+      const int c4 = (tid & 31) * 4;
 #pragma unroll 4
-    for (int p = 0; p < 16; ++p) {
-      const int row = (tid >> 5) + 8 * p;
-      const int grow = m0 + row;
-      if (grow >= gM) continue;                                     // (whole half-waves: the quad reductions below stay intact)
-      const float rs = has_rs ? rs_x[row] : 1.f;
-      float4 v = tile4(row, c4);
-      v.x *= rs, v.y *= rs, v.z *= rs, v.w *= rs;
-      const int col = n0 + c4;
-      if constexpr (EPI == MT3_EPI_RESID) {
-        float4* xp = reinterpret_cast<float4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col);
-        const float4 x = *xp;
-        v.x += x.x, v.y += x.y, v.z += x.z, v.w += x.w;
-        *xp = v;
-        if (g.out_ct) {
-          float t = __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
-          t = quad_sum(t);                                          // the 4 lanes of a quad hold one 16-column group
-          if ((tid & 3) == 0) g.out_ss[static_cast<size_t>(grow) * (gN >> 4) + (col >> 4)] = t;
+      for (int p = 0; p < 8; ++p) {
+        const int row = (tid >> 5) + 8 * p;
+        const int grow = mh + row;
+        if (grow >= gM) continue;                                   // (whole half-waves: the quad reductions below stay intact)
+        const float rs = has_rs ? rs_x[hm * 64 + row] : 1.f;
+        float4 v = tile4(row, c4);
+        v.x *= rs, v.y *= rs, v.z *= rs, v.w *= rs;
+        const int col = n0 + c4;
+        if constexpr (EPI == MT3_EPI_RESID) {
+          float4* xp = reinterpret_cast<float4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col);
+          const float4 x = *xp;
+          v.x += x.x, v.y += x.y, v.z += x.z, v.w += x.w;
+          *xp = v;
+          if (g.out_ct) {
+            float t = __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
+            t = quad_sum(t);                                        // the 4 lanes of a quad hold one 16-column group
+            if ((tid & 3) == 0) g.out_ss[static_cast<size_t>(grow) * (gN >> 4) + (col >> 4)] = t;
+            uint2 pk;
+            pk.x = pack_bf16x2(v.x, v.y);
+            pk.y = pack_bf16x2(v.z, v.w);
+            *reinterpret_cast<uint2*>(static_cast<CT*>(g.out_ct) + static_cast<size_t>(grow) * g.ldo + col) = pk;
+          }
+        } else if constexpr (EPI == MT3_EPI_F32) {
+          *reinterpret_cast<float4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col) = v;
+        } else {
           uint2 pk;
           pk.x = pack_bf16x2(v.x, v.y);
           pk.y = pack_bf16x2(v.z, v.w);
-          *reinterpret_cast<uint2*>(static_cast<CT*>(g.out_ct) + static_cast<size_t>(grow) * g.ldo + col) = pk;
+          size_t dst;
+          if constexpr (EPI == MT3_EPI_HEADS) {   // col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
+            const int hd = gN >> 1, seq = g.seq_len;
+            const int kv = col / hd, hh = (col % hd) >> 6, d = col & 63;
+            const int bb = grow / seq, tt = grow % seq, H = hd >> 6, B = gM / seq;
+            dst = ((((static_cast<size_t>(kv) * B + bb) * H + hh) * seq) + tt) * 64 + d;
+          } else {
+            dst = static_cast<size_t>(grow) * g.ldo + col;
+          }
+          *reinterpret_cast<uint2*>(static_cast<CT*>(g.out) + dst) = pk;
         }
-      } else if constexpr (EPI == MT3_EPI_F32) {
-        *reinterpret_cast<float4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col) = v;
-      } else {
-        uint2 pk;
-        pk.x = pack_bf16x2(v.x, v.y);
-        pk.y = pack_bf16x2(v.z, v.w);
-        size_t dst;
-        if constexpr (EPI == MT3_EPI_HEADS) {   // col = kv*H*64 + h*64 + d, row = b*T + t  ->  [kv][b][h][t][d]
-          const int hd = gN >> 1, seq = g.seq_len;
-          const int kv = col / hd, hh = (col % hd) >> 6, d = col & 63;
-          const int bb = grow / seq, tt = grow % seq, H = hd >> 6, B = gM / seq;
-          dst = ((((static_cast<size_t>(kv) * B + bb) * H + hh) * seq) + tt) * 64 + d;
-        } else {
-          dst = static_cast<size_t>(grow) * g.ldo + col;
-        }
-        *reinterpret_cast<uint2*>(static_cast<CT*>(g.out) + dst) = pk;
       }
     }
   }
