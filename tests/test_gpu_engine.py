@@ -225,9 +225,10 @@ def test_split_residual_stream_matches_the_single_f32_stream(setup, monkeypatch)
     # partial sum would instead shift EVERY row at the percent level.
     d = np.linalg.norm(a.astype(np.float64) - b, axis=1) / np.linalg.norm(b.astype(np.float64), axis=1)
     clean = d < 2e-6
-    assert clean.mean() >= 0.7, d
-    assert d.max() < 1e-2, d
-    assert np.median(d) < 2e-6
+    # (the 34 rows are copies of 3 segments, so flips come in groups: no fraction-of-rows bound; a wrong partial sum
+    # would put EVERY row above 1e-2, a flip stays near 2e-3, identical operands give < 2e-7)
+    assert clean.any(), d
+    assert d.max() < 6e-3, d
     assert np.array_equal(out["split"][0][clean], out["single"][0][clean])
 
 
