@@ -41,6 +41,16 @@
 #ifndef MT3_GLDS_NS
 #define MT3_GLDS_NS 3      // ring stages of the LDS-DMA tile (3: 48.5 KB of LDS, three workgroups per CU; 4: two)
 #endif
+// the tile's bf16 outputs are written once per GEMM by exactly one workgroup: streamed with non-temporal stores they do
+// not push the weight tiles and the shared A panels out of the XCD's 4 MB L2 (probe: a 268 MB STORE 222 -> 183 us)
+#ifndef MT3_GLDS_NO_NT
+#define MT3_GLDS_ST(v, p) __builtin_nontemporal_store((v), (p))
+#else
+#define MT3_GLDS_ST(v, p) (*(p) = (v))
+#endif
+#ifndef MT3_GLDS_BK
+#define MT3_GLDS_BK 32     // K slice of the LDS-DMA tile: 32 (64-byte row pieces) or 64 (whole 128-byte lines)
+#endif
 
 namespace mt3k {
 
@@ -416,11 +426,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
 template <int EPI, int NPV>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   using CT = __bf16;
-  constexpr int BM = 128, BN = 128, BK = 32, FM = 4, FN = 4;
-  constexpr int ROWB = BK * 2;                       // 64 bytes per tile row (4 chunks)
-  constexpr int STAGE_B = (BM + BN) * ROWB;          // 16 KB per stage: A rows, then W rows
+  constexpr int BM = 128, BN = 128, BK = MT3_GLDS_BK, FM = 4, FN = 4;
+  constexpr int ROWB = BK * 2;                       // bytes per tile row: 64 (4 chunks) or 128 (8 chunks)
+  constexpr int CPROW = ROWB / 16;                   // 16-byte chunks per row
+  constexpr int RPP = 64 / CPROW;                    // rows per 1 KB DMA piece: 16 or 8
+  constexpr int KSH = BK == 32 ? 2 : 1;              // swizzle key of row r: (r >> KSH) & (CPROW - 1)
+  constexpr int STAGE_B = (BM + BN) * ROWB;          // 16 / 32 KB per stage: A rows, then W rows
   constexpr int NS = MT3_GLDS_NS, DEPTH = NS - 1;    // ring stages / K slices in flight
-  constexpr int PPW = 4;                             // 1 KB pieces (16 rows) per wave per stage
+  constexpr int PPW = 64 / RPP;                      // 1 KB pieces per wave per stage: 4 or 8
+  static_assert(BK == 32 || BK == 64, "K slice");
   // ONE shared object (a second one makes hipcc drain the DMA queue before every k-step's first ds_read)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE_B + BM * 4];
   float* const rs_x = reinterpret_cast<float*>(smem + NS * STAGE_B);
@@ -450,15 +464,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     for (int u = 0; u < NPV; ++u) pv[u] = p4[u < npv ? u : npv - 1];
   }
 
-  // ---- DMA plan: a stage is 16 one-KB pieces (8 of A, 8 of W).  Waves 0,1 bring A rows 0-63 / 64-127, waves 2,3
-  // W rows 0-63 / 64-127, 4 pieces each; lane i of a piece: row = 16 * piece + (i >> 2), slot = i & 3.
+  // ---- DMA plan: a stage is 16 (32) one-KB pieces, half of A, half of W.  Waves 0,1 bring A rows 0-63 / 64-127,
+  // waves 2,3 W rows 0-63 / 64-127, PPW pieces each; lane i of a piece: row = RPP * piece + i / CPROW, slot = i % CPROW.
   const bool is_a = wave < 2;
   const int half = wave & 1;
   const unsigned char* src[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
-    const int r = half * 64 + j * 16 + (lane >> 2);                      // row inside the operand tile
-    const int chunk = (lane & 3) ^ ((r >> 2) & 3);
+    const int r = half * 64 + j * RPP + lane / CPROW;                    // row inside the operand tile
+    const int chunk = (lane % CPROW) ^ ((r >> KSH) & (CPROW - 1));
     if (is_a) {
       int row = m0 + r;
       row = row < gM ? row : gM - 1;                                     // clamp: such rows are never stored
@@ -467,7 +481,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
       src[j] = static_cast<const unsigned char*>(gW) + (static_cast<size_t>(n0 + r) * gK + chunk * 8) * 2;
     }
   }
-  const int piece0 = (is_a ? 0 : 8) + half * 4;
+  const int piece0 = (is_a ? 0 : 2 * PPW) + half * PPW;
   auto issue = [&](int kt, int stage) {
     const int dst0 = __builtin_amdgcn_readfirstlane(stage * STAGE_B + piece0 * 1024);
 #pragma unroll
@@ -484,9 +498,9 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int frag_row = lane & 15, frag_g = lane >> 4;
-  // byte offsets of this lane's fragment pieces inside a stage: logical chunk frag_g of row frag_row (+ 16 i)
-  const int so = (frag_g ^ ((frag_row >> 2) & 3)) * 16;
-  const int a_off = (wm * 64 + frag_row) * ROWB + so, b_off = BM * ROWB + (wn * 64 + frag_row) * ROWB + so;
+  // byte offsets of this lane's fragment pieces inside a stage: logical chunk 4 kk + frag_g of row frag_row (+ 16 i)
+  const int key = (frag_row >> KSH) & (CPROW - 1);
+  const int a_off = (wm * 64 + frag_row) * ROWB, b_off = BM * ROWB + (wn * 64 + frag_row) * ROWB;
 
   const int KT = gK / BK;
 #pragma unroll
@@ -495,9 +509,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   for (int t = 0; t < KT; ++t) {
     // slice t has landed once at most the (<= DEPTH - 1) younger slices' DMAs of this wave are still outstanding
     const int ahead = KT - 1 - t < DEPTH - 1 ? KT - 1 - t : DEPTH - 1;
-    if (DEPTH > 2 && ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (DEPTH > 2 && ahead >= 2) {
+      if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else if (DEPTH > 1 && ahead == 1) {
+      if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     // raw barrier (no fence: a __syncthreads() here would drain the DMA queue): after it every wave's pieces of
     // slice t are in LDS, and nobody reads stage (t - 1) % NS any more -- the stage slice t + DEPTH goes to
     __builtin_amdgcn_s_barrier();
@@ -505,15 +525,19 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     if (!(MT3_GLDS_PROBE & 2) && t + DEPTH < KT) issue(t + DEPTH, (t + DEPTH) % NS);
     if (MT3_GLDS_PROBE & 1) continue;
     const unsigned char* st = smem + (t % NS) * STAGE_B;
-    u32x4 af[FM], bf[FN];
 #pragma unroll
-    for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(st + a_off + i * 16 * ROWB);
+    for (int kk = 0; kk < BK / 32; ++kk) {
+      const int so = ((4 * kk + frag_g) ^ key) * 16;
+      u32x4 af[FM], bf[FN];
 #pragma unroll
-    for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(st + b_off + j * 16 * ROWB);
+      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(st + a_off + i * 16 * ROWB + so);
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+      for (int j = 0; j < FN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(st + b_off + j * 16 * ROWB + so);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) mfma_chunk<CT>(af[i], bf[j], acc[i][j]);
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) mfma_chunk<CT>(af[i], bf[j], acc[i][j]);
+    }
   }
   if (scale_rows) {
     float t = 0.f;
@@ -563,10 +587,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
         if (mh + row >= gM) continue;
         const float rs = has_rs ? rs_x[hm * 64 + row] : 1.f;
         const float4 ga = tile4(row, 32 * q + s4), li = tile4(row, 32 * q + 16 + s4);
-        uint2 pk;
+        u32x2 pk;
         pk.x = pack_bf16x2(gelu_tanh_fast(ga.x * rs) * (li.x * rs), gelu_tanh_fast(ga.y * rs) * (li.y * rs));
         pk.y = pack_bf16x2(gelu_tanh_fast(ga.z * rs) * (li.z * rs), gelu_tanh_fast(ga.w * rs) * (li.w * rs));
-        *reinterpret_cast<uint2*>(out + static_cast<size_t>(mh + row) * ldo + (n0 >> 1) + u4) = pk;
+        MT3_GLDS_ST(pk, reinterpret_cast<u32x2*>(out + static_cast<size_t>(mh + row) * ldo + (n0 >> 1) + u4));
       }
     } else {
       const int c4 = (tid & 31) * 4;
@@ -580,23 +604,24 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
         v.x *= rs, v.y *= rs, v.z *= rs, v.w *= rs;
         const int col = n0 + c4;
         if constexpr (EPI == MT3_EPI_RESID) {
-          float4* xp = reinterpret_cast<float4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col);
-          const float4 x = *xp;
+          f32x4* xp = reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col);
+          const f32x4 x = *xp;            // (plain accesses: non-temporal ones made the read-modify-write 10-20 % slower)
           v.x += x.x, v.y += x.y, v.z += x.z, v.w += x.w;
-          *xp = v;
+          *xp = f32x4{v.x, v.y, v.z, v.w};
           if (g.out_ct) {
             float t = __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
             t = quad_sum(t);                                        // the 4 lanes of a quad hold one 16-column group
             if ((tid & 3) == 0) g.out_ss[static_cast<size_t>(grow) * (gN >> 4) + (col >> 4)] = t;
-            uint2 pk;
+            u32x2 pk;
             pk.x = pack_bf16x2(v.x, v.y);
             pk.y = pack_bf16x2(v.z, v.w);
-            *reinterpret_cast<uint2*>(static_cast<CT*>(g.out_ct) + static_cast<size_t>(grow) * g.ldo + col) = pk;
+            *reinterpret_cast<u32x2*>(static_cast<CT*>(g.out_ct) + static_cast<size_t>(grow) * g.ldo + col) = pk;
           }
         } else if constexpr (EPI == MT3_EPI_F32) {
-          *reinterpret_cast<float4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col) = v;
+          MT3_GLDS_ST((f32x4{v.x, v.y, v.z, v.w}),
+                      reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col));
         } else {
-          uint2 pk;
+          u32x2 pk;
           pk.x = pack_bf16x2(v.x, v.y);
           pk.y = pack_bf16x2(v.z, v.w);
           size_t dst;
@@ -608,7 +633,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
           } else {
             dst = static_cast<size_t>(grow) * g.ldo + col;
           }
-          *reinterpret_cast<uint2*>(static_cast<CT*>(g.out) + dst) = pk;
+          MT3_GLDS_ST(pk, reinterpret_cast<u32x2*>(static_cast<CT*>(g.out) + dst));
         }
       }
     }
