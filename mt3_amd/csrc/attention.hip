@@ -98,18 +98,35 @@ __device__ __forceinline__ void enc_attn_chunk(const CT* Ks, const CT* Vt, int k
     for (int r = 0; r < 4; ++r) cm = fmaxf(cm, sc[j][r]);
   cm = fmaxf(cm, __shfl_xor(cm, 16));
   cm = fmaxf(cm, __shfl_xor(cm, 32));
-  const float mn = fmaxf(m, cm);
-  const float alpha = expf(m - mn);          // 0 on the first chunk
-  m = mn;
-  float ls = 0.f;
+  float alpha, ls = 0.f;
+  if constexpr (sizeof(CT) == 2) {
+    // bf16 path: the kernel is VALU-bound (16 MFMAs against ~300 VALU instructions per chunk with libm's expf), so
+    // the running maximum lives in the base-2 domain and every probability is ONE v_fma_f32 + ONE v_exp_f32
+    constexpr float kLog2e = 1.4426950408889634f;
+    const float mn = fmaxf(m, cm * kLog2e);
+    alpha = __builtin_amdgcn_exp2f(m - mn);    // 0 on the first chunk
+    m = mn;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float p = expf(sc[j][r] - mn);
-      sc[j][r] = p;
-      ls += p;
-    }
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j][r], kLog2e, -mn));
+        sc[j][r] = p;
+        ls += p;
+      }
+  } else {
+    const float mn = fmaxf(m, cm);
+    alpha = expf(m - mn);                      // 0 on the first chunk
+    m = mn;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = expf(sc[j][r] - mn);
+        sc[j][r] = p;
+        ls += p;
+      }
+  }
   l = l * alpha + ls;
   // rescale O: its rows are queries fg*4 + r, whose alpha lives in lane fg*4 + r
 #pragma unroll
@@ -155,12 +172,35 @@ __device__ __forceinline__ void enc_attn_store(CT* out, size_t row0, int HD, int
   l += __shfl_xor(l, 16);
   l += __shfl_xor(l, 32);
   const float linv = 1.f / l;
+  float li[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const float li = __shfl(linv, fg * 4 + r);
-    CT* dst = out + (row0 + fg * 4 + r) * HD + h * 64 + fr;
+  for (int r = 0; r < 4; ++r) li[r] = __shfl(linv, fg * 4 + r);
+  if constexpr (sizeof(CT) == 2) {
+    // dword stores: lanes fr and fr ^ 1 hold adjacent columns, they swap over DPP and the even lane writes rows
+    // r = 0, 1, the odd lane rows r = 2, 3 of the pair (a 2-byte store costs a read-modify-write in the cache)
+    const int odd = fr & 1;
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) dst[nb * 16] = to_ct<CT>(o[nb][r] * li);
+    for (int nb = 0; nb < 4; ++nb) {
+      float mine[4], other[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        mine[r] = o[nb][r] * li[r];
+        other[r] = lane_xor1(mine[r]);
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const float lo = odd ? other[2 + hh] : mine[hh], hi = odd ? mine[2 + hh] : other[hh];
+        CT* dst = out + (row0 + fg * 4 + odd * 2 + hh) * HD + h * 64 + nb * 16 + fr - odd;
+        *reinterpret_cast<unsigned*>(dst) = pack_bf16x2(lo, hi);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      CT* dst = out + (row0 + fg * 4 + r) * HD + h * 64 + fr;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) dst[nb * 16] = to_ct<CT>(o[nb][r] * li[r]);
+    }
   }
 }
 

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -f gpurun_out/summary.log
-for f in test_gpu_kernels.py test_gpu_engine.py test_gpu_parity_deep.py test_gpu_distributed.py; do
+for f in test_gpu_kernels.py test_gpu_engine.py test_gpu_parity_deep.py test_gpu_distributed.py test_external_fixtures.py; do
   timeout 900 python -m pytest tests/$f -m gpu -q --tb=short -p no:cacheprovider -s > gpurun_out/pytest_$f.log 2>&1
   echo "exit $? : $f" >> gpurun_out/summary.log
   tail -4 gpurun_out/pytest_$f.log >> gpurun_out/summary.log
