@@ -212,18 +212,29 @@ def main():
     # rank 0's host stage (EOS trim + run-length / note decoding in libmt3hip.so) runs on a worker thread, so the
     # NEXT batch's GPU work is already being launched while the previous batch's tokens become notes; every
     # future is joined before the clock stops, so all of it stays inside the timed region
+    # With N ranks, rank 0 receives N shards per step; each shard is decoded as its own "file" on its own worker
+    # thread (the C++ decoder runs outside the GIL), so rank 0's host time per step does not grow with N.
     from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=1)
+    pool = ThreadPoolExecutor(max_workers=max(1, min(world, 8)))
     pending = []
     gather_events = []
 
-    def host_stage(host):
+    def host_shard(host, first):
         eos = host == vocabularies.DECODED_EOS_ID
         n_tok = np.where(eos.any(1), eos.argmax(1), host.shape[1])
         rows = [r[:n] for r, n in zip(host, n_tok)]
         ns, inv, drop = metrics_utils._run(codec, note_sequences.NoteEncodingWithTiesSpec.spec_id, rows,
-                                           start_times[: len(rows)])
+                                           start_times[first: first + len(rows)])
         return len(ns.notes)
+
+    def host_stage(host):
+        """submit one step's token rows; returns the futures (one per source rank's shard)"""
+        futs = []
+        for r in range(world):
+            a, b = distributed.shard_range(host.shape[0], r, world)
+            if b > a:
+                futs.append(pool.submit(host_shard, host[a:b], a))
+        return futs
 
     def step():
         with torch.cuda.stream(stream):
@@ -243,12 +254,12 @@ def main():
                 gather_events.append((e0, e1))
             if rank == 0:
                 host = tokens.cpu().numpy()                                # syncs the stream
-                pending.append(pool.submit(host_stage, host))
+                pending.append(host_stage(host))
 
     def drain():
         n = 0
         while pending:
-            n = pending.pop(0).result()
+            n = sum(f.result() for f in pending.pop(0))
         return n
 
     def sync_all():
@@ -404,7 +415,7 @@ def main():
                             e32.encode(spectrograms.compute_spectrogram_batch(a256, None))
                             ids = e32.decode(num_steps=args.decode_steps)
                             host = vocab.decode_tf(ids).cpu().numpy()
-                        return host_stage(host)
+                        return sum(f.result() for f in host_stage(host))
                     with torch.cuda.stream(stream):
                         e32.encode(lm256)
                         e32.decode(num_steps=2)
@@ -441,7 +452,8 @@ def main():
                             e8.encode(spectrograms.compute_spectrogram_batch(a256, None))
                             ids = e8.decode(num_steps=args.decode_steps)
                             host = vocab.decode_tf(ids).cpu().numpy()
-                        host_stage(host)
+                        for f in host_stage(host):
+                            f.result()
                         torch.cuda.synchronize()
                         d8 = time.perf_counter() - t1
                         extras[key] = {"value": Br * SEG_SECONDS / d8, "unit": "audio-s/s", "ms_per_step": d8 * 1e3,
