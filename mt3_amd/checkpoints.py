@@ -179,8 +179,11 @@ def _target_tree(index: Dict[str, Any]) -> Optional[Dict[str, Any]]:
 
 
 # ---------------------------------------------------------------------------------------- public API
-def load_t5x_checkpoint(ckpt_dir: str, dtype=np.float32) -> Dict[str, np.ndarray]:
+def load_t5x_checkpoint(ckpt_dir: str, dtype=np.float32, expected: Optional[Iterable[str]] = None) -> Dict[str, np.ndarray]:
     """All model parameters (`target.*`) of a t5x checkpoint directory as {'a/b/c': array}.
+    `expected`: the parameter names the caller wants ('a/b/c' form).  Array directories are named with '.' between
+    tree levels, which is ambiguous for a level name that itself contains a dot; with `expected` a directory
+    is mapped to the expected name whose dotted form it equals, and only otherwise by replacing every '.'.
 
     The msgpack index is authoritative when present (inline leaves, TensorStore specs resolved
     relative to the directory); array directories named `target.*` that the index does not mention
@@ -202,9 +205,11 @@ def load_t5x_checkpoint(ckpt_dir: str, dtype=np.float32) -> Dict[str, np.ndarray
                 continue
             else:
                 raise CheckpointError("%s: leaf %s has unsupported type %s" % (ckpt_dir, name, type(leaf).__name__))
+    dotted = {n.replace("/", "."): n for n in expected} if expected is not None else {}
     for entry in sorted(os.listdir(ckpt_dir)):
         if entry.startswith(_TARGET_PREFIX) and os.path.isfile(os.path.join(ckpt_dir, entry, ".zarray")):
-            name = entry[len(_TARGET_PREFIX):].replace(".", "/")
+            tail = entry[len(_TARGET_PREFIX):]
+            name = dotted.get(tail, tail.replace(".", "/"))
             if name not in params:
                 params[name] = read_zarr_array(os.path.join(ckpt_dir, entry))
     if not params:

@@ -104,7 +104,8 @@ class InferenceModel(object):
             params = checkpoint_path
         elif checkpoint_path is not None and os.path.isdir(str(checkpoint_path)):      # real paths win over 'random'
             from . import checkpoints
-            params = checkpoints.load_t5x_checkpoint(str(checkpoint_path))
+            params = checkpoints.load_t5x_checkpoint(str(checkpoint_path),
+                                                     expected=network.param_shapes(self.model_config))
         elif checkpoint_path is not None and str(checkpoint_path).endswith(".npz") and \
                 os.path.exists(str(checkpoint_path)):
             with np.load(str(checkpoint_path)) as z:

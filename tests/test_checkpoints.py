@@ -137,3 +137,18 @@ def test_errors(tmp_path):
         CK.read_zarr_array(str(tmp_path / "gone"))
     with pytest.raises(CK.CheckpointError, match="no .zarray"):
         CK.read_zarr_array(str(tmp_path / "empty"))
+
+
+def test_directory_names_with_dots_resolve_against_the_expected_tree(tmp_path):
+    """Array directories join tree levels with '.', which is ambiguous for a level whose own name has a dot; with
+    the caller's expected names the reader maps `target.enc.v1.5.kernel` to 'enc/v1.5/kernel', not 'enc/v1/5/kernel'."""
+    from mt3_amd import checkpoints
+    d = tmp_path / "ck"
+    a = np.arange(6, dtype=np.float32).reshape(2, 3)
+    checkpoints.write_zarr_array(str(d / "target.enc.v1.5.kernel"), a)
+    checkpoints.write_zarr_array(str(d / "target.enc.plain.kernel"), a + 1)
+    naive = checkpoints.load_t5x_checkpoint(str(d))
+    assert "enc/v1/5/kernel" in naive
+    got = checkpoints.load_t5x_checkpoint(str(d), expected=["enc/v1.5/kernel", "enc/plain/kernel"])
+    assert set(got) == {"enc/v1.5/kernel", "enc/plain/kernel"}
+    assert np.array_equal(got["enc/v1.5/kernel"], a) and np.array_equal(got["enc/plain/kernel"], a + 1)

@@ -102,6 +102,9 @@ def test_teacher_forced_logits_all_positions_bf16(forced_case):
     safe = (top2[..., 1] - top2[..., 0]) > 0.05 * ref.std(-1)
     assert safe.mean() > 0.5
     assert np.array_equal(logits.argmax(-1)[safe], ref.argmax(-1)[safe])
+    agree = float((logits.argmax(-1) == ref.argmax(-1)).mean())
+    print(f"bf16 vs f32 oracle, teacher-forced, 8 x 1024 positions: rel-L2 max {r.max():.3e} mean {r.mean():.3e}; "
+          f"arg-max agreement {agree:.4f} overall ({safe.mean():.3f} of positions have a margin > 0.05 sigma: all agree)")
     assert eng.status(1) == 1 and eng.status(2) == 1        # graph replay, split residual stream
 
 
