@@ -172,7 +172,7 @@ int mt3_engine_decode_forced(mt3_engine* e, int32_t batch, int32_t num_steps, in
  * LAST_DECODE_USED_GRAPH: 1/0 for the most recent decode; RESIDUAL_SPLIT: 1 if the bf16 decode loop carries the
  * residual rows as f32 + bf16 copy + partial sums of squares. */
 enum { MT3_STATUS_GRAPH_FALLBACKS = 0, MT3_STATUS_LAST_DECODE_USED_GRAPH = 1, MT3_STATUS_RESIDUAL_SPLIT = 2,
-       MT3_STATUS_KV_FP8 = 3 };
+       MT3_STATUS_KV_FP8 = 3, MT3_STATUS_Q_FOLD = 4 /* cross q-projection folded into the neighbouring launches */ };
 int mt3_engine_status(const mt3_engine* e, int32_t what);
 
 /* GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271): -1 from the

@@ -17,7 +17,7 @@ MT3_OK, MT3_ERR_INVALID, MT3_ERR_HIP, MT3_ERR_CAPACITY, MT3_ERR_MISSING = 0, -1,
 MT3_BF16, MT3_F32, MT3_FP8_E4M3 = 0, 1, 2
 EPI_STORE, EPI_RESID, EPI_GEGLU, EPI_POS, EPI_F32, EPI_HEADS = range(6)
 DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SKIP_SELF_ATTN, DECODE_SKIP_CROSS_ATTN = 1, 2, 4, 8, 16
-STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8 = range(4)
+STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8, STATUS_Q_FOLD = range(5)
 EV_SHIFT, EV_PITCH, EV_VELOCITY, EV_TIE, EV_PROGRAM, EV_DRUM = range(6)
 EVENT_TYPE_NAMES = ("shift", "pitch", "velocity", "tie", "program", "drum")
 SPEC_ONSETS, SPEC_NOTES, SPEC_TIES = range(3)

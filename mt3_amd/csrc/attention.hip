@@ -368,7 +368,21 @@ __device__ __forceinline__ float key_group_sum(float v) {
   return v;
 }
 
-template <typename CT, bool APPEND, int NW>
+// 1 / rms of residual row b from its n (<= 64, a multiple of 4) partial sums of squares: lanes 0 .. n/4 - 1 of the
+// wave's first DPP row fetch a float4 each, the row is summed on the DPP network, lane 0's value is broadcast through
+// an SGPR -- the same order in every wave, a few VALU cycles instead of a six-step ds_bpermute butterfly
+__device__ __forceinline__ float row_rs_from_partials(const float* ss, int n, int lane) {
+  float part = 0.f;
+  if (lane < (n >> 2)) {
+    const float4 v = reinterpret_cast<const float4*>(ss)[lane];
+    part = ((v.x + v.y) + v.z) + v.w;
+  }
+  part = row16_sum(part);
+  const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, part)));
+  return rsqrtf(tot / static_cast<float>(16 * n) + 1e-6f);
+}
+
+template <typename CT, bool APPEND, int NW, bool QF32 = false>
 __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int KPL = CTraits<CT>::KPL;
   constexpr int D = 64;
@@ -403,8 +417,18 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
     }
   }
 
-  const u32x4 qc = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.q) +
-                                                   static_cast<size_t>(b) * a.q_stride + h * D + sub * KPL);
+  u32x4 qc;
+  if constexpr (QF32) {
+    // the query as unnormalised f32 + the partial sums of squares of its residual row: 1/rms here
+    const float* qp = a.q_f32 + static_cast<size_t>(b) * a.q_stride + h * D + sub * KPL;
+    const float4 q0 = *reinterpret_cast<const float4*>(qp), q1 = *reinterpret_cast<const float4*>(qp + 4);
+    const float rs = row_rs_from_partials(a.q_ss + static_cast<size_t>(b) * a.q_ss_n, a.q_ss_n, lane);
+    const float f[8] = {q0.x * rs, q0.y * rs, q0.z * rs, q0.w * rs, q1.x * rs, q1.y * rs, q1.z * rs, q1.w * rs};
+    qc = pack_bf16x8(f);
+  } else {
+    qc = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.q) + static_cast<size_t>(b) * a.q_stride + h * D +
+                                         sub * KPL);
+  }
 
   // Online softmax in base 2 (scores scaled by log2 e once; v_exp_f32 is 2^x) with ONE rescale of the
   // running state per group of UNROLL keys.  Out-of-range keys re-read the row's last cached key and get
@@ -595,7 +619,17 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
 
   // q: 16 bf16 of this lane's slice -> f32, pre-multiplied by log2(e) (base-2 softmax)
   float q[EPL];
-  {
+  if (a.q_f32) {     // (wave-uniform) folded q-projection: unnormalised f32 query + the row's partial sums of squares
+    const float* qp = a.q_f32 + static_cast<size_t>(b) * a.q_stride + h * D + sub * EPL;
+#pragma unroll
+    for (int j = 0; j < EPL; j += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(qp + j);
+      q[j] = v.x, q[j + 1] = v.y, q[j + 2] = v.z, q[j + 3] = v.w;
+    }
+    const float rs = row_rs_from_partials(a.q_ss + static_cast<size_t>(b) * a.q_ss_n, a.q_ss_n, lane) * kLog2e;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) q[j] *= rs;
+  } else {
     const __bf16* qp = static_cast<const __bf16*>(a.q) + static_cast<size_t>(b) * a.q_stride + h * D + sub * EPL;
     const u32x4 q0 = *reinterpret_cast<const u32x4*>(qp), q1 = *reinterpret_cast<const u32x4*>(qp + 8);
     unpack_chunk<__bf16>(q0, q);
@@ -762,8 +796,10 @@ int launch_kv_quantize_fp8(const void* src_bf16, void* dst_fp8, void* scales, in
 }
 
 int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
-  if (!a.q || !a.kcache || !a.vcache || !a.out || a.B <= 0 || a.H <= 0 || a.cap <= 0)
+  if ((!a.q && !a.q_f32) || !a.kcache || !a.vcache || !a.out || a.B <= 0 || a.H <= 0 || a.cap <= 0)
     return mt3::fail(MT3_ERR_INVALID, "decode_attention: bad arguments");
+  if (a.q_f32 && (dtype != MT3_BF16 || a.new_k || !a.q_ss || a.q_ss_n <= 0 || a.q_ss_n > 64 || (a.q_ss_n & 3)))
+    return mt3::fail(MT3_ERR_INVALID, "decode_attention: the f32 query form is the bf16 cross-attention's");
   if (!a.step && (a.n_keys <= 0 || a.n_keys > a.cap)) return mt3::fail(MT3_ERR_INVALID, "decode_attention: n_keys");
   const bool append = a.new_k != nullptr;
   if (append && !a.new_v) return mt3::fail(MT3_ERR_INVALID, "decode_attention: new_k without new_v");
@@ -807,7 +843,11 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
     else if (nw == 3) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 3>), grid, block, 0, s, a);     \
     else hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 4>), grid, block, 0, s, a);                  \
   } while (0)
-  if (dtype == MT3_BF16) {
+  if (dtype == MT3_BF16 && a.q_f32) {
+    if (nw == 2) hipLaunchKernelGGL((dec_attn_kernel<__bf16, false, 2, true>), grid, block, 0, s, a);
+    else if (nw == 3) hipLaunchKernelGGL((dec_attn_kernel<__bf16, false, 3, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((dec_attn_kernel<__bf16, false, 4, true>), grid, block, 0, s, a);
+  } else if (dtype == MT3_BF16) {
     if (append) MT3_LAUNCH_DEC(__bf16, true);
     else MT3_LAUNCH_DEC(__bf16, false);
   } else if (dtype == MT3_F32) {

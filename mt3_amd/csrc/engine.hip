@@ -62,6 +62,9 @@ struct LayerDev {
   void* wq_x = nullptr;      // decoder cross query [HD][emb]
   void* wkv_x = nullptr;     // decoder cross key|value [2HD][emb]
   void* wo_x = nullptr;      // decoder cross out [emb][HD]
+  // q-fold (bf16 decode): the cross-attention q-projection rides in the two neighbouring launches
+  void* wqkv_ext = nullptr;  // decoder [3HD + HD][emb]: wqkv rows, then the cross query rows (pre_cross norm scale folded)
+  void* wo_ext = nullptr;    // decoder [emb + HD][HD]: self out-projection rows, then (Wo . (s2 * Wq_x))^T
   void* wi = nullptr;        // [2*mlp][emb] interleaved gate/linear
   void* wo_mlp = nullptr;    // [emb][mlp]
   void* self_k = nullptr;    // decoder [Bm][H][L][64]
@@ -110,6 +113,12 @@ struct mt3_engine {
   void* y_ct = nullptr;          // [max_batch][emb] bf16
   float* y_ss = nullptr;         // [max_batch][emb/16]
   bool y_split = false;
+  // q-fold: y_new . Wq' = y_old . Wq' + attn . (Wo . Wq') by linearity, so the first term is 384 extra output columns
+  // of the QKV launch (same A operand), the second 384 extra columns of the self out-projection launch (same A
+  // operand), and the row's 1/rms is applied by the cross-attention kernel from the partial sums the out-projection's
+  // RESID epilogue leaves anyway: 8 launches per step fewer
+  float* qf = nullptr;           // [max_batch][HD] f32, unnormalised cross-attention query
+  bool q_fold = false;
   void* qkv_d = nullptr;
   void* attn_d = nullptr;
   void* q_d = nullptr;
@@ -226,6 +235,38 @@ int build_attention(mt3_engine* e, const std::string& prefix, const float* scale
   return MT3_OK;
 }
 
+// q-fold matrices of one decoder layer (see mt3_engine::qf)
+int build_q_fold(mt3_engine* e, const std::string& P, const float* s1, const float* s2, LayerDev* L) {
+  const int emb = e->cfg.emb_dim, hd = e->HD();
+  const std::string S = P + "/self_attention", X = P + "/encoder_decoder_attention";
+  const HostWeight *q = find(e, S + "/query/kernel", emb, hd), *k = find(e, S + "/key/kernel", emb, hd),
+                   *v = find(e, S + "/value/kernel", emb, hd), *o = find(e, S + "/out/kernel", hd, emb),
+                   *qx = find(e, X + "/query/kernel", emb, hd);
+  if (!q || !k || !v || !o || !qx) return MT3_ERR_MISSING;
+  std::vector<float> t(static_cast<size_t>(4) * hd * emb);
+  put_transposed(t, emb, 0, *q, s1);
+  put_transposed(t, emb, hd, *k, s1);
+  put_transposed(t, emb, 2 * hd, *v, s1);
+  put_transposed(t, emb, 3 * hd, *qx, s2);
+  int rc;
+  if ((rc = upload_ct(e, t, &L->wqkv_ext))) return rc;
+  // rows [0, emb): Wo^T;  rows [emb, emb + hd): P^T with P[k][n] = sum_e Wo[k][e] * s2[e] * Wq_x[e][n]  (double)
+  std::vector<float> u(static_cast<size_t>(emb + hd) * hd);
+  put_transposed(u, hd, 0, *o, nullptr);
+  std::vector<double> acc(hd);
+  for (int kk = 0; kk < hd; ++kk) {
+    std::fill(acc.begin(), acc.end(), 0.0);
+    const float* orow = o->data.data() + static_cast<size_t>(kk) * emb;
+    for (int ee = 0; ee < emb; ++ee) {
+      const double w = static_cast<double>(orow[ee]) * s2[ee];
+      const float* qrow = qx->data.data() + static_cast<size_t>(ee) * hd;
+      for (int n = 0; n < hd; ++n) acc[n] += w * qrow[n];
+    }
+    for (int n = 0; n < hd; ++n) u[static_cast<size_t>(emb + n) * hd + kk] = static_cast<float>(acc[n]);
+  }
+  return upload_ct(e, u, &L->wo_ext);
+}
+
 int build_mlp(mt3_engine* e, const std::string& prefix, const float* scale, LayerDev* L) {
   const int emb = e->cfg.emb_dim, mlp = e->cfg.mlp_dim;
   const HostWeight *w0 = find(e, prefix + "/wi_0/kernel", emb, mlp), *w1 = find(e, prefix + "/wi_1/kernel", emb, mlp),
@@ -334,6 +375,12 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   LayerDev& L = e->dec[op >> 3];
   switch (op & 7) {
     case 0:
+      if (e->q_fold) {
+        mt3k::GemmArgs g = normed(L.wqkv_ext, qkv_d, 4 * hd, 3 * hd);
+        g.out2 = e->qf + static_cast<size_t>(row0) * hd;
+        g.n_split = 3 * hd;
+        return mt3k::launch_gemm(dt, g, false, 2, mt3k::kEpiStoreQ, small, s);
+      }
       return mt3k::launch_gemm(dt, normed(L.wqkv, qkv_d, 3 * hd, 3 * hd), !split, nrm, MT3_EPI_STORE, small, s);
     case 1: {
       if (skip & 1) return MT3_OK;
@@ -354,14 +401,27 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
       return mt3k::launch_decode_attention(dt, a, s);
     }
     case 2:
+      if (e->q_fold) {
+        mt3k::GemmArgs g = resid(attn_d, L.wo_ext, hd);
+        g.N = emb + hd;
+        g.out2 = e->qf + static_cast<size_t>(row0) * hd;
+        g.n_split = emb;
+        return mt3k::launch_gemm(dt, g, false, 0, mt3k::kEpiResidQ, small, s);
+      }
       return mt3k::launch_gemm(dt, resid(attn_d, L.wo, hd), false, 0, MT3_EPI_RESID, small, s);
     case 3:
+      if (e->q_fold) return MT3_OK;           // folded into ops 0 and 2
       return mt3k::launch_gemm(dt, normed(L.wq_x, q_d, hd, hd), !split, nrm, MT3_EPI_STORE, small, s);
     case 4: {
       if (skip & 2) return MT3_OK;
       mt3k::DecAttnArgs x{};
       x.q = q_d;
       x.q_stride = hd;
+      if (e->q_fold) {
+        x.q_f32 = e->qf + static_cast<size_t>(row0) * hd;
+        x.q_ss = y_ss;
+        x.q_ss_n = emb / 16;
+      }
       x.kcache = static_cast<char*>(L.cross_kv) + static_cast<size_t>(row0) * H * T * 64 * kes;
       x.vcache = static_cast<char*>(L.cross_kv) + (static_cast<size_t>(B_total) + row0) * H * T * 64 * kes;
       x.kv_scale = e->kv_fp8 ? L.cross_scale + static_cast<size_t>(row0) * H * T : nullptr;
@@ -561,6 +621,9 @@ int mt3_engine_finalize(mt3_engine* e) {
     if ((rc = upload_f32(e, w->data, &e->embedding))) return rc;
   }
   e->dec.resize(c.num_decoder_layers);
+  const bool q_fold = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && (emb <= 512 || emb == 768) && emb <= 1024 &&
+                      !getenv("MT3_NO_Y_SPLIT") && !getenv("MT3_NO_QFOLD");
+  e->q_fold = q_fold;
   for (int l = 0; l < c.num_decoder_layers; ++l) {
     const std::string P = "decoder/layers_" + std::to_string(l);
     const float* s1 = scale_of(e, P + "/pre_self_attention_layer_norm/scale");
@@ -569,6 +632,7 @@ int mt3_engine_finalize(mt3_engine* e) {
     if (!s1 || !s2 || !s3) return MT3_ERR_MISSING;
     if ((rc = build_attention(e, P + "/self_attention", s1, false, &e->dec[l]))) return rc;
     if ((rc = build_attention(e, P + "/encoder_decoder_attention", s2, true, &e->dec[l]))) return rc;
+    if (q_fold && (rc = build_q_fold(e, P, s1, s2, &e->dec[l]))) return rc;
     if ((rc = build_mlp(e, P + "/mlp", s3, &e->dec[l]))) return rc;
     const size_t kvb = static_cast<size_t>(Bm) * c.num_heads * L * 64 * e->kv_esize;
     if ((rc = dmalloc(e, &e->dec[l].self_k, kvb))) return rc;
@@ -624,6 +688,8 @@ int mt3_engine_finalize(mt3_engine* e) {
     if ((rc = dmalloc(e, &e->y_ct, static_cast<size_t>(Bm) * emb * 2))) return rc;
     if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y_ss), static_cast<size_t>(Bm) * (emb / 16) * 4))) return rc;
   }
+  if (e->q_fold && !e->y_split) e->q_fold = false;
+  if (e->q_fold && (rc = dmalloc(e, reinterpret_cast<void**>(&e->qf), static_cast<size_t>(Bm) * hd * 4))) return rc;
   if ((rc = dmalloc(e, &e->qkv_d, static_cast<size_t>(Bm) * 3 * hd * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->attn_d, static_cast<size_t>(Bm) * hd * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->q_d, static_cast<size_t>(Bm) * hd * e->esize))) return rc;
@@ -789,6 +855,7 @@ int mt3_engine_status(const mt3_engine* e, int32_t what) {
     case MT3_STATUS_LAST_DECODE_USED_GRAPH: return e->last_used_graph;
     case MT3_STATUS_RESIDUAL_SPLIT: return e->y_split ? 1 : 0;
     case MT3_STATUS_KV_FP8: return e->kv_fp8 ? 1 : 0;
+    case MT3_STATUS_Q_FOLD: return e->q_fold ? 1 : 0;
     default: return mt3::fail(MT3_ERR_INVALID, "mt3_engine_status: unknown item");
   }
 }

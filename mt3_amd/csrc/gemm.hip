@@ -120,17 +120,38 @@ __device__ __forceinline__ void gemm_load_tiles(u32x4 (&a_reg)[A_PASSES], u32x4 
 struct EpiCtx {
   void* out;
   const float* aux;
-  int M, N, ldo, seq;
+  int M, N, ldo, seq;       // N: width of the primary output region (= n_split for the *Q epilogues)
   void* out_ct;
   float* out_ss;
+  float* out2;              // *Q epilogues: f32 [M][ld2] for tile columns >= n_split
+  int n_split, ld2;
 };
 
 // acc[i][j]: the wave's (wm, wn) sub-tile as FM x FN 16x16 C fragments of the workgroup tile at (m0, n0);
 // row_rs(lrow) = 1 / rms of tile row lrow (or 1)
-template <typename CT, int EPI, int FM, int FN, typename RowRs>
+template <typename CT, int EPI_, int FM, int FN, typename RowRs>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm, int wn, int lane, int m0, int n0,
                                               const EpiCtx& c, RowRs row_rs) {
   const int frag_row = lane & 15, frag_g = lane >> 4;
+  if constexpr (EPI_ == kEpiStoreQ || EPI_ == kEpiResidQ) {
+    if (n0 >= c.n_split) {       // (tile-uniform) the second product: plain f32, no row scale
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * FM * 16 + i * 16 + frag_g * 4 + r;
+          if (row >= c.M) continue;
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            float* o = c.out2 + static_cast<size_t>(row) * c.ld2 + (n0 - c.n_split) + wn * FN * 16 + j * 16 + frag_row;
+            if constexpr (EPI_ == kEpiResidQ) *o = *o + acc[i][j][r];
+            else *o = acc[i][j][r];
+          }
+        }
+      return;
+    }
+  }
+  constexpr int EPI = EPI_ == kEpiStoreQ ? MT3_EPI_STORE : EPI_ == kEpiResidQ ? MT3_EPI_RESID : EPI_;
   // ---- epilogue: C fragment (i, j): rows (lane>>4)*4 + r, col lane & 15
   // 2-byte outputs are never stored one element at a time (a sub-dword store costs a read-modify-write in the
   // cache: the bf16 STORE epilogue of a decode GEMM took 2.5 us against 0.7 us for the f32 RESID one): lanes l
@@ -404,7 +425,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
     return rsqrtf(t / static_cast<float>(gK) + 1e-6f);
   };
   MT3_PROF_MARK(5);
-  const EpiCtx ec{gO, gAux, gM, gN, gLdo, gSeq, gOutCt, gOutSs};
+  constexpr bool SPLIT = EPI == kEpiStoreQ || EPI == kEpiResidQ;
+  const EpiCtx ec{gO, gAux, gM, SPLIT ? g.n_split : gN, gLdo, gSeq, gOutCt, gOutSs, g.out2, g.n_split, gN - g.n_split};
   gemm_epilogue<CT, EPI, FM, FN>(acc, wm, wn, lane, m0, n0, ec, row_rs);
   MT3_PROF_MARK(4);
 }
@@ -717,6 +739,11 @@ static int launch_typed(const GemmArgs& g, bool a_f32, int norm, int epi, bool s
       case MT3_EPI_STORE: return launch_tile<CT, false, false, MT3_EPI_STORE>(g, small, s);
       case MT3_EPI_GEGLU: return launch_tile<CT, false, false, MT3_EPI_GEGLU>(g, small, s);
       case MT3_EPI_F32: return launch_tile<CT, false, false, MT3_EPI_F32>(g, small, s);
+      case kEpiStoreQ:
+        if constexpr (sizeof(CT) == 2) {
+          if (small) return launch_tile<CT, false, false, kEpiStoreQ>(g, small, s);
+        }
+        break;
       default: break;
     }
     return mt3::fail(MT3_ERR_INVALID, "gemm: unsupported epilogue for norm 2");
@@ -740,6 +767,11 @@ static int launch_typed(const GemmArgs& g, bool a_f32, int norm, int epi, bool s
   } else {
     switch (epi) {
       case MT3_EPI_RESID: return launch_tile<CT, false, false, MT3_EPI_RESID>(g, small, s);
+      case kEpiResidQ:
+        if constexpr (sizeof(CT) == 2) {
+          if (small) return launch_tile<CT, false, false, kEpiResidQ>(g, small, s);
+        }
+        break;
       case MT3_EPI_HEADS: return launch_tile<CT, false, false, MT3_EPI_HEADS>(g, small, s);
       case MT3_EPI_STORE: return launch_tile<CT, false, false, MT3_EPI_STORE>(g, small, s);
       case MT3_EPI_F32: return launch_tile<CT, false, false, MT3_EPI_F32>(g, small, s);
@@ -753,6 +785,8 @@ int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, int norm, int epi, boo
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.Wt || !g.out)
     return mt3::fail(MT3_ERR_INVALID, "gemm: bad shape or null pointer");
   if (epi == MT3_EPI_POS && (!g.aux || g.seq_len <= 0)) return mt3::fail(MT3_ERR_INVALID, "gemm: POS needs aux/seq_len");
+  if ((epi == kEpiStoreQ || epi == kEpiResidQ) && (!g.out2 || g.n_split <= 0 || g.n_split >= g.N || g.n_split % 64))
+    return mt3::fail(MT3_ERR_INVALID, "gemm: split epilogue needs out2 and 0 < n_split < N, n_split a multiple of 64");
   if (epi == MT3_EPI_HEADS && (g.seq_len <= 0 || g.M % g.seq_len != 0 || g.N % 128 != 0))
     return mt3::fail(MT3_ERR_INVALID, "gemm: HEADS needs M = B*T and N = 2*H*64");
   if (dtype == MT3_BF16 && !small && glds_eligible(g, a_f32, norm, epi)) {

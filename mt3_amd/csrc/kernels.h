@@ -23,7 +23,13 @@ struct GemmArgs {
   const float* a_ss;  // norm == 2: [M][K/16] partial sums of squares of the rows whose compute-type copy is A
   void* out_ct;       // EPI_RESID: also write the updated rows in the compute type here [M][ldo] (nullptr: no)
   float* out_ss;      // EPI_RESID with out_ct: [M][N/16] partial sums of squares of the updated rows
+  // kEpiStoreQ / kEpiResidQ: output columns [n_split, N) are a SECOND product riding in the same launch -- they go to
+  // out2 (f32 [M][N - n_split], unscaled; ResidQ accumulates into it), columns [0, n_split) take the STORE / RESID path
+  float* out2;
+  int n_split;
 };
+// internal epilogues (not part of the C ABI): STORE / RESID with a second f32 output region, see GemmArgs::out2
+constexpr int kEpiStoreQ = 6, kEpiResidQ = 7;
 
 // norm: 0 none, 1 fused RMSNorm with statistics from the f32 A stream, 2 fused RMSNorm from g.a_ss (A = compute type)
 int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, int norm, int epi, bool small, hipStream_t s);
@@ -47,6 +53,12 @@ struct DecAttnArgs {
   // non-null: the cache holds OCP e4m3 bytes [B, H, cap, 64] and this is its side array [B, H, cap] of
   // {k_scale, v_scale} (power-of-two row scales); q / new rows / out are bf16
   float2* kv_scale;
+  // bf16 path, no append: the query arrives as UNNORMALISED f32 rows q_f32 [B][q_stride] plus the partial sums of
+  // squares q_ss [B][q_ss_n] of the residual row it was projected from (emb = 16 * q_ss_n); the kernel applies
+  // rsqrt(mean + 1e-6) itself (the cross-attention q-projection folded into the neighbouring GEMM launches)
+  const float* q_f32;
+  const float* q_ss;
+  int q_ss_n;
 };
 // bf16 K rows then V rows ([2][rows][64]) -> e4m3 [2][rows][64] + float2 scales [rows]
 int launch_kv_quantize_fp8(const void* src_bf16, void* dst_fp8, void* scales, int rows, hipStream_t s);

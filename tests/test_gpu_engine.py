@@ -209,6 +209,7 @@ def test_split_residual_stream_matches_the_single_f32_stream(setup, monkeypatch)
     and the greedy tokens must be identical."""
     x = torch.from_numpy(np.repeat(setup["x"], 12, axis=0)[:34]).cuda()          # ragged: 34 rows = 32 + 2
     out = {}
+    monkeypatch.setenv("MT3_NO_QFOLD", "1")          # (the folded q-projection rounds differently: its own test below)
     for name, env in (("split", None), ("single", "1")):
         if env is None:
             monkeypatch.delenv("MT3_NO_Y_SPLIT", raising=False)
@@ -230,6 +231,32 @@ def test_split_residual_stream_matches_the_single_f32_stream(setup, monkeypatch)
     assert clean.any(), d
     assert d.max() < 6e-3, d
     assert np.array_equal(out["split"][0][clean], out["single"][0][clean])
+
+
+def test_folded_cross_query_projection_matches_the_separate_launch(setup, monkeypatch):
+    """bf16 decode folds the cross-attention q-projection into the QKV and self out-projection launches
+    (y_new.Wq' = y_old.Wq' + attn.(Wo.Wq'), 1/rms applied by the cross-attention kernel from the partial sums): the
+    same function of the same weights, rounded in different places.  Against the separate launch (MT3_NO_QFOLD=1):
+    step-0 logits within bf16 noise on every row; against the f32 oracle both stay inside the bf16 bound."""
+    x = torch.from_numpy(np.repeat(setup["x"], 12, axis=0)[:34]).cuda()
+    out = {}
+    for name, env in (("fold", None), ("separate", "1")):
+        if env is None:
+            monkeypatch.delenv("MT3_NO_QFOLD", raising=False)
+        else:
+            monkeypatch.setenv("MT3_NO_QFOLD", env)
+        eng = _engine("bfloat16", setup["params"], 34)
+        assert eng.status(4) == (1 if env is None else 0)
+        eng.encode(x)
+        ids, logits0 = eng.decode(num_steps=24, return_first_logits=True)
+        out[name] = (ids.cpu().numpy(), logits0.cpu().numpy())
+    a, b = out["fold"][1], out["separate"][1]
+    d = np.linalg.norm(a.astype(np.float64) - b, axis=1) / np.linalg.norm(b.astype(np.float64), axis=1)
+    assert d.max() < 1e-2 and np.median(d) < 5e-3, d
+    ref = np.repeat(setup["logits_ref"][:, 0], 12, axis=0)[:34]
+    for got in (a, b):
+        r = np.linalg.norm(got.astype(np.float64) - ref, axis=1) / np.linalg.norm(ref.astype(np.float64), axis=1)
+        assert r.max() < 3e-2, r
 
 
 def test_inference_model_end_to_end():
