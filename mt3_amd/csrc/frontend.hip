@@ -40,6 +40,25 @@ constexpr int kWaves = 4;
 constexpr int kMelBins = 512;
 constexpr int kMagStride = 1028;
 constexpr int kMaxBandWeights = 2048;       // >= sum of band lengths (1934 for the reference's mel matrix)
+// longest band (spectrum bins per mel bin) inside each group of 64 mel bins, for the reference's mel matrix
+// (512 bins, 20 .. 7600 Hz over 1025 FFT bins: 2 2 3 3 4 6 8 10); mt3_frontend_create checks the tables against it
+constexpr int kGroupMaxBand[8] = {2, 2, 3, 3, 4, 6, 8, 10};
+// logf(1e-5f) as numpy's float32 evaluates it (spectral_ops.safe_log's floor), and ln 2
+constexpr float kLogFloor = -11.512925148010254f, kLn2 = 0.6931471805599453f;
+
+// safe_log of a mel value: v_log_f32 (log2, 1 ulp) * ln 2 instead of logf's expansion; denormal inputs (which the
+// instruction would flush) take the slow path
+__device__ __forceinline__ float safe_log_fast(float m) {
+  if (m <= 0.f) return kLogFloor;
+  if (m < 1.17549435e-38f) return logf(m);
+  return __builtin_amdgcn_logf(m) * kLn2;
+}
+
+template <int I>
+__device__ __forceinline__ void mel_group(const mt3fe::MelTables& mel, int lane, const float* mag, float* dst) {
+  const int j = lane + 64 * I;
+  dst[j] = safe_log_fast(mt3fe::mel_bin_fixed<kGroupMaxBand[I]>(mel, j, mag));
+}
 
 // The 4 waves of a workgroup work on different frames and only meet at the initial staging barrier;
 // inside the frame loop every LDS hand-off is between lanes of ONE wave (private xchg / mag regions).
@@ -114,13 +133,15 @@ __global__ __launch_bounds__(256) void logmel_kernel(FrontendDev t, const float*
     wave_lds_sync();
     const int f = f0 + fl;
     float* dst = out + (static_cast<size_t>(seg) * frames_per_segment + f) * kMelBins;
-    if (f < n) {
-#pragma unroll
-      for (int i = 0; i < kMelBins / 64; ++i) {
-        const int j = lane + 64 * i;
-        const float m = mt3fe::mel_bin(mel, j, mag);
-        dst[j] = logf(m <= 0.f ? 1e-5f : m);                     // spectral_ops.safe_log
-      }
+    if (f < n) {                                                 // spectral_ops.safe_log(mel)
+      mel_group<0>(mel, lane, mag, dst);
+      mel_group<1>(mel, lane, mag, dst);
+      mel_group<2>(mel, lane, mag, dst);
+      mel_group<3>(mel, lane, mag, dst);
+      mel_group<4>(mel, lane, mag, dst);
+      mel_group<5>(mel, lane, mag, dst);
+      mel_group<6>(mel, lane, mag, dst);
+      mel_group<7>(mel, lane, mag, dst);
     } else {
 #pragma unroll
       for (int i = 0; i < kMelBins / 64; ++i) dst[lane + 64 * i] = 0.f;
@@ -174,6 +195,12 @@ int mt3_frontend_create(const mt3_frontend_config* cfg, mt3_frontend** out) {
     delete fe;
     return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_create: mel band table too large for the kernel's LDS budget");
   }
+  for (int j = 0; j < kMelBins; ++j)
+    if (fe->host.cnt[j] > kGroupMaxBand[j / 64]) {
+      delete fe;
+      return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_create: a mel band is longer than the kernel's unrolled bound "
+                                        "(this build is specialised to 20 .. 7600 Hz at 16 kHz)");
+    }
   *out = fe;
   return MT3_OK;
 }

@@ -29,6 +29,14 @@
 #define MT3_UNROLL
 #endif
 
+// device build: the raw v_sqrt_f32 (1 ulp) instead of sqrtf's ~10-instruction denormal-safe expansion -- 16 per frame
+// and lane in a kernel that is VALU-issue-bound; the host emulation keeps libm
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MT3_FE_SQRT(x) __builtin_amdgcn_sqrtf(x)
+#else
+#define MT3_FE_SQRT(x) sqrtf(x)
+#endif
+
 namespace mt3fe {
 
 constexpr int kFft = 2048;
@@ -165,7 +173,7 @@ MT3_HD void untangle_mag(const LaneConst& c, int lane, const cpx (&z)[16], const
     const cpx d = a - b;
     const cpx o = {0.5f * d.im, -0.5f * d.re};           // -i/2 * (a - b)
     const cpx x = e + cmul(c.twU[m], o);
-    mag[k] = sqrtf(x.re * x.re + x.im * x.im);
+    mag[k] = MT3_FE_SQRT(x.re * x.re + x.im * x.im);
   }
   if (lane == 0) {
     const float v = z[0].re - z[0].im;                   // X[1024] = Re Z0 - Im Z0
@@ -187,6 +195,26 @@ MT3_HD float mel_bin(const MelTables& t, int j, const float* mag) {
   const float* w = t.w + t.off[j];
   const float* m = mag + t.k0[j];
   for (int i = 0; i < n; ++i) acc += m[i] * w[i];
+  return acc;
+}
+
+// The same sum with a COMPILE-TIME trip count MAXC >= cnt[j] (the longest band of the bin's group of 64): branch-free,
+// immediate LDS offsets, terms past the band get weight 0 (fma(m, 0, acc) == acc, so the result is bit-identical to
+// mel_bin; reads past the band stay inside the mag / weight arrays: k0 + 10 <= 983 < 1028).
+template <int MAXC>
+MT3_HD float mel_bin_fixed(const MelTables& t, int j, const float* mag) {
+  float acc = 0.f;
+  const int n = t.cnt[j];
+  const float* w = t.w + t.off[j];
+  const float* m = mag + t.k0[j];
+  float wv[MAXC], mv[MAXC];
+  MT3_UNROLL
+  for (int i = 0; i < MAXC; ++i) {      // unconditional loads first (a "load or zero" select would become a branch
+    wv[i] = w[i];                       // around every load on the device)
+    mv[i] = m[i];
+  }
+  MT3_UNROLL
+  for (int i = 0; i < MAXC; ++i) acc += mv[i] * (i < n ? wv[i] : 0.f);
   return acc;
 }
 
