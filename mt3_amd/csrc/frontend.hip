@@ -40,24 +40,22 @@ constexpr int kWaves = 4;
 constexpr int kMelBins = 512;
 constexpr int kMagStride = 1028;
 constexpr int kMaxBandWeights = 2048;       // >= sum of band lengths (1934 for the reference's mel matrix)
-// longest band (spectrum bins per mel bin) inside each group of 64 mel bins, for the reference's mel matrix
-// (512 bins, 20 .. 7600 Hz over 1025 FFT bins: 2 2 3 3 4 6 8 10); mt3_frontend_create checks the tables against it
-constexpr int kGroupMaxBand[8] = {2, 2, 3, 3, 4, 6, 8, 10};
 // logf(1e-5f) as numpy's float32 evaluates it (spectral_ops.safe_log's floor), and ln 2
 constexpr float kLogFloor = -11.512925148010254f, kLn2 = 0.6931471805599453f;
 
 // safe_log of a mel value: v_log_f32 (log2, 1 ulp) * ln 2 instead of logf's expansion; denormal inputs (which the
-// instruction would flush) take the slow path
+// instruction would flush) are clamped
 __device__ __forceinline__ float safe_log_fast(float m) {
-  if (m <= 0.f) return kLogFloor;
-  if (m < 1.17549435e-38f) return logf(m);
-  return __builtin_amdgcn_logf(m) * kLn2;
+  // (a positive DENORMAL mel -- below 1.2e-38, i.e. numerical dust of a silent frame -- is read as the smallest
+  // normal number: v_log_f32 would flush it to zero)
+  const float l = __builtin_amdgcn_logf(fmaxf(m, 1.17549435e-38f)) * kLn2;
+  return m <= 0.f ? kLogFloor : l;
 }
 
 template <int I>
-__device__ __forceinline__ void mel_group(const mt3fe::MelTables& mel, int lane, const float* mag, float* dst) {
+__device__ __forceinline__ void mel_group(const int* k0, const float* wpad, int lane, const float* mag, float* dst) {
   const int j = lane + 64 * I;
-  dst[j] = safe_log_fast(mt3fe::mel_bin_fixed<kGroupMaxBand[I]>(mel, j, mag));
+  dst[j] = safe_log_fast(mt3fe::mel_bin_padded<mt3fe::kGroupMaxBand[I]>(k0, wpad + mt3fe::group_base(I), j, mag));
 }
 
 // The 4 waves of a workgroup work on different frames and only meet at the initial staging barrier;
@@ -87,8 +85,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(FrontendDev t, const float*
   __shared__ __attribute__((aligned(16))) float s_samples[kTileSamples];
   __shared__ __attribute__((aligned(16))) cpx s_xchg[kWaves][mt3fe::kXchg];   // also holds Z in natural order
   __shared__ __attribute__((aligned(16))) float s_mag[kWaves][kMagStride];
-  __shared__ int s_k0[kMelBins], s_cnt[kMelBins], s_off[kMelBins];      // band tables: read per frame
-  __shared__ float s_w[kMaxBandWeights];
+  __shared__ int s_k0[kMelBins];                                        // first spectrum bin of every mel band
+  __shared__ float s_w[mt3fe::kPaddedWeights];                                 // group-padded, transposed band weights
 
   const int tiles = frames_per_segment / kFramesPerBlock;
   const int seg = blockIdx.x / tiles;
@@ -105,15 +103,10 @@ __global__ __launch_bounds__(256) void logmel_kernel(FrontendDev t, const float*
     if (idx < valid) v = *reinterpret_cast<const float4*>(seg_audio + idx);
     *reinterpret_cast<float4*>(&s_samples[4 * i]) = v;
   }
-  for (int i = tid; i < kMelBins; i += 256) {
-    s_k0[i] = t.k0[i];
-    s_cnt[i] = t.cnt[i];
-    s_off[i] = t.off[i];
-  }
-  for (int i = tid; i < t.n_w; i += 256) s_w[i] = t.w[i];
+  for (int i = tid; i < kMelBins; i += 256) s_k0[i] = t.k0[i];
+  for (int i = tid; i < mt3fe::kPaddedWeights; i += 256) s_w[i] = t.w[i];
   mt3fe::LaneConst lc;
   mt3fe::load_lane_const(lc, lane, t.hann, t.tw1024, t.tw2048);
-  const mt3fe::MelTables mel{s_k0, s_cnt, s_off, s_w};
   __syncthreads();
 
   cpx* xchg = s_xchg[wave];
@@ -134,14 +127,14 @@ __global__ __launch_bounds__(256) void logmel_kernel(FrontendDev t, const float*
     const int f = f0 + fl;
     float* dst = out + (static_cast<size_t>(seg) * frames_per_segment + f) * kMelBins;
     if (f < n) {                                                 // spectral_ops.safe_log(mel)
-      mel_group<0>(mel, lane, mag, dst);
-      mel_group<1>(mel, lane, mag, dst);
-      mel_group<2>(mel, lane, mag, dst);
-      mel_group<3>(mel, lane, mag, dst);
-      mel_group<4>(mel, lane, mag, dst);
-      mel_group<5>(mel, lane, mag, dst);
-      mel_group<6>(mel, lane, mag, dst);
-      mel_group<7>(mel, lane, mag, dst);
+      mel_group<0>(s_k0, s_w, lane, mag, dst);
+      mel_group<1>(s_k0, s_w, lane, mag, dst);
+      mel_group<2>(s_k0, s_w, lane, mag, dst);
+      mel_group<3>(s_k0, s_w, lane, mag, dst);
+      mel_group<4>(s_k0, s_w, lane, mag, dst);
+      mel_group<5>(s_k0, s_w, lane, mag, dst);
+      mel_group<6>(s_k0, s_w, lane, mag, dst);
+      mel_group<7>(s_k0, s_w, lane, mag, dst);
     } else {
 #pragma unroll
       for (int i = 0; i < kMelBins / 64; ++i) dst[lane + 64 * i] = 0.f;
@@ -169,7 +162,8 @@ struct mt3_frontend {
   void* d_k0 = nullptr;
   void* d_cnt = nullptr;
   void* d_off = nullptr;
-  void* d_w = nullptr;
+  void* d_w = nullptr;           // group-padded transposed band weights (mt3fe::kPaddedWeights floats)
+  std::vector<float> wpad;
   // per-call frame counts travel through a pre-sized ring (device + pinned host mirror): nothing is allocated on
   // the call path, the copy is stream-ordered from pinned memory, and a later call on another stream takes the
   // NEXT slot instead of overwriting counts an earlier launch may still be reading
@@ -195,12 +189,12 @@ int mt3_frontend_create(const mt3_frontend_config* cfg, mt3_frontend** out) {
     delete fe;
     return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_create: mel band table too large for the kernel's LDS budget");
   }
-  for (int j = 0; j < kMelBins; ++j)
-    if (fe->host.cnt[j] > kGroupMaxBand[j / 64]) {
-      delete fe;
-      return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_create: a mel band is longer than the kernel's unrolled bound "
-                                        "(this build is specialised to 20 .. 7600 Hz at 16 kHz)");
-    }
+  if (!mt3fe::bands_fit(fe->host)) {
+    delete fe;
+    return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_create: a mel band is longer than the kernel's unrolled bound "
+                                      "(this build is specialised to 512 bins over 20 .. 7600 Hz at 16 kHz)");
+  }
+  fe->wpad = mt3fe::build_padded_weights(fe->host);
   *out = fe;
   return MT3_OK;
 }
@@ -232,7 +226,7 @@ static int ensure_device_tables(mt3_frontend* fe) {
   if ((rc = upload(fe->host.k0, &fe->d_k0))) return rc;
   if ((rc = upload(fe->host.cnt, &fe->d_cnt))) return rc;
   if ((rc = upload(fe->host.off, &fe->d_off))) return rc;
-  if ((rc = upload(fe->host.w, &fe->d_w))) return rc;
+  if ((rc = upload(fe->wpad, &fe->d_w))) return rc;
   MT3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&fe->d_nframes), sizeof(int) * kNFramesRing));
   MT3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&fe->h_nframes), sizeof(int) * kNFramesRing, hipHostMallocDefault));
   fe->on_device = true;

@@ -50,7 +50,19 @@ struct cpx {
 };
 MT3_HD cpx operator+(cpx a, cpx b) { return {a.re + b.re, a.im + b.im}; }
 MT3_HD cpx operator-(cpx a, cpx b) { return {a.re - b.re, a.im - b.im}; }
+#if defined(__HIP_DEVICE_COMPILE__)
+// device: two packed f32 instructions (v_pk_mul_f32 + v_pk_fma_f32, half-swaps and the sign riding on op_sel / neg)
+// instead of two multiplies and two FMAs
+typedef float mt3_f2 __attribute__((ext_vector_type(2)));
+MT3_HD cpx cmul(cpx a, cpx b) {
+  const mt3_f2 av = {a.re, a.im}, as = {a.im, a.re};
+  const mt3_f2 br = {b.re, b.re}, bi = {-b.im, b.im};
+  const mt3_f2 r = __builtin_elementwise_fma(as, bi, av * br);
+  return {r.x, r.y};
+}
+#else
 MT3_HD cpx cmul(cpx a, cpx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+#endif
 MT3_HD cpx mul_neg_i(cpx a) { return {a.im, -a.re}; }   // a * (-i)
 MT3_HD cpx mul_pos_i(cpx a) { return {-a.im, a.re}; }   // a * (+i)
 
@@ -161,7 +173,11 @@ MT3_HD void publish_z(int lane, const cpx (&z)[16], cpx* zlin /*[1024]*/) {
   for (int m = 0; m < 16; ++m) zlin[lane + 64 * m] = z[m];
 }
 
-// ---- untangle: |X[k]| for k = lane + 64*m (m = 0..15), plus k = 1024 on lane 0
+// ---- untangle: 2 |X[k]| for k = lane + 64*m (m = 0..15), plus k = 1024 on lane 0.
+// X[k] = E + W2048^k O with E = (a + b')/2, O = -i (a - b')/2, a = Z[k], b' = conj(Z[N/2 - k]).  The two halvings
+// are exact scalings by a power of two, so they are left out here (x2 = 2 X[k] exactly, sqrt(4 y) = 2 sqrt(y)
+// exactly) and the band weights of the mel tables carry the factor 1/2 instead (HostTables::w is stored halved):
+// 4 multiplies per bin less, bit-identical mel sums.
 MT3_HD void untangle_mag(const LaneConst& c, int lane, const cpx (&z)[16], const cpx* zlin, float* mag /*[1025]*/) {
   MT3_UNROLL
   for (int m = 0; m < 16; ++m) {
@@ -169,14 +185,14 @@ MT3_HD void untangle_mag(const LaneConst& c, int lane, const cpx (&z)[16], const
     const cpx a = z[m];
     const cpx zb = zlin[(kHalf - k) & (kHalf - 1)];
     const cpx b = {zb.re, -zb.im};                       // conj(Z[N/2 - k])
-    const cpx e = {0.5f * (a.re + b.re), 0.5f * (a.im + b.im)};
+    const cpx e2 = a + b;
     const cpx d = a - b;
-    const cpx o = {0.5f * d.im, -0.5f * d.re};           // -i/2 * (a - b)
-    const cpx x = e + cmul(c.twU[m], o);
-    mag[k] = MT3_FE_SQRT(x.re * x.re + x.im * x.im);
+    const cpx o2 = {d.im, -d.re};                        // -i (a - b)
+    const cpx x2 = e2 + cmul(c.twU[m], o2);
+    mag[k] = MT3_FE_SQRT(x2.re * x2.re + x2.im * x2.im);
   }
   if (lane == 0) {
-    const float v = z[0].re - z[0].im;                   // X[1024] = Re Z0 - Im Z0
+    const float v = 2.f * (z[0].re - z[0].im);           // X[1024] = Re Z0 - Im Z0
     mag[kHalf] = v < 0.f ? -v : v;
   }
 }
@@ -215,6 +231,37 @@ MT3_HD float mel_bin_fixed(const MelTables& t, int j, const float* mag) {
   }
   MT3_UNROLL
   for (int i = 0; i < MAXC; ++i) acc += mv[i] * (i < n ? wv[i] : 0.f);
+  return acc;
+}
+
+// longest band (spectrum bins per mel bin) inside each group of 64 mel bins, for the reference's mel matrix
+// (512 bins, 20 .. 7600 Hz over 1025 FFT bins); mt3_frontend_create checks the tables against it
+constexpr int kGroupMaxBand[8] = {2, 2, 3, 3, 4, 6, 8, 10};
+// offset of group I inside the padded weight table: 64 * (sum of the bounds of the groups before it)
+constexpr int group_base(int I) {
+  int b = 0;
+  for (int i = 0; i < I; ++i) b += 64 * kGroupMaxBand[i];
+  return b;
+}
+constexpr int kPaddedWeights = group_base(8);   // 64 * 38 = 2432 floats
+
+// Group-padded form of the same tables (what the kernel keeps in LDS): the bands of the 64 mel bins of group i are
+// zero-padded to the group's longest band MAXC and stored TRANSPOSED, wpad[base_i + q * 64 + (j & 63)] = weight q of
+// bin j -- no per-bin count / offset, no select per term, conflict-free lane-consecutive reads; adding the zero
+// terms leaves the sum bit-identical to mel_bin (fma(m, 0, acc) == acc).
+template <int MAXC>
+MT3_HD float mel_bin_padded(const int* k0, const float* wpad_group, int j, const float* mag) {
+  const float* m = mag + k0[j];
+  const float* w = wpad_group + (j & 63);
+  float wv[MAXC], mv[MAXC];
+  MT3_UNROLL
+  for (int i = 0; i < MAXC; ++i) {
+    wv[i] = w[i * 64];
+    mv[i] = m[i];
+  }
+  float acc = 0.f;
+  MT3_UNROLL
+  for (int i = 0; i < MAXC; ++i) acc += mv[i] * wv[i];
   return acc;
 }
 

@@ -14,6 +14,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "frontend_core.h"
+
 namespace mt3fe {
 
 struct HostTables {
@@ -23,7 +25,7 @@ struct HostTables {
   std::vector<float> tw2048;      // [1025][2]  exp(-2 pi i j/2048)
   std::vector<float> mel_dense;   // [bins][mel]
   std::vector<int32_t> k0, cnt, off;   // per mel bin: first spectrum bin, count, offset into w
-  std::vector<float> w;           // band weights, concatenated per mel bin
+  std::vector<float> w;           // band weights / 2 (exact), concatenated per mel bin: the kernel's magnitudes are 2|X|
   int64_t nnz = 0;
   int max_cnt = 0;
 };
@@ -82,13 +84,27 @@ inline HostTables build_tables(int sample_rate, int fft, int mel_bins, double lo
       t.cnt[j] = last - first + 1;
       for (int k = first; k <= last; ++k) {
         const float v = t.mel_dense[static_cast<size_t>(k) * mel_bins + j];
-        t.w.push_back(v);
+        t.w.push_back(0.5f * v);
         if (v != 0.f) ++t.nnz;
       }
       if (t.cnt[j] > t.max_cnt) t.max_cnt = t.cnt[j];
     }
   }
   return t;
+}
+
+// the kernel's form of the band weights (frontend_core.h: mel_bin_padded)
+inline bool bands_fit(const HostTables& t) {
+  if (t.mel != 512) return false;
+  for (int j = 0; j < t.mel; ++j)
+    if (t.cnt[j] > kGroupMaxBand[j / 64]) return false;
+  return true;
+}
+inline std::vector<float> build_padded_weights(const HostTables& t) {
+  std::vector<float> wpad(kPaddedWeights, 0.f);
+  for (int j = 0; j < t.mel; ++j)
+    for (int q = 0; q < t.cnt[j]; ++q) wpad[group_base(j / 64) + q * 64 + (j & 63)] = t.w[t.off[j] + q];
+  return wpad;
 }
 
 }  // namespace mt3fe

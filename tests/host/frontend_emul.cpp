@@ -13,11 +13,27 @@
 
 using mt3fe::cpx;
 
+// mel_bin_padded<MAXC> of group i (the kernel unrolls the groups at compile time)
+static float padded_bin(int i, const int* k0, const float* wp, int j, const float* mag) {
+  using namespace mt3fe;
+  switch (i) {
+    case 0: return mel_bin_padded<kGroupMaxBand[0]>(k0, wp + group_base(0), j, mag);
+    case 1: return mel_bin_padded<kGroupMaxBand[1]>(k0, wp + group_base(1), j, mag);
+    case 2: return mel_bin_padded<kGroupMaxBand[2]>(k0, wp + group_base(2), j, mag);
+    case 3: return mel_bin_padded<kGroupMaxBand[3]>(k0, wp + group_base(3), j, mag);
+    case 4: return mel_bin_padded<kGroupMaxBand[4]>(k0, wp + group_base(4), j, mag);
+    case 5: return mel_bin_padded<kGroupMaxBand[5]>(k0, wp + group_base(5), j, mag);
+    case 6: return mel_bin_padded<kGroupMaxBand[6]>(k0, wp + group_base(6), j, mag);
+    default: return mel_bin_padded<kGroupMaxBand[7]>(k0, wp + group_base(7), j, mag);
+  }
+}
+
 extern "C" int emul_logmel(const float* audio, int n_frames, int frames_per_segment, float* out) {
   static const mt3fe::HostTables T = mt3fe::build_tables(16000, 2048, 512, 20.0, 7600.0);
   const int hop = 128, G = 16, tile = G * hop + 1920;
   const int valid = n_frames * hop;
-  const mt3fe::MelTables mel{T.k0.data(), T.cnt.data(), T.off.data(), T.w.data()};
+  static const std::vector<float> WP = mt3fe::build_padded_weights(T);     // the kernel's group-padded table
+  if (!mt3fe::bands_fit(T)) return 1;
   std::vector<mt3fe::LaneConst> lc(64);
   for (int l = 0; l < 64; ++l)
     mt3fe::load_lane_const(lc[l], l, T.hann.data(), reinterpret_cast<const cpx*>(T.tw1024.data()),
@@ -43,7 +59,7 @@ extern "C" int emul_logmel(const float* audio, int n_frames, int frames_per_segm
         for (int i = 0; i < 8; ++i) {
           const int j = l + 64 * i;
           if (f < n_frames) {
-            const float m = mt3fe::mel_bin(mel, j, mag.data());
+            const float m = padded_bin(i, T.k0.data(), WP.data(), j, mag.data());
             dst[j] = logf(m <= 0.f ? 1e-5f : m);
           } else {
             dst[j] = 0.f;
