@@ -208,7 +208,9 @@ int mt3_op_encoder_attention(int32_t dtype, const void* d_qkv, void* d_out, int3
 /* single-query attention: q [B, H*64] (row stride q_stride elements) against cache K/V [B, H, cap, 64],
  * attending positions 0..n_keys-1; if d_new_kv != NULL its [B, 2, H, 64]-strided K/V rows (row stride
  * kv_stride, K at +0 and V at +H*64) are first appended at position n_keys-1.  With d_step != NULL the key
- * count is read PER ROW from device memory: n_keys = d_step[b] + 1. */
+ * count is read PER ROW from device memory: n_keys = d_step[b] + 1.  The kernel requests its first group of
+ * keys before it knows the row's length and masks what lies past it: cache rows beyond n_keys (up to `cap`) must
+ * hold FINITE values (zero-fill the cache once; the engine does). */
 int mt3_op_decode_attention(int32_t dtype, const void* d_q, int32_t q_stride, void* d_kcache, void* d_vcache,
                             int32_t cap, const void* d_new_k, const void* d_new_v, int32_t kv_stride,
                             const int32_t* d_step, int32_t n_keys, void* d_out, int32_t B, int32_t H, void* stream);

@@ -397,12 +397,23 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPK, slot = lane / LPK;
+  const CT* kc = static_cast<const CT*>(a.kcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;
+  const CT* vc = static_cast<const CT*>(a.vcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;
+  // The first group of keys is requested BEFORE the row's position counter is known (its load would otherwise sit
+  // in front of every cache load: one dependent memory round trip per launch): positions past the row's length are
+  // masked below, the memory behind them is always valid (the cache is allocated to `cap` rows and zero-filled at
+  // engine creation; whatever an earlier, longer decode left there is finite and gets weight 0).
+  u32x4 kv0[UNROLL], vv0[UNROLL];
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) {
+    const int key = min(wave * KPW + slot + u * STRIDE, a.cap - 1);
+    kv0[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + static_cast<size_t>(key) * D + sub * KPL));
+    vv0[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + static_cast<size_t>(key) * D + sub * KPL));
+  }
   const int n_keys = a.step ? (a.step[b] + 1) : a.n_keys;      // per-row position counter
   const int pos = n_keys - 1;
   const int n_cache = APPEND ? pos : n_keys;                   // keys that come from the cache
 
-  const CT* kc = static_cast<const CT*>(a.kcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;
-  const CT* vc = static_cast<const CT*>(a.vcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;
   u32x4 new_k = {0u, 0u, 0u, 0u}, new_v = {0u, 0u, 0u, 0u};
   if constexpr (APPEND) {
     // this step's K/V row: folded in below from registers, persisted for the later steps
@@ -437,16 +448,8 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
 #pragma unroll
   for (int j = 0; j < KPL; ++j) acc[j] = 0.f;
 
-  for (int base = wave * KPW; base < n_cache; base += STRIDE * UNROLL) {
-    u32x4 kv[UNROLL], vv[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int key = min(base + slot + u * STRIDE, n_cache - 1);
-      // streamed once per step by exactly one CU: non-temporal, so the K/V stream (up to 3.2 GB per
-      // step) does not evict the decoder weights / activations the GEMMs re-read from L2 / MALL
-      kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + static_cast<size_t>(key) * D + sub * KPL));
-      vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + static_cast<size_t>(key) * D + sub * KPL));
-    }
+  // one group of UNROLL x KPW x NW keys starting at `base`, already in registers
+  auto fold = [&](const u32x4 (&kv)[UNROLL], const u32x4 (&vv)[UNROLL], int base) {
     float sc[UNROLL];
     float mn = m;
 #pragma unroll
@@ -469,6 +472,19 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
     }
     l = l * rs + psum;
     m = mn;
+  };
+  if (wave * KPW < n_cache) fold(kv0, vv0, wave * KPW);
+  for (int base = wave * KPW + STRIDE * UNROLL; base < n_cache; base += STRIDE * UNROLL) {
+    u32x4 kv[UNROLL], vv[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int key = min(base + slot + u * STRIDE, n_cache - 1);
+      // streamed once per step by exactly one CU: non-temporal, so the K/V stream (up to 3.2 GB per
+      // step) does not evict the decoder weights / activations the GEMMs re-read from L2 / MALL
+      kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + static_cast<size_t>(key) * D + sub * KPL));
+      vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + static_cast<size_t>(key) * D + sub * KPL));
+    }
+    fold(kv, vv, base);
   }
   if constexpr (APPEND) {
     // the new key: one lane group of the block carries it (weight 0 everywhere else)
@@ -608,14 +624,24 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 3, slot = lane >> 2;
-  const int n_keys = a.step ? (a.step[b] + 1) : a.n_keys;
-  const int pos = n_keys - 1;
-  const int n_cache = APPEND ? pos : n_keys;
-
   const size_t head = (static_cast<size_t>(b) * a.H + h) * a.cap;
   const uint8_t* kc = static_cast<const uint8_t*>(a.kcache) + head * D;
   const uint8_t* vc = static_cast<const uint8_t*>(a.vcache) + head * D;
   const float2* sc2 = a.kv_scale + head;
+  // first key group requested before the row's position counter is known (see dec_attn_kernel): the cache and its
+  // scale array are zero-filled at engine creation, so what lies past the row's length is finite and gets weight 0
+  u32x4 kv0[UNROLL], vv0[UNROLL];
+  float2 ss0[UNROLL];
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u) {
+    const int key = min(wave * KPW + slot + u * STRIDE, a.cap - 1);
+    kv0[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + static_cast<size_t>(key) * D + sub * EPL));
+    vv0[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + static_cast<size_t>(key) * D + sub * EPL));
+    ss0[u] = sc2[key];
+  }
+  const int n_keys = a.step ? (a.step[b] + 1) : a.n_keys;
+  const int pos = n_keys - 1;
+  const int n_cache = APPEND ? pos : n_keys;
 
   // q: 16 bf16 of this lane's slice -> f32, pre-multiplied by log2(e) (base-2 softmax)
   float q[EPL];
@@ -659,16 +685,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
 #pragma unroll
   for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
 
-  for (int base = wave * KPW; base < n_cache; base += STRIDE * UNROLL) {
-    u32x4 kv[UNROLL], vv[UNROLL];
-    float2 ss[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      const int key = min(base + slot + u * STRIDE, n_cache - 1);
-      kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + static_cast<size_t>(key) * D + sub * EPL));
-      vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + static_cast<size_t>(key) * D + sub * EPL));
-      ss[u] = sc2[key];
-    }
+  auto fold = [&](const u32x4 (&kv)[UNROLL], const u32x4 (&vv)[UNROLL], const float2 (&ss)[UNROLL], int base) {
     float sc[UNROLL];
     float mn = m;
 #pragma unroll
@@ -703,6 +720,19 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
     }
     l = l * rs + psum;
     m = mn;
+  };
+  if (wave * KPW < n_cache) fold(kv0, vv0, ss0, wave * KPW);
+  for (int base = wave * KPW + STRIDE * UNROLL; base < n_cache; base += STRIDE * UNROLL) {
+    u32x4 kv[UNROLL], vv[UNROLL];
+    float2 ss[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const int key = min(base + slot + u * STRIDE, n_cache - 1);
+      kv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + static_cast<size_t>(key) * D + sub * EPL));
+      vv[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + static_cast<size_t>(key) * D + sub * EPL));
+      ss[u] = sc2[key];
+    }
+    fold(kv, vv, ss, base);
   }
   if constexpr (APPEND) {
     float d = 0.f;

@@ -637,12 +637,17 @@ int mt3_engine_finalize(mt3_engine* e) {
     const size_t kvb = static_cast<size_t>(Bm) * c.num_heads * L * 64 * e->kv_esize;
     if ((rc = dmalloc(e, &e->dec[l].self_k, kvb))) return rc;
     if ((rc = dmalloc(e, &e->dec[l].self_v, kvb))) return rc;
+    // zero-filled once: the decode-attention kernels request their first key group before they know the row's
+    // length and mask what lies past it -- those bytes must be finite (0 x NaN would poison the accumulators)
+    MT3_HIP_CHECK(hipMemset(e->dec[l].self_k, 0, kvb));
+    MT3_HIP_CHECK(hipMemset(e->dec[l].self_v, 0, kvb));
     if ((rc = dmalloc(e, &e->dec[l].cross_kv, static_cast<size_t>(2) * Bm * c.num_heads * T * 64 * e->kv_esize)))
       return rc;
     if (e->kv_fp8) {
       if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->dec[l].self_scale),
                         static_cast<size_t>(Bm) * c.num_heads * L * sizeof(float2))))
         return rc;
+      MT3_HIP_CHECK(hipMemset(e->dec[l].self_scale, 0, static_cast<size_t>(Bm) * c.num_heads * L * sizeof(float2)));
       if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->dec[l].cross_scale),
                         static_cast<size_t>(Bm) * c.num_heads * T * sizeof(float2))))
         return rc;
