@@ -69,3 +69,20 @@ def test_note_matching_vs_brute_force():
     b = NoteSequence(notes=[Note(0.03, 1.3, 60, 100), Note(1.2, 2.0, 62, 100)])
     s = metrics.transcription_scores(a, b)
     assert s["Onset F1"] == 0.5 and s["Onset + offset F1"] == 0.0 and s["Onset recall"] == 0.5
+
+
+def test_midi_bytes_of_a_one_note_sequence_follow_the_smf_specification():
+    """Pinned on the Standard MIDI File format itself, byte for byte (independent of this module's reader): header
+    MThd / length 6 / format 1 / 2 tracks / division 220; track 0 = tempo 500,000 us per quarter (120 qpm) at tick 0;
+    track 1 = program change, note-on at tick 220 (0.5 s x 220 x 120 / 60) as VLQ 0x81 0x5C, note-off 220 ticks
+    later; every track ends with FF 2F 00."""
+    ns = NoteSequence(notes=[Note(0.5, 1.0, 60, 100, 0, False, 0)], total_time=1.0)
+    want = (b"MThd" + bytes([0, 0, 0, 6, 0, 1, 0, 2, 0, 220]) +
+            b"MTrk" + bytes([0, 0, 0, 11]) + bytes([0x00, 0xFF, 0x51, 0x03, 0x07, 0xA1, 0x20, 0x00, 0xFF, 0x2F, 0x00]) +
+            b"MTrk" + bytes([0, 0, 0, 17]) +
+            bytes([0x00, 0xC0, 0x00, 0x81, 0x5C, 0x90, 0x3C, 0x64, 0x81, 0x5C, 0x80, 0x3C, 0x00, 0x00, 0xFF, 0x2F, 0x00]))
+    assert midi_io.note_sequence_to_midi_bytes(ns) == want
+    # a drum note goes to channel 9 and a note shorter than a tick still gets one tick
+    d = NoteSequence(notes=[Note(0.0, 0.0005, 38, 127, 0, True, 9)], total_time=0.01)
+    b = midi_io.note_sequence_to_midi_bytes(d)
+    assert bytes([0x00, 0x99, 0x26, 0x7F, 0x01, 0x89, 0x26, 0x00]) in b
