@@ -37,6 +37,7 @@ SEG_SECONDS = 2.048          # 256 frames * 128 hop / 16 kHz  (mt3.gin:4, spectr
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 MFMA_F32_PEAK_TFLOPS = 157.3
+MFMA_FP8_PEAK_TFLOPS = 5000.0              # dense MX-scaled fp8 (K = 128 instructions), MI355X_MICROARCH.md
 ENC_GFLOP_PER_SEGMENT = 10.603 + 1.611     # encoder + the one-off cross-K/V projections of 8 layers
 FRONTEND_BYTES_PER_SEGMENT = 655360        # 131072 in + 524288 out
 
@@ -144,6 +145,9 @@ def main():
     ap.add_argument("--kv-dtype", default="", choices=["", "fp8_e4m3"],
                     help="K/V cache format: '' = the compute dtype; fp8_e4m3 = OCP e4m3 rows + per-row scales "
                          "(BASELINE configs[4]'s fp8 path; NOT the default line: the headline stays bf16)")
+    ap.add_argument("--dense-dtype", default="", choices=["", "fp8_e4m3"],
+                    help="encoder dense layers + cross-K/V projections: '' = the compute dtype; fp8_e4m3 = MXFP8 on the "
+                         "block-scaled MFMA (BASELINE configs[4]'s fp8 MFMA path; NOT the default line)")
     ap.add_argument("--model", default="mt3", choices=["mt3", "base"],
                     help="mt3 = gin/model.gin (configs[1..3]); base = gin/ismir2022/base.gin shape (configs[4])")
     ap.add_argument("--chains", type=int, default=1,
@@ -199,7 +203,7 @@ def main():
     n_global = corpus if corpus else args.batch * world
     import dataclasses
     shape = network.MT3_BASE if args.model == "base" else network.MT3_SMALL
-    cfg = dataclasses.replace(shape, dtype=args.dtype, kv_dtype=args.kv_dtype)
+    cfg = dataclasses.replace(shape, dtype=args.dtype, kv_dtype=args.kv_dtype, dense_dtype=args.dense_dtype)
     eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, decode_chains=args.chains)
     eng.load_params(network.init_random_params(cfg, seed=0))
     codec = vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1))
@@ -371,7 +375,7 @@ def main():
                 "cross_attn": {"achieved": cross_bytes / launches / (cross_us * 1e-6) / 1e9, "avg_launch_us": cross_us,
                                "algorithmic_bytes_per_launch": cross_bytes / launches}}
 
-        if not args.no_extras and not corpus and args.model == "mt3" and not args.kv_dtype:
+        if not args.no_extras and not corpus and args.model == "mt3" and not args.kv_dtype and not args.dense_dtype:
             # ---- stage extras, driver-timed (HIP events on the launch stream, inputs in HBM)
             peak = MFMA_BF16_PEAK_TFLOPS if esize == 2 else MFMA_F32_PEAK_TFLOPS
             a256 = audio[:Br]
@@ -434,13 +438,15 @@ def main():
                     extras["f32"] = {"value": None, "error": repr(ex)[:300]}
 
             # ---- BASELINE configs[4] ingredients, one warm-up + one timed step each (not the headline):
-            #   fp8_kv : this workload with e4m3 K/V caches (half the bytes of the HBM-bound decode stream)
-            #   configs4: the ismir2022/base.gin shape (emb 768, 12 heads, 12+12 layers, mlp 2048) with e4m3 K/V caches
+            #   fp8_kv    : this workload with e4m3 K/V caches (half the bytes of the HBM-bound decode stream)
+            #   fp8_kv_mx8: the same plus the encoder's dense layers / cross-K/V projections as MXFP8 on the scaled MFMA
+            #   configs4  : the ismir2022/base.gin shape (emb 768, 12 heads, 12+12 layers, mlp 2048) with both
             if args.dtype == "bfloat16" and world == 1:
-                for key, shp, label in (("fp8_kv", network.MT3_SMALL, "MT3 (model.gin) shape"),
-                                        ("configs4", network.MT3_BASE, "ismir2022/base.gin shape")):
+                for key, shp, dense, label in (("fp8_kv", network.MT3_SMALL, "", "MT3 (model.gin) shape"),
+                                               ("fp8_kv_mx8", network.MT3_SMALL, "fp8_e4m3", "MT3 (model.gin) shape"),
+                                               ("configs4", network.MT3_BASE, "fp8_e4m3", "ismir2022/base.gin shape")):
                     try:
-                        c8 = dataclasses.replace(shp, dtype="bfloat16", kv_dtype="fp8_e4m3")
+                        c8 = dataclasses.replace(shp, dtype="bfloat16", kv_dtype="fp8_e4m3", dense_dtype=dense)
                         e8 = network.Transformer(c8, input_length=256, max_decode_length=L, max_batch=Br)
                         e8.load_params(network.init_random_params(c8, seed=0))
                         with torch.cuda.stream(stream):
@@ -456,11 +462,20 @@ def main():
                             f.result()
                         torch.cuda.synchronize()
                         d8 = time.perf_counter() - t1
+                        e8_ms = min(timed(lambda: e8.encode(lm256), reps=5) for _ in range(2))
                         extras[key] = {"value": Br * SEG_SECONDS / d8, "unit": "audio-s/s", "ms_per_step": d8 * 1e3,
-                                       "steps": 1, "dtype": "bf16 compute + fp8 (e4m3) K/V caches",
+                                       "steps": 1, "dtype": "bf16 compute + fp8 (e4m3) K/V caches" +
+                                                            (" + MXFP8 encoder dense layers" if dense else ""),
                                        "workload": "%s, batch=%d, %d greedy steps, same pipeline as the headline"
                                                    % (label, Br, args.decode_steps),
-                                       "device_bytes": e8.device_bytes}
+                                       "encoder_ms": e8_ms, "device_bytes": e8.device_bytes}
+                        if key == "fp8_kv_mx8":
+                            tf8 = ENC_GFLOP_PER_SEGMENT * Br / (e8_ms * 1e-3) / 1e3
+                            extras["encoder_mx8"] = {"segments": Br, "ms": e8_ms, "bound": "mfma", "achieved": tf8,
+                                                     "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                     "frac": tf8 / MFMA_FP8_PEAK_TFLOPS,
+                                                     "note": "encoder + cross-K/V projections with MXFP8 operands "
+                                                             "(v_mfma_scale_f32_16x16x128_f8f6f4); attention stays bf16"}
                         del e8
                     except Exception as ex:
                         extras[key] = {"value": None, "error": repr(ex)[:300]}
@@ -485,7 +500,8 @@ def main():
             "value": value, "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "strong" if corpus else "weak",
             "vs_baseline": None,
-            "dtype": ("bf16" if args.dtype == "bfloat16" else "f32") + ("+fp8kv" if args.kv_dtype else ""),
+            "dtype": ("bf16" if args.dtype == "bfloat16" else "f32") + ("+fp8kv" if args.kv_dtype else "") +
+                     ("+mxfp8 encoder" if args.dense_dtype else ""),
             "data": "synthetic",
             "config": {"workload": workload,
                        "segments_per_gpu": n_local, "segments_total": n_global, "decode_steps": args.decode_steps,

@@ -85,7 +85,7 @@ int mt3_frontend_logmel_dev(mt3_frontend* fe, const float* d_audio, int32_t n_se
  * models.ContinuousInputsEncoderDecoderModel (mt3/models.py:121-152):
  * encode once, cross-K/V once, then up to `max_decode_len` cached decode steps.
  */
-typedef enum mt3_dtype { MT3_BF16 = 0, MT3_F32 = 1, MT3_FP8_E4M3 = 2 /* K/V caches only: OCP e4m3fn */ } mt3_dtype;
+typedef enum mt3_dtype { MT3_BF16 = 0, MT3_F32 = 1, MT3_FP8_E4M3 = 2 /* K/V caches and the encoder's dense layers only: OCP e4m3fn */ } mt3_dtype;
 
 typedef struct mt3_engine_config {   /* network.T5Config (network.py:25-41), model.gin:47-59 */
   int32_t vocab_size;           /* 1536 (mt3) / 1664 (ismir2021): vocabularies.num_embeddings */
@@ -106,6 +106,12 @@ typedef struct mt3_engine_config {   /* network.T5Config (network.py:25-41), mod
                                    cross-attention K/V rows are cached as OCP e4m3 bytes + one power-of-two scale per
                                    (row, head, position) -- half the bytes the HBM-bound decode step streams
                                    (BASELINE configs[4] "fp8 path"; tolerances in DESIGN.md section 4) */
+  int32_t dense_dtype;          /* 0: every dense layer in the compute dtype.  MT3_FP8_E4M3 (with MT3_BF16 compute): the
+                                   ENCODER's dense layers and the cross-attention K/V projections (the MFMA-bound 99 % of
+                                   the encoder's FLOPs) run as MXFP8 -- e4m3 operands with one E8M0 scale per 32 K
+                                   elements on v_mfma_scale_f32_16x16x128_f8f6f4, weights quantised once at finalize,
+                                   activations by the producing epilogue; the decode step's M = batch GEMMs stay bf16
+                                   (they are launch-latency-bound) */
 } mt3_engine_config;
 
 typedef struct mt3_engine mt3_engine;
@@ -172,7 +178,8 @@ int mt3_engine_decode_forced(mt3_engine* e, int32_t batch, int32_t num_steps, in
  * LAST_DECODE_USED_GRAPH: 1/0 for the most recent decode; RESIDUAL_SPLIT: 1 if the bf16 decode loop carries the
  * residual rows as f32 + bf16 copy + partial sums of squares. */
 enum { MT3_STATUS_GRAPH_FALLBACKS = 0, MT3_STATUS_LAST_DECODE_USED_GRAPH = 1, MT3_STATUS_RESIDUAL_SPLIT = 2,
-       MT3_STATUS_KV_FP8 = 3, MT3_STATUS_Q_FOLD = 4 /* cross q-projection folded into the neighbouring launches */ };
+       MT3_STATUS_KV_FP8 = 3, MT3_STATUS_Q_FOLD = 4 /* cross q-projection folded into the neighbouring launches */,
+       MT3_STATUS_DENSE_FP8 = 5 /* encoder dense layers on the MXFP8 path */ };
 int mt3_engine_status(const mt3_engine* e, int32_t what);
 
 /* GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271): -1 from the
@@ -223,6 +230,25 @@ int mt3_op_decode_attention_fp8(const void* d_q, int32_t q_stride, void* d_kcach
                                 void* stream);
 /* d_src bf16 [2][rows][64] (K rows, then V rows) -> d_dst e4m3 [2][rows][64] + d_scales [rows] f32 pairs */
 int mt3_op_kv_quantize_fp8(const void* d_src, void* d_dst, void* d_scales, int32_t rows, void* stream);
+
+/* MXFP8 dense path (dense_dtype MT3_FP8_E4M3; no counterpart in the reference, whose DenseGeneral is f32,
+ * mt3/layers.py:311-360): operands are OCP e4m3fn bytes [rows][K] with one E8M0 power-of-two scale per 32 consecutive
+ * K elements [rows][K/32]: scale = 2^(floor(log2 amax) - 7), so amax / scale lies in [128, 256) and nothing
+ * saturates; elements are rounded to nearest even.  mt3_host_mx8_quantize is the host (weight) side of that rule,
+ * mt3_op_mx8_quantize the device (activation) side: in_is_f32 ? f32 : bf16 rows [M][K], K a multiple of 64;
+ * d_ss (f32 input only, may be NULL) receives the per-16-column sums of squares [M][K/16]. */
+int mt3_host_mx8_quantize(const float* h_w, int64_t rows, int64_t K, uint8_t* h_q, uint8_t* h_sc);
+int mt3_op_mx8_quantize(const void* d_in, int32_t in_is_f32, int32_t M, int32_t K, uint8_t* d_q, uint8_t* d_sc,
+                        float* d_ss, void* stream);
+/* out = epilogue( [rms] * A[M,K] @ W[N,K]^T ) on v_mfma_scale_f32_16x16x128_f8f6f4, f32 accumulation; K and N
+ * multiples of 128.  d_a_ss != NULL: fused RMSNorm from the [M][K/16] sums of squares of the rows A was quantised
+ * from (K <= 1024).  epilogue: MT3_EPI_STORE (bf16 d_out [M][N]), MT3_EPI_HEADS (bf16 [2][B][H][seq_len][64]),
+ * MT3_EPI_RESID (f32 d_out [M][N] += product; the updated rows also leave as MXFP8 d_out_q / d_out_sc and their
+ * per-16-column sums of squares d_out_ss), MT3_EPI_GEGLU (W rows interleaved gate/linear in 16s as for mt3_op_gemm;
+ * the result gelu(gate) * linear leaves ONLY as MXFP8 d_out_q [M][N/2] / d_out_sc [M][N/64]). */
+int mt3_op_gemm_mx8(const uint8_t* d_A, const uint8_t* d_a_sc, const uint8_t* d_W, const uint8_t* d_w_sc, void* d_out,
+                    int32_t M, int32_t N, int32_t K, int32_t epilogue, int32_t seq_len, const float* d_a_ss,
+                    uint8_t* d_out_q, uint8_t* d_out_sc, float* d_out_ss, void* stream);
 
 /* --------------------------------------------------- symbolic stage (host CPU)
  * Replaces metrics_utils.event_predictions_to_ns (mt3/metrics_utils.py:59-146) =

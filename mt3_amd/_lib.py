@@ -17,7 +17,8 @@ MT3_OK, MT3_ERR_INVALID, MT3_ERR_HIP, MT3_ERR_CAPACITY, MT3_ERR_MISSING = 0, -1,
 MT3_BF16, MT3_F32, MT3_FP8_E4M3 = 0, 1, 2
 EPI_STORE, EPI_RESID, EPI_GEGLU, EPI_POS, EPI_F32, EPI_HEADS = range(6)
 DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SKIP_SELF_ATTN, DECODE_SKIP_CROSS_ATTN = 1, 2, 4, 8, 16
-STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8, STATUS_Q_FOLD = range(5)
+(STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8, STATUS_Q_FOLD,
+ STATUS_DENSE_FP8) = range(6)
 EV_SHIFT, EV_PITCH, EV_VELOCITY, EV_TIE, EV_PROGRAM, EV_DRUM = range(6)
 EVENT_TYPE_NAMES = ("shift", "pitch", "velocity", "tie", "program", "drum")
 SPEC_ONSETS, SPEC_NOTES, SPEC_TIES = range(3)
@@ -38,7 +39,7 @@ class EngineConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "vocab_size", "emb_dim", "num_heads", "head_dim", "mlp_dim", "num_encoder_layers",
         "num_decoder_layers", "input_depth", "input_length", "max_decode_len", "max_batch", "compute_dtype",
-        "decode_chains", "kv_cache_dtype")]
+        "decode_chains", "kv_cache_dtype", "dense_dtype")]
 
 
 class EventRange(C.Structure):
@@ -86,6 +87,10 @@ SIGNATURES = {
     "mt3_op_decode_attention_fp8": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, C.c_int32, _P, C.c_int32,
                                               _P, C.c_int32, C.c_int32, _P]),
     "mt3_op_kv_quantize_fp8": (C.c_int, [_P, _P, _P, C.c_int32, _P]),
+    "mt3_host_mx8_quantize": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P]),
+    "mt3_op_mx8_quantize": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "mt3_op_gemm_mx8": (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
+                                  _P, _P]),
     "mt3_build_codec": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(CodecDesc)]),
     "mt3_codec_num_classes": (C.c_int, [C.POINTER(CodecDesc)]),
     "mt3_codec_decode_event": (C.c_int, [C.POINTER(CodecDesc), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

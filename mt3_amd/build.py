@@ -17,8 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmt3hip.so")
 OBJ = os.path.join(ROOT, "build", "obj")
 
-HIP_SOURCES = ["frontend.hip", "gemm.hip", "attention.hip", "decode_ops.hip", "engine.hip"]
-CPP_SOURCES = ["errors.cpp", "symbolic.cpp"]
+HIP_SOURCES = ["frontend.hip", "gemm.hip", "gemm_mx8.hip", "attention.hip", "decode_ops.hip", "engine.hip"]
+CPP_SOURCES = ["errors.cpp", "symbolic.cpp", "mx8_host.cpp"]
 
 
 def _hipcc() -> str:

@@ -70,6 +70,9 @@ struct LayerDev {
   void* self_k = nullptr;    // decoder [Bm][H][L][64]
   void* self_v = nullptr;
   void* cross_kv = nullptr;  // decoder [2][B][H][T][64]
+  // MXFP8 dense path (dense_dtype MT3_FP8_E4M3): the same matrices as e4m3 bytes + E8M0 block scales [rows][K / 32]
+  uint8_t *wqkv_q = nullptr, *wqkv_sc = nullptr, *wo_q = nullptr, *wo_sc = nullptr, *wi_q = nullptr, *wi_sc = nullptr,
+          *wo_mlp_q = nullptr, *wo_mlp_sc = nullptr, *wkv_x_q = nullptr, *wkv_x_sc = nullptr;
   // fp8 (e4m3) K/V caches only: {k_scale, v_scale} per cached row
   float2* self_scale = nullptr;    // [Bm][H][L]
   float2* cross_scale = nullptr;   // [B][H][T]
@@ -87,6 +90,12 @@ struct mt3_engine {
   int kv_esize = 2;              // bytes per cached K/V element: esize, or 1 with the fp8 (e4m3) caches
   bool kv_fp8 = false;
   void* cross_stage = nullptr;   // fp8 caches: bf16 [2][Bm][H][T][64] landing buffer of the cross-K/V GEMM (one layer)
+  // MXFP8 encoder (gemm_mx8.hip): every GEMM operand of the encoder as e4m3 + E8M0 block scales
+  bool dense_fp8 = false;
+  uint8_t *x_q = nullptr, *x_sc = nullptr;         // residual rows [M][emb], written by the RESID epilogues
+  uint8_t *attn_q = nullptr, *attn_sc = nullptr;   // attention output [M][HD]
+  uint8_t *h_q = nullptr, *h_sc = nullptr;         // GEGLU output [M][mlp], written by the GEGLU epilogue
+  uint8_t *enc_q = nullptr, *enc_sc = nullptr;     // normed encoder output [M][emb] (A of the cross-K/V projections)
 
   void* enc_in = nullptr;        // [emb][input_depth]
   float* enc_norm = nullptr;     // [emb] f32
@@ -175,6 +184,19 @@ int upload_ct(mt3_engine* e, const std::vector<float>& h, void** d) {
   return MT3_OK;
 }
 
+// upload a host f32 matrix [rows][K] as MXFP8 (only when the engine runs the MXFP8 dense path)
+int upload_mx8(mt3_engine* e, const std::vector<float>& h, int64_t rows, int64_t K, uint8_t** q, uint8_t** sc) {
+  if (!e->dense_fp8) return MT3_OK;
+  std::vector<uint8_t> hq(h.size()), hs(static_cast<size_t>(rows) * (K / 32));
+  int rc = mt3_host_mx8_quantize(h.data(), rows, K, hq.data(), hs.data());
+  if (rc) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(q), hq.size()))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(sc), hs.size()))) return rc;
+  MT3_HIP_CHECK(hipMemcpy(*q, hq.data(), hq.size(), hipMemcpyHostToDevice));
+  MT3_HIP_CHECK(hipMemcpy(*sc, hs.data(), hs.size(), hipMemcpyHostToDevice));
+  return MT3_OK;
+}
+
 int upload_f32(mt3_engine* e, const std::vector<float>& h, float** d) {
   int rc = dmalloc(e, reinterpret_cast<void**>(d), h.size() * 4);
   if (rc) return rc;
@@ -208,7 +230,8 @@ void put_transposed(std::vector<float>& dst, int in, int row0, const HostWeight&
   }
 }
 
-int build_attention(mt3_engine* e, const std::string& prefix, const float* scale, bool cross, LayerDev* L) {
+int build_attention(mt3_engine* e, const std::string& prefix, const float* scale, bool cross, LayerDev* L,
+                    bool encoder = false) {
   const int emb = e->cfg.emb_dim, hd = e->HD();
   const HostWeight *q = find(e, prefix + "/query/kernel", emb, hd), *k = find(e, prefix + "/key/kernel", emb, hd),
                    *v = find(e, prefix + "/value/kernel", emb, hd), *o = find(e, prefix + "/out/kernel", hd, emb);
@@ -223,6 +246,10 @@ int build_attention(mt3_engine* e, const std::string& prefix, const float* scale
     put_transposed(t, emb, 2 * hd, *v, scale);
     if ((rc = upload_ct(e, t, &L->wqkv))) return rc;
     if ((rc = upload_ct(e, ot, &L->wo))) return rc;
+    if (encoder) {
+      if ((rc = upload_mx8(e, t, 3 * hd, emb, &L->wqkv_q, &L->wqkv_sc))) return rc;
+      if ((rc = upload_mx8(e, ot, emb, hd, &L->wo_q, &L->wo_sc))) return rc;
+    }
   } else {
     std::vector<float> tq(static_cast<size_t>(hd) * emb), tkv(static_cast<size_t>(2) * hd * emb);
     put_transposed(tq, emb, 0, *q, scale);         // query side sees the pre_cross_attention norm
@@ -230,6 +257,7 @@ int build_attention(mt3_engine* e, const std::string& prefix, const float* scale
     put_transposed(tkv, emb, hd, *v, nullptr);
     if ((rc = upload_ct(e, tq, &L->wq_x))) return rc;
     if ((rc = upload_ct(e, tkv, &L->wkv_x))) return rc;
+    if ((rc = upload_mx8(e, tkv, 2 * hd, emb, &L->wkv_x_q, &L->wkv_x_sc))) return rc;
     if ((rc = upload_ct(e, ot, &L->wo_x))) return rc;
   }
   return MT3_OK;
@@ -267,7 +295,7 @@ int build_q_fold(mt3_engine* e, const std::string& P, const float* s1, const flo
   return upload_ct(e, u, &L->wo_ext);
 }
 
-int build_mlp(mt3_engine* e, const std::string& prefix, const float* scale, LayerDev* L) {
+int build_mlp(mt3_engine* e, const std::string& prefix, const float* scale, LayerDev* L, bool encoder = false) {
   const int emb = e->cfg.emb_dim, mlp = e->cfg.mlp_dim;
   const HostWeight *w0 = find(e, prefix + "/wi_0/kernel", emb, mlp), *w1 = find(e, prefix + "/wi_1/kernel", emb, mlp),
                    *wo = find(e, prefix + "/wo/kernel", mlp, emb);
@@ -286,6 +314,10 @@ int build_mlp(mt3_engine* e, const std::string& prefix, const float* scale, Laye
   put_transposed(ot, mlp, 0, *wo, nullptr);
   int rc;
   if ((rc = upload_ct(e, t, &L->wi))) return rc;
+  if (encoder) {
+    if ((rc = upload_mx8(e, t, 2 * mlp, emb, &L->wi_q, &L->wi_sc))) return rc;
+    if ((rc = upload_mx8(e, ot, emb, mlp, &L->wo_mlp_q, &L->wo_mlp_sc))) return rc;
+  }
   return upload_ct(e, ot, &L->wo_mlp);
 }
 
@@ -545,9 +577,14 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: kv_cache_dtype must be 0 (= compute dtype) or MT3_FP8_E4M3");
   if (cfg->kv_cache_dtype == MT3_FP8_E4M3 && cfg->compute_dtype != MT3_BF16)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the fp8 K/V caches go with compute_dtype MT3_BF16");
+  if (cfg->dense_dtype != 0 && cfg->dense_dtype != MT3_FP8_E4M3)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: dense_dtype must be 0 (= compute dtype) or MT3_FP8_E4M3");
+  if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
   e->cfg = *cfg;
+  e->dense_fp8 = cfg->dense_dtype == MT3_FP8_E4M3;
   e->esize = cfg->compute_dtype == MT3_BF16 ? 2 : 4;
   e->kv_fp8 = cfg->kv_cache_dtype == MT3_FP8_E4M3;
   e->kv_esize = e->kv_fp8 ? 1 : e->esize;
@@ -606,8 +643,8 @@ int mt3_engine_finalize(mt3_engine* e) {
     const float* s1 = scale_of(e, P + "/pre_attention_layer_norm/scale");
     const float* s2 = scale_of(e, P + "/pre_mlp_layer_norm/scale");
     if (!s1 || !s2) return MT3_ERR_MISSING;
-    if ((rc = build_attention(e, P + "/attention", s1, false, &e->enc[l]))) return rc;
-    if ((rc = build_mlp(e, P + "/mlp", s2, &e->enc[l]))) return rc;
+    if ((rc = build_attention(e, P + "/attention", s1, false, &e->enc[l], true))) return rc;
+    if ((rc = build_mlp(e, P + "/mlp", s2, &e->enc[l], true))) return rc;
   }
   {
     const HostWeight* w = find(e, "encoder/encoder_norm/scale", emb, -1);
@@ -678,10 +715,21 @@ int mt3_engine_finalize(mt3_engine* e) {
   // ---- workspaces
   const size_t M = static_cast<size_t>(Bm) * T;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x), M * emb * 4))) return rc;
-  e->x_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && emb <= 1024 && !getenv("MT3_NO_X_SPLIT");
+  e->x_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && emb <= 1024 && !getenv("MT3_NO_X_SPLIT") && !e->dense_fp8;
   if (e->x_split) {
     if ((rc = dmalloc(e, &e->x_ct, M * emb * 2))) return rc;
     if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x_ss), M * (emb / 16) * 4))) return rc;
+  }
+  if (e->dense_fp8) {
+    if (!e->x_ss && (rc = dmalloc(e, reinterpret_cast<void**>(&e->x_ss), M * (emb / 16) * 4))) return rc;
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x_q), M * emb))) return rc;
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x_sc), M * (emb / 32)))) return rc;
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->attn_q), M * hd))) return rc;
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->attn_sc), M * (hd / 32)))) return rc;
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->h_q), M * c.mlp_dim))) return rc;
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->h_sc), M * (c.mlp_dim / 32)))) return rc;
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->enc_q), M * emb))) return rc;
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->enc_sc), M * (emb / 32)))) return rc;
   }
   if ((rc = dmalloc(e, &e->qkv, M * 3 * hd * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->attn, M * hd * e->esize))) return rc;
@@ -735,6 +783,65 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
     g.aux = e->pos_table;
     g.seq_len = T;
     MT3_TRY(mt3k::launch_gemm(dt, g, true, false, MT3_EPI_POS, small, s));
+  }
+  if (e->dense_fp8) {
+    // MXFP8 encoder: x travels as f32 rows + e4m3/E8M0 copy + per-16-column sums of squares; every GEMM operand is
+    // MXFP8, written in that form by its producer (the quantiser below, the RESID / GEGLU epilogues)
+    auto mx = [&](const uint8_t* A, const uint8_t* a_sc, const uint8_t* W, const uint8_t* w_sc, int N, int K) {
+      mt3k::Mx8Args g{};
+      g.A = A;
+      g.a_sc = a_sc;
+      g.W = W;
+      g.w_sc = w_sc;
+      g.M = M;
+      g.N = N;
+      g.K = K;
+      g.ldo = N;
+      return g;
+    };
+    auto resid = [&](const uint8_t* A, const uint8_t* a_sc, const uint8_t* W, const uint8_t* w_sc, int K) {
+      mt3k::Mx8Args g = mx(A, a_sc, W, w_sc, emb, K);
+      g.out = e->x;
+      g.out_q = e->x_q;
+      g.out_sc = e->x_sc;
+      g.out_ss = e->x_ss;
+      return mt3k::launch_gemm_mx8(g, MT3_EPI_RESID, s);
+    };
+    MT3_TRY(mt3k::launch_mx8_quantize(e->x, true, M, emb, e->x_q, e->x_sc, e->x_ss, s));
+    for (int l = 0; l < c.num_encoder_layers; ++l) {
+      LayerDev& L = e->enc[l];
+      {
+        mt3k::Mx8Args g = mx(e->x_q, e->x_sc, L.wqkv_q, L.wqkv_sc, 3 * hd, emb);
+        g.out = e->qkv;
+        g.a_ss = e->x_ss;
+        MT3_TRY(mt3k::launch_gemm_mx8(g, MT3_EPI_STORE, s));
+      }
+      MT3_TRY(mt3k::launch_encoder_attention(dt, e->qkv, e->attn, batch, T, c.num_heads, s));
+      MT3_TRY(mt3k::launch_mx8_quantize(e->attn, false, M, hd, e->attn_q, e->attn_sc, nullptr, s));
+      MT3_TRY(resid(e->attn_q, e->attn_sc, L.wo_q, L.wo_sc, hd));
+      {
+        mt3k::Mx8Args g = mx(e->x_q, e->x_sc, L.wi_q, L.wi_sc, 2 * c.mlp_dim, emb);
+        g.ldo = c.mlp_dim;
+        g.a_ss = e->x_ss;
+        g.out_q = e->h_q;
+        g.out_sc = e->h_sc;
+        MT3_TRY(mt3k::launch_gemm_mx8(g, MT3_EPI_GEGLU, s));
+      }
+      MT3_TRY(resid(e->h_q, e->h_sc, L.wo_mlp_q, L.wo_mlp_sc, c.mlp_dim));
+    }
+    MT3_TRY(mt3k::launch_rmsnorm(dt, e->x, e->enc_norm, e->enc_out, d_encoded_f32, M, emb, s));
+    MT3_TRY(mt3k::launch_mx8_quantize(e->enc_out, false, M, emb, e->enc_q, e->enc_sc, nullptr, s));
+    for (int l = 0; l < c.num_decoder_layers; ++l) {
+      mt3k::Mx8Args g = mx(e->enc_q, e->enc_sc, e->dec[l].wkv_x_q, e->dec[l].wkv_x_sc, 2 * hd, emb);
+      g.out = e->kv_fp8 ? e->cross_stage : e->dec[l].cross_kv;
+      g.seq_len = T;
+      MT3_TRY(mt3k::launch_gemm_mx8(g, MT3_EPI_HEADS, s));
+      if (e->kv_fp8)
+        MT3_TRY(mt3k::launch_kv_quantize_fp8(e->cross_stage, e->dec[l].cross_kv, e->dec[l].cross_scale,
+                                             batch * c.num_heads * T, s));
+    }
+    e->cur_batch = batch;
+    return MT3_OK;
   }
   const bool xs = e->x_split;
   if (xs) MT3_TRY(mt3k::launch_residual_split(e->x, e->x_ct, e->x_ss, M, emb, s));
@@ -860,6 +967,7 @@ int mt3_engine_status(const mt3_engine* e, int32_t what) {
     case MT3_STATUS_LAST_DECODE_USED_GRAPH: return e->last_used_graph;
     case MT3_STATUS_RESIDUAL_SPLIT: return e->y_split ? 1 : 0;
     case MT3_STATUS_KV_FP8: return e->kv_fp8 ? 1 : 0;
+    case MT3_STATUS_DENSE_FP8: return e->dense_fp8 ? 1 : 0;
     case MT3_STATUS_Q_FOLD: return e->q_fold ? 1 : 0;
     default: return mt3::fail(MT3_ERR_INVALID, "mt3_engine_status: unknown item");
   }

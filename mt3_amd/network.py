@@ -34,6 +34,8 @@ class T5Config:
     logits_via_embedding: bool = False
     input_depth: int = 512           # spectrograms.input_depth
     kv_dtype: str = ""               # "" = K/V caches in `dtype`; "fp8_e4m3" (with bfloat16): e4m3 rows + per-row scales
+    dense_dtype: str = ""            # "" = dense layers in `dtype`; "fp8_e4m3" (with bfloat16): the encoder's dense layers and
+                                     # the cross-K/V projections as MXFP8 (e4m3 + one E8M0 scale per 32 K) on the scaled MFMA
 
 
 MT3_SMALL = T5Config()                                           # model.gin / ismir2022/small.gin
@@ -119,12 +121,15 @@ class Transformer:
             raise ValueError("T5Config.dtype must be 'bfloat16' or 'float32'")
         if config.kv_dtype not in ("", "fp8_e4m3") or (config.kv_dtype and config.dtype != "bfloat16"):
             raise ValueError("T5Config.kv_dtype must be '' or 'fp8_e4m3' (the latter with dtype 'bfloat16')")
+        if config.dense_dtype not in ("", "fp8_e4m3") or (config.dense_dtype and config.dtype != "bfloat16"):
+            raise ValueError("T5Config.dense_dtype must be '' or 'fp8_e4m3' (the latter with dtype 'bfloat16')")
         self._lib = _lib.load()
         ec = _lib.EngineConfig(config.vocab_size, config.emb_dim, config.num_heads, config.head_dim, config.mlp_dim,
                                config.num_encoder_layers, config.num_decoder_layers, config.input_depth,
                                input_length, max_decode_length, max_batch,
                                _lib.MT3_BF16 if config.dtype == "bfloat16" else _lib.MT3_F32, decode_chains,
-                               _lib.MT3_FP8_E4M3 if config.kv_dtype == "fp8_e4m3" else 0)
+                               _lib.MT3_FP8_E4M3 if config.kv_dtype == "fp8_e4m3" else 0,
+                               _lib.MT3_FP8_E4M3 if config.dense_dtype == "fp8_e4m3" else 0)
         self._ec = ec
         self._h = None
         self._create()

@@ -1,0 +1,48 @@
+"""Host (weight) side of the MXFP8 dense path, on CPU: mt3_host_mx8_quantize against the torch.float8_e4m3fn emulation
+of the format (tests/mx8_ref.py) -- normal values, subnormal e4m3 results, ties, zero blocks, huge and tiny blocks."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from mt3_amd import _lib
+from tests import mx8_ref
+
+
+def _host(x: np.ndarray):
+    rows, K = x.shape
+    q = np.empty((rows, K), np.uint8)
+    sc = np.empty((rows, K // 32), np.uint8)
+    _lib.check(_lib.load().mt3_host_mx8_quantize(x.ctypes.data_as(C.c_void_p), rows, K, q.ctypes.data_as(C.c_void_p),
+                                                 sc.ctypes.data_as(C.c_void_p)))
+    return torch.from_numpy(q), torch.from_numpy(sc)
+
+
+def test_host_quantiser_matches_the_e4m3_emulation():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(64, 512, generator=g)
+    x[:, ::3] *= torch.exp(3 * torch.randn(64, 171, generator=g))       # wide dynamic range inside the blocks
+    x[3, 32:64] = 0.0                                                   # an all-zero block
+    x[4, :32] *= 1e30                                                   # a huge block
+    x[5, :32] *= 1e-30                                                  # a tiny one
+    x[6, 0] = 448.0
+    x[6, 1:32] = torch.linspace(0.0, 447.9, 31)
+    # exact ties of the 3-bit mantissa (k + 0.5) / 8 at amax 128: must go to even
+    x[7, :32] = torch.tensor([128.0] + [(8 + k + 0.5) / 8 for k in range(31)])
+    q, sc = _host(np.ascontiguousarray(x.numpy()))
+    rq, rsc = mx8_ref.quantize(x)
+    assert torch.equal(sc, rsc)
+    assert mx8_ref.same_values(q, rq)
+    # the format's promise: |x - dequant| <= 2^-4 |x| for e4m3 normals, and nothing saturated
+    d = mx8_ref.dequantize(q, sc)
+    blk = d.reshape(64, 16, 32).abs().amax(-1) / torch.ldexp(torch.ones(64, 16, dtype=torch.float64), sc.int() - 127)
+    assert float(blk.max()) <= 256.0 and float(blk[blk > 0].min()) >= 128.0
+    big = (x.abs().double() >= d.reshape(64, 16, 32).abs().amax(-1).repeat_interleave(32, 1) * 2.0 ** -13) & (x != 0)
+    assert float(((d - x.double()).abs()[big] / x.abs().double()[big]).max()) <= 2.0 ** -4 + 1e-12
+
+
+def test_host_quantiser_rejects_ragged_blocks():
+    x = np.zeros((2, 48), np.float32)
+    with pytest.raises(_lib.Mt3Error):
+        _host(x)

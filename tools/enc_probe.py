@@ -1,5 +1,6 @@
 """Encoder probe (GPU): run-to-run determinism of encode(), split-vs-single decode residual stream agreement, and
-HIP-event timing of encode at B=256 (for rocprofv3 --kernel-trace --stats runs of the encoder alone)."""
+HIP-event timing of encode at B=256 (for rocprofv3 --kernel-trace --stats runs of the encoder alone).
+PROBE_DENSE=fp8_e4m3 runs the MXFP8 encoder."""
 import os
 import sys
 
@@ -10,7 +11,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mt3_amd import network, spectrograms, synthetic  # noqa: E402
 
 B = int(os.environ.get("PROBE_B", "256"))
-cfg = network.T5Config(dtype="bfloat16")
+import dataclasses  # noqa: E402
+cfg = dataclasses.replace(network.T5Config(dtype="bfloat16"), dense_dtype=os.environ.get("PROBE_DENSE", ""))   # "fp8_e4m3": MXFP8 encoder
 params = network.init_random_params(cfg, seed=0, norm_scale_jitter=0.2)
 eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=B)
 eng.load_params(params)

@@ -16,3 +16,12 @@ for t in frontend_probe attn_probe; do
 done
 wait
 ls build/micro/
+# the MXFP8 encoder GEMM: complete / parts left out, ring depth 2 and 3
+rm -f build/micro/mx8_probe_*
+for v in ${MX8:-0:2 0:3 1:2 2:2 4:2 6:2}; do
+  IFS=: read -r p ns <<< "$v"
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -DMT3_MX8_PROBE=$p -DMT3_MX8_NS=$ns -I include -I mt3_amd/csrc \
+    tools/micro/mx8_probe.hip mt3_amd/csrc/errors.cpp mt3_amd/csrc/mx8_host.cpp -o build/micro/mx8_probe_p${p}_ns${ns} &
+done
+wait
+ls build/micro/
