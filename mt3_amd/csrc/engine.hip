@@ -36,6 +36,7 @@
 
 #include "common.h"
 #include "kernels.h"
+#include "mx8.h"
 #include "mt3_hip.h"
 
 namespace {

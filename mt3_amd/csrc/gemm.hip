@@ -475,10 +475,12 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   // norm 2: request this thread's tile row's partial sums now, fold them after the K loop
   // (unconditional loads from always-valid addresses: a per-element "load or zero" select makes hipcc branch around
   // every load and wait for each one)
+  // (the RESID epilogue never carries a row scale: no partial sums, their registers go to its residual prefetch)
+  constexpr bool kMayScale = EPI != MT3_EPI_RESID;
   float4 pv[NPV];
-  const bool scale_rows = gAss != nullptr && tid < BM;
+  const bool scale_rows = kMayScale && gAss != nullptr && tid < BM;
   const int npv = gAss ? (gK >> 6) : 1;
-  {
+  if constexpr (kMayScale) {
     const int prow = m0 + (tid & (BM - 1)) < gM ? m0 + (tid & (BM - 1)) : gM - 1;
     const float4* p4 = gAss ? reinterpret_cast<const float4*>(gAss + static_cast<size_t>(prow) * (gK >> 4))
                             : reinterpret_cast<const float4*>(gW);
@@ -561,14 +563,16 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
         for (int j = 0; j < FN; ++j) mfma_chunk<CT>(af[i], bf[j], acc[i][j]);
     }
   }
-  if (scale_rows) {
-    float t = 0.f;
+  if constexpr (kMayScale) {
+    if (scale_rows) {
+      float t = 0.f;
 #pragma unroll
-    for (int u = 0; u < NPV; ++u) {
-      const float4 v = u < npv ? pv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-      t = (((t + v.x) + v.y) + v.z) + v.w;                                                  // fixed order per row
+      for (int u = 0; u < NPV; ++u) {
+        const float4 v = u < npv ? pv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        t = (((t + v.x) + v.y) + v.z) + v.w;                                                // fixed order per row
+      }
+      rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);
     }
-    rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);
   }
   if ((MT3_GLDS_PROBE & 4) && gM > 0) return;
   // ---- epilogue through LDS.  The C fragments (lane = 4 rows x 1 column) would reach memory as 32/64-byte pieces
@@ -578,10 +582,23 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   // lane groups of a fragment write hit disjoint banks; then every thread walks rows with float4s -- a wave
   // instruction covers two whole 512-byte tile rows.
   float* const tile = reinterpret_cast<float*>(smem);
-  const bool has_rs = gAss != nullptr;
+  const bool has_rs = kMayScale && gAss != nullptr;
   auto tile4 = [&](int row, int col) -> float4 {                   // logical (half-local row, col .. col + 3), col % 4 == 0
     return *reinterpret_cast<const float4*>(&tile[row * BN + (col ^ (((row >> 2) & 3) << 4))]);
   };
+  // RESID: the residual rows this thread will update (both halves) are requested NOW, into the registers the operand
+  // fragments just left, so that their HBM latency runs under the two LDS transpositions instead of after each
+  f32x4 xpre[2][8];
+  if constexpr (EPI == MT3_EPI_RESID) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int grow = m0 + h * 64 + (tid >> 5) + 8 * p;
+        xpre[h][p] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.out) +
+                                                     static_cast<size_t>(grow < gM ? grow : gM - 1) * g.ldo + n0 + (tid & 31) * 4);
+      }
+  }
 #pragma unroll 1
   for (int hm = 0; hm < 2; ++hm) {
     __syncthreads();                     // the ring / the previous half's image is no longer read (rs_x is visible)
@@ -616,7 +633,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
       }
     } else {
       const int c4 = (tid & 31) * 4;
-#pragma unroll 4
+      constexpr int kRowUnroll = EPI == MT3_EPI_RESID ? 8 : 4;      // RESID: p must be static (xpre lives in registers)
+#pragma unroll kRowUnroll
       for (int p = 0; p < 8; ++p) {
         const int row = (tid >> 5) + 8 * p;
         const int grow = mh + row;
@@ -627,7 +645,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
         const int col = n0 + c4;
         if constexpr (EPI == MT3_EPI_RESID) {
           f32x4* xp = reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col);
-          const f32x4 x = *xp;            // (plain accesses: non-temporal ones made the read-modify-write 10-20 % slower)
+          const f32x4 x = hm ? xpre[1][p] : xpre[0][p];   // (plain accesses: non-temporal ones made the read-modify-write 10-20 % slower)
           v.x += x.x, v.y += x.y, v.z += x.z, v.w += x.w;
           *xp = f32x4{v.x, v.y, v.z, v.w};
           if (g.out_ct) {

@@ -20,6 +20,7 @@
 #include "common.h"
 #include "device.h"
 #include "kernels.h"
+#include "mx8.h"
 
 #ifndef MT3_MX8_NS
 #define MT3_MX8_NS 2          // ring stages: 2 (66 KB, two workgroups per CU) or 3 (99 KB, one)
@@ -120,15 +121,30 @@ __global__ __launch_bounds__(256) void gemm_mx8_kernel(Mx8Args g) {
   const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
 
   // fused RMSNorm (norm 2): this thread's tile row's partial sums of squares, requested now, folded after the K loop
+  constexpr bool kMayScale = EPI != MT3_EPI_RESID;          // (RESID never carries a row scale)
   float4 pv[NPV];
-  const bool scale_rows = gAss != nullptr && tid < BM;
+  const bool scale_rows = kMayScale && gAss != nullptr && tid < BM;
   const int npv = gAss ? (gK >> 6) : 1;
-  {
+  if constexpr (kMayScale) {
     const int prow = m0 + (tid & (BM - 1)) < gM ? m0 + (tid & (BM - 1)) : gM - 1;
     const float4* p4 = gAss ? reinterpret_cast<const float4*>(gAss + static_cast<size_t>(prow) * (gK >> 4))
                             : reinterpret_cast<const float4*>(g.W);
 #pragma unroll
     for (int u = 0; u < NPV; ++u) pv[u] = p4[u < npv ? u : npv - 1];
+  }
+
+  // RESID: the residual rows this thread will update in the epilogue (both 64-row halves) are requested FIRST, so
+  // that the f32 read of the read-modify-write -- 40 % of this launch's HBM bytes -- runs under the K loop
+  f32x4 xpre[2][8];
+  if constexpr (EPI == MT3_EPI_RESID) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int grow = m0 + h * 64 + (tid >> 5) + 8 * p;
+        xpre[h][p] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(g.out) +
+                                                     static_cast<size_t>(grow < gM ? grow : gM - 1) * g.ldo + n0 + (tid & 31) * 4);
+      }
   }
 
   // ---- DMA plan.  Waves 0, 1 bring A rows 0-63 / 64-127, waves 2, 3 W rows; piece j = 8 rows x 128 B; lane i of a
@@ -216,21 +232,23 @@ __global__ __launch_bounds__(256) void gemm_mx8_kernel(Mx8Args g) {
       for (int j = 0; j < FN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af[i], bf[j], acc[i][j], 0, 0, 0, sa[i], 0, sb[j]);
   }
-  if (scale_rows) {
-    float t = 0.f;
+  if constexpr (kMayScale) {
+    if (scale_rows) {
+      float t = 0.f;
 #pragma unroll
-    for (int u = 0; u < NPV; ++u) {
-      const float4 v = u < npv ? pv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-      t = (((t + v.x) + v.y) + v.z) + v.w;                                 // fixed order per row
+      for (int u = 0; u < NPV; ++u) {
+        const float4 v = u < npv ? pv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        t = (((t + v.x) + v.y) + v.z) + v.w;                               // fixed order per row
+      }
+      rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);
     }
-    rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);
   }
   if ((MT3_MX8_PROBE & 4) && gM > 0) return;
 
   // ---- epilogue through LDS, 64 rows at a time (as gemm.hip's bf16 tile): the C fragments are transposed through the
   // idle ring so that every thread then walks rows with float4s and stores whole lines
   float* const tile = reinterpret_cast<float*>(smem);
-  const bool has_rs = gAss != nullptr;
+  const bool has_rs = kMayScale && gAss != nullptr;
   auto tile4 = [&](int row, int col) -> float4 {
     return *reinterpret_cast<const float4*>(&tile[row * BN + (col ^ (((row >> 2) & 3) << 4))]);
   };
@@ -275,7 +293,8 @@ __global__ __launch_bounds__(256) void gemm_mx8_kernel(Mx8Args g) {
       }
     } else {
       const int c4 = (tid & 31) * 4;
-#pragma unroll 4
+      constexpr int kRowUnroll = EPI == MT3_EPI_RESID ? 8 : 4;      // RESID: p must be static (xpre lives in registers)
+#pragma unroll kRowUnroll
       for (int p = 0; p < 8; ++p) {
         const int row = (tid >> 5) + 8 * p;
         const bool ok = mh + row < gM;
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(256) void gemm_mx8_kernel(Mx8Args g) {
           // x += product; the new rows also leave as the split residual form of this path: per-16-column sums of
           // squares (exact f32, for the next fused RMSNorm) and the MXFP8 copy the next GEMM reads
           f32x4* xp = reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col);
-          const f32x4 x = *xp;
+          const f32x4 x = hm ? xpre[1][p] : xpre[0][p];
           v.x += x.x, v.y += x.y, v.z += x.z, v.w += x.w;
           float t = __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
           t = quad_sum(t);
