@@ -99,6 +99,8 @@ def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int):
         dt = time.perf_counter() - t0
         # (b) encoder-only (configs[1]) at all cores: big GEMMs, this one does scale with threads
         torch.set_num_threads(nproc)
+        if dt > 45.0:                   # a slow (shared) host: keep the whole CPU leg bounded
+            enc_segments = max(16, enc_segments // 2)
         t1 = time.perf_counter()
         lm2 = np.stack([OF.compute_logmel(a, np.float32) for a in audio[:enc_segments]])
         orc.encode(lm2)
