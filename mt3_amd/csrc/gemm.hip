@@ -129,9 +129,12 @@ struct EpiCtx {
 
 // acc[i][j]: the wave's (wm, wn) sub-tile as FM x FN 16x16 C fragments of the workgroup tile at (m0, n0);
 // row_rs(lrow) = 1 / rms of tile row lrow (or 1)
-template <typename CT, int EPI_, int FM, int FN, typename RowRs>
+// PRE: pre[i][j][r] already holds the element of the f32 output region that a RESID epilogue is about to add to (the
+// kernel asked for it before its K loop: on the latency-bound decode tiles the read-modify-write's read would
+// otherwise be one more dependent memory round trip at the very end of the launch)
+template <typename CT, int EPI_, int FM, int FN, bool PRE, typename RowRs>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm, int wn, int lane, int m0, int n0,
-                                              const EpiCtx& c, RowRs row_rs) {
+                                              const EpiCtx& c, RowRs row_rs, const float (&pre)[FM][FN][4]) {
   const int frag_row = lane & 15, frag_g = lane >> 4;
   if constexpr (EPI_ == kEpiStoreQ || EPI_ == kEpiResidQ) {
     if (n0 >= c.n_split) {       // (tile-uniform) the second product: plain f32, no row scale
@@ -144,7 +147,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm
 #pragma unroll
           for (int j = 0; j < FN; ++j) {
             float* o = c.out2 + static_cast<size_t>(row) * c.ld2 + (n0 - c.n_split) + wn * FN * 16 + j * 16 + frag_row;
-            if constexpr (EPI_ == kEpiResidQ) *o = *o + acc[i][j][r];
+            if constexpr (EPI_ == kEpiResidQ) *o = (PRE ? pre[i][j][r] : *o) + acc[i][j][r];
             else *o = acc[i][j][r];
           }
         }
@@ -213,7 +216,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + lrow0 + r;
           const size_t at = static_cast<size_t>(row < c.M ? row : c.M - 1) * c.ldo + col;
-          vnew[r] = static_cast<float*>(c.out)[at] + acc[i][j][r];
+          vnew[r] = (PRE ? pre[i][j][r] : static_cast<float*>(c.out)[at]) + acc[i][j][r];
           if (row < c.M) static_cast<float*>(c.out)[at] = vnew[r];
         }
         if (c.out_ct) {
@@ -340,6 +343,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
     for (int u = 0; u < NPV; ++u)
       pv[u] = (scale_rows && u < (gK >> 6)) ? p4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // decode-sized RESID tiles (bf16): this lane's elements of the residual rows, requested before anything else
+  constexpr bool kPre = (EPI == MT3_EPI_RESID || EPI == kEpiResidQ) && sizeof(CT) == 2 && FM * FN <= 2;
+  float xpre[FM][FN][4];
+  if constexpr (kPre) {
+    const float* src = static_cast<const float*>(gO);
+    int ld = gLdo, c0 = n0;
+    if constexpr (EPI == kEpiResidQ) {
+      if (n0 >= g.n_split) {             // (tile-uniform) the second product's f32 region
+        src = g.out2;
+        ld = gN - g.n_split;
+        c0 = n0 - g.n_split;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * FM * 16 + i * 16 + (lane >> 4) * 4 + r;
+          xpre[i][j][r] = src[static_cast<size_t>(row < gM ? row : gM - 1) * ld + c0 + wn * FN * 16 + j * 16 + (lane & 15)];
+        }
+  }
   u32x4 a_reg[A_PASSES], b_reg[B_PASSES];
   float ss[A_PASSES];
 #pragma unroll
@@ -427,7 +453,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   MT3_PROF_MARK(5);
   constexpr bool SPLIT = EPI == kEpiStoreQ || EPI == kEpiResidQ;
   const EpiCtx ec{gO, gAux, gM, SPLIT ? g.n_split : gN, gLdo, gSeq, gOutCt, gOutSs, g.out2, g.n_split, gN - g.n_split};
-  gemm_epilogue<CT, EPI, FM, FN>(acc, wm, wn, lane, m0, n0, ec, row_rs);
+  gemm_epilogue<CT, EPI, FM, FN, kPre>(acc, wm, wn, lane, m0, n0, ec, row_rs, xpre);
   MT3_PROF_MARK(4);
 }
 
