@@ -39,7 +39,10 @@ extern "C" int mt3_host_mx8_quantize(const float* h_w, int64_t rows, int64_t K, 
     for (int64_t b = 0; b < nb; ++b) {
       const float* v = h_w + r * K + b * 32;
       float amax = 0.f;
-      for (int j = 0; j < 32; ++j) amax = std::fmax(amax, std::fabs(v[j]));
+      for (int j = 0; j < 32; ++j) {
+        if (!std::isfinite(v[j])) return mt3::fail(MT3_ERR_INVALID, "mt3_host_mx8_quantize: non-finite value in the matrix");
+        amax = std::fmax(amax, std::fabs(v[j]));
+      }
       uint32_t u;
       std::memcpy(&u, &amax, 4);
       const uint32_t e = (u >> 23) & 0xffu;

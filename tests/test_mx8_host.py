@@ -46,3 +46,22 @@ def test_host_quantiser_rejects_ragged_blocks():
     x = np.zeros((2, 48), np.float32)
     with pytest.raises(_lib.Mt3Error):
         _host(x)
+
+
+def test_host_quantiser_rejects_non_finite_weights():
+    x = np.ones((2, 64), np.float32)
+    x[1, 40] = np.inf
+    with pytest.raises(_lib.Mt3Error, match="non-finite"):
+        _host(x)
+    x[1, 40] = np.nan
+    with pytest.raises(_lib.Mt3Error, match="non-finite"):
+        _host(x)
+
+
+def test_dense_dtype_is_validated_before_anything_touches_the_device():
+    import dataclasses
+    from mt3_amd import network
+    with pytest.raises(ValueError, match="dense_dtype"):
+        network.Transformer(dataclasses.replace(network.T5Config(), dtype="float32", dense_dtype="fp8_e4m3"))
+    with pytest.raises(ValueError, match="dense_dtype"):
+        network.Transformer(dataclasses.replace(network.T5Config(), dtype="bfloat16", dense_dtype="int8"))
