@@ -65,3 +65,24 @@ def test_dense_dtype_is_validated_before_anything_touches_the_device():
         network.Transformer(dataclasses.replace(network.T5Config(), dtype="float32", dense_dtype="fp8_e4m3"))
     with pytest.raises(ValueError, match="dense_dtype"):
         network.Transformer(dataclasses.replace(network.T5Config(), dtype="bfloat16", dense_dtype="int8"))
+
+
+def test_mxfp8_encoder_emulation_distance_from_the_f32_oracle():
+    """What the FORMAT costs, without a GPU: the CPU emulation of the engine's MXFP8 encoder (tests/mx8_encoder_ref.py)
+    against the f32 oracle on the random-init MT3 shape.  The device measures 5.6-9.2e-2 per segment
+    (tests/test_gpu_mx8.py); the emulation must land in the same place, or the device is doing something else."""
+    from mt3_amd import network
+    from oracle import frontend as OF
+    from oracle import network as ON
+    from tests import mx8_encoder_ref
+    cfg = network.T5Config(dtype="float32")
+    params = network.init_random_params(cfg, seed=0, norm_scale_jitter=0.2)
+    audio = OF.synth_audio(2, seed=0)
+    x = np.stack([OF.compute_logmel(a, np.float64).astype(np.float32) for a in audio])
+    ref = ON.Oracle(params, ON.T5Config()).encode(x).double()
+    emu = mx8_encoder_ref.encode(params, cfg, x)
+    for b in range(2):
+        r = float((emu[b] - ref[b]).norm() / ref[b].norm())
+        cos = float((emu[b] * ref[b]).sum() / (emu[b].norm() * ref[b].norm()))
+        print(f"MXFP8 emulation vs f32 oracle, segment {b}: rel-L2 {r:.3e} cosine {cos:.5f}")
+        assert 2e-2 < r < 1.3e-1 and cos > 0.992
