@@ -9,7 +9,7 @@ the decoded int32 token rows before host run-length decoding.  The payload is ti
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import Tuple
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:

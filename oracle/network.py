@@ -26,8 +26,7 @@ Flax tree of SURVEY.md A.3 joined with '/'.
 from __future__ import annotations
 
 import dataclasses
-import math
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List
 
 import numpy as np
 import torch

@@ -24,7 +24,7 @@ from __future__ import annotations
 import bisect
 import dataclasses
 import math
-from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+from typing import Dict, Iterable, List, Sequence, Tuple
 
 import numpy as np
 

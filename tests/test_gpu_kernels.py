@@ -4,7 +4,6 @@ Each HIP kernel is compared with a float64 evaluation of the same operation on t
 same (already rounded) inputs; tolerances are stated next to each check.  Integer
 kernels are bit-exact against the oracle.
 """
-import ctypes as C
 import math
 
 import numpy as np

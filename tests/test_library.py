@@ -38,7 +38,6 @@ def test_argument_errors_are_reported_not_swallowed():
 @pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_no_gpu_means_loud_failure_not_cpu_fallback():
     """Without a device the engine cannot finalize: MT3_ERR_HIP, never a silent CPU path."""
-    import numpy as np
     from mt3_amd import network
     cfg = network.T5Config(num_encoder_layers=1, num_decoder_layers=1)
     eng = network.Transformer(cfg, max_batch=1)

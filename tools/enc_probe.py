@@ -4,7 +4,6 @@ PROBE_DENSE=fp8_e4m3 runs the MXFP8 encoder."""
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,6 +1,6 @@
 """Where do the small decode kernels spend their ~5 us?  Decode with both attention kernels skipped
 (caches stay hot: only ~44 MB of weights + activations are touched per step) vs with them."""
-import os, sys, time
+import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mt3_amd import network, spectrograms, synthetic
