@@ -526,13 +526,13 @@ def main():
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-segments",
                                     str(args.cpu_segments), "--cpu-enc-segments", str(args.cpu_enc_segments),
                                     "--decode-steps", str(args.decode_steps)],
-                                   capture_output=True, text=True, timeout=420)
+                                   capture_output=True, text=True, timeout=300)
                 line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
                 out["cpu_baseline"] = json.loads(line[-1][len("CPU_BASELINE "):]) if line else \
                     {"value": None, "unit": "audio-s/s", "cores": 0, "kind": "port", "sample": "failed: " + r.stderr[-300:]}
             except subprocess.TimeoutExpired:
                 out["cpu_baseline"] = {"value": None, "unit": "audio-s/s", "cores": 0, "kind": "port",
-                                       "sample": "oracle did not finish %d segments in 420 s" % args.cpu_segments}
+                                       "sample": "oracle did not finish %d segments in 300 s" % args.cpu_segments}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
