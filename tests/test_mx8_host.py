@@ -81,8 +81,11 @@ def test_mxfp8_encoder_emulation_distance_from_the_f32_oracle():
     x = np.stack([OF.compute_logmel(a, np.float64).astype(np.float32) for a in audio])
     ref = ON.Oracle(params, ON.T5Config()).encode(x).double()
     emu = mx8_encoder_ref.encode(params, cfg, x)
+    emu16 = mx8_encoder_ref.encode(params, cfg, x, fmt="bf16")
     for b in range(2):
         r = float((emu[b] - ref[b]).norm() / ref[b].norm())
         cos = float((emu[b] * ref[b]).sum() / (emu[b].norm() * ref[b].norm()))
-        print(f"MXFP8 emulation vs f32 oracle, segment {b}: rel-L2 {r:.3e} cosine {cos:.5f}")
+        r16 = float((emu16[b] - ref[b]).norm() / ref[b].norm())
+        print(f"segment {b}: MXFP8 emulation vs f32 oracle rel-L2 {r:.3e} cosine {cos:.5f}; bf16 emulation {r16:.3e}")
         assert 2e-2 < r < 1.3e-1 and cos > 0.992
+        assert 2e-3 < r16 < 1e-2                    # the bf16 engine measures 4.595e-3 / 4.298e-3 on these two segments
