@@ -40,25 +40,28 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_FP8_PEAK_TFLOPS = 5000.0              # dense MX-scaled fp8 (K = 128 instructions), MI355X_MICROARCH.md
 ENC_GFLOP_PER_SEGMENT = 10.603 + 1.611     # encoder + the one-off cross-K/V projections of 8 layers
 FRONTEND_BYTES_PER_SEGMENT = 655360        # 131072 in + 524288 out
+FRONTEND_SOURCES = ("frontend.hip", "frontend_core.h", "frontend_tables.h")
 
 
-def kernel_source_hash():
+def kernel_source_hash(files=("attention.hip", "device.h", "kernels.h")):
     """Identity of the kernel a PMC file was collected from: sha256 over the sources the decode-attention kernels
-    are compiled from (a change to any of them invalidates a committed traffic ratio)."""
+    (default) are compiled from (a change to any of them invalidates a committed traffic ratio)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mt3_amd", "csrc")
-    for f in ("attention.hip", "device.h", "kernels.h"):
+    for f in files:
         with open(os.path.join(d, f), "rb") as fh:
             h.update(f.encode() + b"\0" + fh.read())
     return h.hexdigest()[:16]
 
 
 # ----------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int):
+def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int, small_segments: int = 0):
     """The oracle (CPU restatement of the reference path: numpy frontend + torch-CPU f32 network + pure-Python
     note decoding; NOT JAX -- SURVEY 8c: jax/t5x are not installable here) timed on this box's host cores on a
-    bounded sample: (a) the full path on `n_segments` segments as ONE batch (reduced configs[2]), (b) configs[1]:
-    log-mel + encoder only on `enc_segments` segments."""
+    bounded sample: (a) the full path on `n_segments` segments as ONE batch (reduced configs[2]; 32 by default: a
+    batch large enough for the decode GEMMs to use the host), (b) the same on `small_segments` (the batch of 8 the
+    reference's InferenceModel uses, NB:190; skipped when (a) was slow), (c) configs[1]: log-mel + encoder only on
+    `enc_segments` segments."""
     import numpy as np
     import torch
     from mt3_amd import network
@@ -68,15 +71,14 @@ def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int):
     params = network.init_random_params(cfg, seed=0)
     audio = OF.synth_audio(max(n_segments, enc_segments), seed=0)
     orc = ON.Oracle(params, ON.T5Config())
-    # thread count: the decode step is a chain of batch-8 GEMVs whose speed peaks well below a 256-core host's
-    # nproc; pick the fastest of a few candidates on 4 real decode steps each (the probe is not part of the
-    # timed sample) and say which one was used
-    with torch.no_grad():
-        lm_probe = np.stack([OF.compute_logmel(a, np.float32) for a in audio[:n_segments]])
-        torch.set_num_threads(min(nproc, 16))
-        enc_probe = orc.encode(lm_probe)
+    vocab = OS.GenericTokenVocabulary(1388, extra_ids=100)
+    codec = OS.build_codec(OS.VocabularyConfig(num_velocity_bins=1))
+
+    def pick_threads(enc_probe, candidates):
+        # the decode step is a chain of small-batch GEMMs whose speed peaks well below a 256-core host's nproc: take
+        # the fastest candidate on 4 real decode steps (the probe is not part of the timed sample) and say which
         best = (None, 1e30)
-        for th in sorted({min(nproc, c) for c in (16, 32, 64)}):      # (8 and nproc = 256 never won on these hosts)
+        for th in sorted({min(nproc, c) for c in candidates}):
             torch.set_num_threads(th)
             orc.greedy_decode(enc_probe, 1)
             t0 = time.perf_counter()
@@ -84,37 +86,52 @@ def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int):
             dt = time.perf_counter() - t0
             if dt < best[1]:
                 best = (th, dt)
-        threads = best[0]
-        torch.set_num_threads(threads)
-        t0 = time.perf_counter()
-        lm = np.stack([OF.compute_logmel(a, np.float32) for a in audio[:n_segments]])
-        enc = orc.encode(lm)
-        ids = orc.greedy_decode(enc, decode_steps)
-        vocab = OS.GenericTokenVocabulary(1388, extra_ids=100)
-        toks = vocab.decode_tf(ids)
-        codec = OS.build_codec(OS.VocabularyConfig(num_velocity_bins=1))
-        preds = [{"est_tokens": OS.trim_eos(t), "start_time": OS.floor_start_time(i * SEG_SECONDS, 100)}
-                 for i, t in enumerate(toks)]
-        OS.event_predictions_to_ns(preds, codec, "ties")
-        dt = time.perf_counter() - t0
-        # (b) encoder-only (configs[1]) at all cores: big GEMMs, this one does scale with threads
+        return best[0]
+
+    def full_path(n, candidates):
+        with torch.no_grad():
+            torch.set_num_threads(min(nproc, 32))
+            enc_probe = orc.encode(np.stack([OF.compute_logmel(a, np.float32) for a in audio[:n]]))
+            threads = pick_threads(enc_probe, candidates)
+            torch.set_num_threads(threads)
+            t0 = time.perf_counter()
+            lm = np.stack([OF.compute_logmel(a, np.float32) for a in audio[:n]])
+            enc = orc.encode(lm)
+            ids = orc.greedy_decode(enc, decode_steps)
+            toks = vocab.decode_tf(ids)
+            preds = [{"est_tokens": OS.trim_eos(t), "start_time": OS.floor_start_time(i * SEG_SECONDS, 100)}
+                     for i, t in enumerate(toks)]
+            OS.event_predictions_to_ns(preds, codec, "ties")
+            return time.perf_counter() - t0, threads
+
+    t_begin = time.perf_counter()
+    dt, threads = full_path(n_segments, (32, 64, 128))
+    out = {"value": n_segments * SEG_SECONDS / dt, "unit": "audio-s/s", "cores": threads, "nproc": nproc,
+           "kind": "port",
+           "sample": "%d segments as one batch (%.1f s of audio), same path: log-mel + encoder + %d greedy steps + "
+                     "note decoding; oracle restatement (numpy/torch-CPU f32), not JAX; %d torch threads (fastest of "
+                     "32/64/128 of nproc=%d on a 4-step probe); %.1f s wall"
+                     % (n_segments, n_segments * SEG_SECONDS, decode_steps, threads, nproc, dt)}
+    if small_segments and time.perf_counter() - t_begin < 110.0:
+        dt8, th8 = full_path(small_segments, (16, 32, 64))
+        out["batch_%d" % small_segments] = {
+            "value": small_segments * SEG_SECONDS / dt8, "unit": "audio-s/s", "cores": th8,
+            "sample": "the reference InferenceModel's own batch size (NB:190): %d segments as one batch, same path, "
+                      "%d torch threads (fastest of 16/32/64); %.1f s wall" % (small_segments, th8, dt8)}
+    with torch.no_grad():
+        # (c) encoder-only (configs[1]) at all cores: big GEMMs, this one does scale with threads
         torch.set_num_threads(nproc)
-        if dt > 45.0:                   # a slow (shared) host: keep the whole CPU leg bounded
+        if time.perf_counter() - t_begin > 150.0:      # a slow (shared) host: keep the whole CPU leg bounded
             enc_segments = max(16, enc_segments // 2)
         t1 = time.perf_counter()
         lm2 = np.stack([OF.compute_logmel(a, np.float32) for a in audio[:enc_segments]])
         orc.encode(lm2)
         dt2 = time.perf_counter() - t1
-    return {"value": n_segments * SEG_SECONDS / dt, "unit": "audio-s/s", "cores": threads, "nproc": nproc,
-            "kind": "port",
-            "sample": "%d segments as one batch (%.1f s of audio), same path: log-mel + encoder + %d greedy steps + "
-                      "note decoding; oracle restatement (numpy/torch-CPU f32), not JAX; %d torch threads (fastest of "
-                      "16/32/64 of nproc=%d on a 4-step probe); %.1f s wall"
-                      % (n_segments, n_segments * SEG_SECONDS, decode_steps, threads, nproc, dt),
-            "encoder_only": {"value": enc_segments * SEG_SECONDS / dt2, "unit": "audio-s/s",
-                             "segments_per_s": enc_segments / dt2, "cores": nproc,
-                             "sample": "configs[1] on the CPU: log-mel + encoder, %d segments, %d torch threads, "
-                                       "%.1f s wall" % (enc_segments, nproc, dt2)}}
+    out["encoder_only"] = {"value": enc_segments * SEG_SECONDS / dt2, "unit": "audio-s/s",
+                           "segments_per_s": enc_segments / dt2, "cores": nproc,
+                           "sample": "configs[1] on the CPU: log-mel + encoder, %d segments, %d torch threads, "
+                                     "%.1f s wall" % (enc_segments, nproc, dt2)}
+    return out
 
 
 # ----------------------------------------------------------------------------------------- rank spawning
@@ -162,15 +179,19 @@ def main():
                     help="BASELINE configs[3]: a fixed corpus of this many segments sharded over the ranks (strong "
                          "scaling; 10000 = 1250 per GPU at 8 GPUs); one step = one pass over the corpus")
     ap.add_argument("--corpus-batch", type=int, default=1250, help="segments per engine call in --corpus mode")
+    ap.add_argument("--file-segments", type=int, default=256,
+                    help="the corpus is a list of files of this many consecutive segments (256 x 2.048 s = 8.7 min of "
+                         "audio); host note decoding is sequential inside a file and parallel across files")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the f32 line and the stage (frontend/encoder) extras")
-    ap.add_argument("--cpu-segments", type=int, default=8)
+    ap.add_argument("--cpu-segments", type=int, default=32)
+    ap.add_argument("--cpu-small-segments", type=int, default=8)
     ap.add_argument("--cpu-enc-segments", type=int, default=64)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print("CPU_BASELINE " + json.dumps(cpu_baseline(args.cpu_segments, args.decode_steps, args.cpu_enc_segments)),
-              flush=True)
+        print("CPU_BASELINE " + json.dumps(cpu_baseline(args.cpu_segments, args.decode_steps, args.cpu_enc_segments,
+                                                        args.cpu_small_segments)), flush=True)
         return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
@@ -215,58 +236,51 @@ def main():
     stream = torch.cuda.Stream()                                          # a real (capturable) stream
     start_times = [s * SEG_SECONDS - (s * SEG_SECONDS) % 0.01 for s in range(n_global)]
 
-    # rank 0's host stage (EOS trim + run-length / note decoding in libmt3hip.so) runs on a worker thread, so the
+    # rank 0's host stage (EOS trim + run-length / note decoding in libmt3hip.so) runs on worker threads, so the
     # NEXT batch's GPU work is already being launched while the previous batch's tokens become notes; every
-    # future is joined before the clock stops, so all of it stays inside the timed region
-    # With N ranks, rank 0 receives N shards per step; each shard is decoded as its own "file" on its own worker
-    # thread (the C++ decoder runs outside the GIL), so rank 0's host time per step does not grow with N.
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=max(1, min(world, 8)))
-    pending = []
+    # future is joined before the clock stops, so all of it stays inside the timed region.
+    # The corpus is a list of FILES of `--file-segments` consecutive segments (the host state machine is sequential
+    # inside a file, mt3/metrics_utils.py:92-116); file boundaries do not depend on the number of ranks, each file is
+    # decoded on its own worker thread (the C++ decoder runs outside the GIL), so rank 0's host time per step does
+    # not grow with N and the notes are the same for every N (tests/test_distributed_gloo.py).
     gather_events = []
 
-    def host_shard(host, first):
-        eos = host == vocabularies.DECODED_EOS_ID
-        n_tok = np.where(eos.any(1), eos.argmax(1), host.shape[1])
-        rows = [r[:n] for r, n in zip(host, n_tok)]
-        ns, inv, drop = metrics_utils._run(codec, note_sequences.NoteEncodingWithTiesSpec.spec_id, rows,
-                                           start_times[first: first + len(rows)])
+    def notes_of_file(rows, first):
+        eos = rows == vocabularies.DECODED_EOS_ID
+        n_tok = np.where(eos.any(1), eos.argmax(1), rows.shape[1])
+        ns, inv, drop = metrics_utils._run(codec, note_sequences.NoteEncodingWithTiesSpec.spec_id,
+                                           [r[:n] for r, n in zip(rows, n_tok)], start_times[first: first + len(rows)])
         return len(ns.notes)
 
+    def transcribe(first, count, engine=None):
+        """frontend -> encode -> decode -> ids -> tokens for global segments [first, first + count): CUDA int32 [count, L]"""
+        chunk = audio[first - lo: first - lo + count]
+        e = engine or eng
+        e.encode(spectrograms.compute_spectrogram_batch(chunk, None))
+        return vocab.decode_tf(e.decode(num_steps=args.decode_steps, beam1=args.decoding == "beam1"))
+
+    def on_gather(phase):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        if phase == 0:
+            gather_events.append([ev, None])
+        else:
+            gather_events[-1][1] = ev
+
+    job = distributed.ShardedTranscriber(n_global, rank, world, transcribe, notes_of_file, call_segments=B,
+                                         file_segments=args.file_segments, host_threads=8, on_gather=on_gather)
+
     def host_stage(host):
-        """submit one step's token rows; returns the futures (one per source rank's shard)"""
-        futs = []
-        for r in range(world):
-            a, b = distributed.shard_range(host.shape[0], r, world)
-            if b > a:
-                futs.append(pool.submit(host_shard, host[a:b], a))
-        return futs
+        """one step's token rows of THIS rank's shard alone (the single-GPU extras): futures, one per file"""
+        return [job._pool.submit(notes_of_file, host[a:b], a) for a, b in distributed.file_ranges(host.shape[0],
+                                                                                                   args.file_segments)]
 
     def step():
         with torch.cuda.stream(stream):
-            parts = []
-            for s in range(0, n_local, B):
-                chunk = audio[s:s + B]
-                logmel = spectrograms.compute_spectrogram_batch(chunk, None)
-                eng.encode(logmel)
-                ids = eng.decode(num_steps=args.decode_steps, beam1=args.decoding == "beam1")
-                parts.append(vocab.decode_tf(ids))                         # CUDA int32 [b, L]
-            tokens = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
-            if world > 1:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(stream)
-                tokens = distributed.gather_token_rows(tokens, n_global)   # ONE RCCL all-gather of int32 token rows
-                e1.record(stream)
-                gather_events.append((e0, e1))
-            if rank == 0:
-                host = tokens.cpu().numpy()                                # syncs the stream
-                pending.append(host_stage(host))
+            job.step()
 
     def drain():
-        n = 0
-        while pending:
-            n = sum(f.result() for f in pending.pop(0))
-        return n
+        return sum(job.drain())
 
     def sync_all():
         torch.cuda.synchronize()
@@ -303,7 +317,8 @@ def main():
     # ---- roofline of the dominant kernel (decode self-attention: HBM streaming of the K/V cache).
     # In-situ and live: HIP events (recorded on the stream the graphs are launched on) around the whole
     # graph-replayed decode, once as it ships and once with that kernel's launches left out of the step
-    # graph; the difference / launches = the kernel's average duration inside the real decode loop.
+    # graph (mt3_debug_engine_decode, include/mt3_hip_debug.h); the difference / launches = the kernel's average
+    # duration inside the real decode loop.
     roof, extras = None, {}
     if rank == 0:
         Br = min(B, n_local)
@@ -318,76 +333,98 @@ def main():
             e1.synchronize()
             return e0.elapsed_time(e1) / reps
 
-        def decode_ms(engine=eng, **kw):
-            kw["chains"] = 1      # the kernel at full-GPU width, one launch at a time (as rocprofv3 sees it)
-            with torch.cuda.stream(stream):
-                engine.decode(num_steps=2, **kw)                      # capture / warm this graph variant
-            return timed(lambda: engine.decode(num_steps=args.decode_steps, **kw))
+        def pmc_ratio(section, key):
+            """HBM traffic / algorithmic bytes of a decode-attention kernel from the PMC counters (rocprofv3 --pmc
+            FETCH_SIZE / WRITE_SIZE, separate passes, FETCH_SIZE x2 on gfx950 -- calibrated on a 1 GiB copy): a bench
+            run cannot wrap itself in rocprofv3, so tools/gpu_pmc.sh collects them at this exact shape and
+            tools/pmc_summary.py stamps the summary with the hash of the kernel sources it was collected from; a summary
+            from OTHER sources is refused (traffic = null) instead of silently carrying an old ratio over a kernel change."""
+            for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_summary.json")),
+                               reverse=True):
+                try:
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        pmc = json.load(f)
+                    if key is None:         # the frontend kernel: its own sources
+                        if pmc.get("frontend_source_hash") != kernel_source_hash(FRONTEND_SOURCES) or Br != 256:
+                            continue
+                        return pmc[section]["traffic_over_algorithmic"], name, pmc["frontend_source_hash"]
+                    if pmc.get("kernel_source_hash") != kernel_source_hash() or pmc["shape"]["B"] != Br:
+                        continue
+                    return pmc[section][key]["traffic_over_algorithmic"], name, pmc["kernel_source_hash"]
+                except (OSError, KeyError, ValueError, TypeError):
+                    continue
+            return None, None, None
+
+        def attention_roofline(engine, ecfg, reps=2):
+            """roofline block of `engine`'s decode self-attention kernel (plus the cross-attention figures), measured
+            on the engine's current encoded batch of Br rows"""
+            def decode_ms(**kw):
+                with torch.cuda.stream(stream):
+                    engine.debug_decode(num_steps=2, chains=1, **kw)          # capture / warm this graph variant
+                # the kernel at full-GPU width, one launch at a time (as rocprofv3 sees it)
+                return min(timed(lambda: engine.debug_decode(num_steps=args.decode_steps, chains=1, **kw))
+                           for _ in range(reps))
+            t_full = decode_ms()
+            t_noself = decode_ms(skip_self_attn=True)
+            t_nocross = decode_ms(skip_cross_attn=True)
+            esz = 2 if ecfg.dtype == "bfloat16" else 4
+            H, S, nl = ecfg.num_heads, args.decode_steps, ecfg.num_decoder_layers
+            # K+V bytes of one cache position, all rows (fp8: 64 e4m3 bytes each + the {k, v} f32 scale pair of the row)
+            kv_row = Br * H * (2.0 * 64 + 8.0) if ecfg.kv_dtype else 2.0 * Br * H * 64 * esz
+            launches = S * nl
+            # algorithmic bytes: read the t cached K/V rows + the new row + q, write the new row + the output
+            self_bytes = nl * sum(kv_row * (t + 1) + kv_row + 2.0 * Br * H * 64 * esz for t in range(S))
+            cross_bytes = launches * (kv_row * 256 + 2.0 * Br * H * 64 * esz)
+            self_us = (t_full - t_noself) * 1e3 / launches
+            cross_us = (t_full - t_nocross) * 1e3 / launches
+            ach = self_bytes / launches / (self_us * 1e-6) / 1e9
+            kname = ("fp8" if ecfg.kv_dtype else ("bf16" if esz == 2 else "f32"))
+            traffic, traffic_src = None, "no PMC summary for these kernel sources / this shape (run tools/gpu_pmc.sh)"
+            if args.decode_steps == 1024 and ecfg.num_heads == 6:
+                ratio, fname, khash = pmc_ratio("dec_attn_self_append_" + kname, "n_keys_513")
+                if ratio is not None:
+                    traffic = ratio * self_bytes / launches
+                    traffic_src = "profiles/%s (kernel sources %s; measured traffic/algorithmic = %.4f at the mean " \
+                                  "launch)" % (fname, khash, ratio)
+            return {"bound": "hbm",
+                    "kernel": "mt3k::dec_attn_fp8_kernel<APPEND=true> (decode self-attention over the e4m3 K/V cache)"
+                    if ecfg.kv_dtype else "mt3k::dec_attn_kernel<%s, APPEND=true> (decode self-attention over the K/V "
+                                          "cache)" % kname,
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic, "traffic_source": traffic_src,
+                    "avg_launch_us": self_us, "algorithmic_bytes_per_launch": self_bytes / launches,
+                    "launches": launches,
+                    "method": "HIP events on the launch stream around the whole graph-replayed decode, with and "
+                              "without this kernel in the step graph; (difference)/launches",
+                    "decode_ms_single_chain": t_full, "decode_ms_without_self_attn": t_noself,
+                    "decode_ms_without_cross_attn": t_nocross,
+                    "small_kernel_us_per_step": (t_noself + t_nocross - t_full) * 1e3 / S,
+                    "whole_step_hbm_frac": (self_bytes + cross_bytes) / (t_full * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "cross_attn": {"achieved": cross_bytes / launches / (cross_us * 1e-6) / 1e9,
+                                   "frac": cross_bytes / launches / (cross_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                   "avg_launch_us": cross_us, "algorithmic_bytes_per_launch": cross_bytes / launches}}
 
         with torch.cuda.stream(stream):
             eng.encode(spectrograms.compute_spectrogram_batch(audio[:Br], None))
-        t_full = min(decode_ms(), decode_ms())
-        t_noself = min(decode_ms(skip_self_attn=True), decode_ms(skip_self_attn=True))
-        t_nocross = min(decode_ms(skip_cross_attn=True), decode_ms(skip_cross_attn=True))
-        esize = 2 if args.dtype == "bfloat16" else 4
-        H, S, nl = cfg.num_heads, args.decode_steps, cfg.num_decoder_layers
-        # K+V bytes of one cache position, all rows (fp8: 64 e4m3 bytes each + the {k, v} f32 scale pair of the row)
-        kv_row = Br * H * (2.0 * 64 + 8.0) if args.kv_dtype else 2.0 * Br * H * 64 * esize
-        launches = S * nl
-        # algorithmic bytes: read the t+1 cached K/V rows + q, write the new row + the output
-        self_bytes = nl * sum(kv_row * (t + 1) + kv_row + 2.0 * Br * H * 64 * esize for t in range(S))
-        cross_bytes = launches * (kv_row * 256 + 2.0 * Br * H * 64 * esize)
-        self_us = (t_full - t_noself) * 1e3 / launches
-        cross_us = (t_full - t_nocross) * 1e3 / launches
-        ach = self_bytes / launches / (self_us * 1e-6) / 1e9
-        # HBM traffic of that kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-        # passes, FETCH_SIZE x2 on gfx950 -- calibrated on a 1 GiB copy): a bench run cannot wrap itself in
-        # rocprofv3, so tools/gpu_pmc.sh collects them at this exact shape and tools/pmc_summary.py stamps the
-        # summary with the hash of the kernel sources it was collected from; a summary from OTHER sources is
-        # refused (traffic = null) instead of silently carrying an old ratio over a kernel change
-        traffic, traffic_src = None, "no PMC summary for these kernel sources (run tools/gpu_pmc.sh)"
-        for name in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_summary.json")),
-                           reverse=True):
-            try:
-                with open(os.path.join(ROOT, "profiles", name)) as f:
-                    pmc = json.load(f)
-                if pmc.get("kernel_source_hash") != kernel_source_hash():
-                    continue
-                if pmc["shape"]["B"] == Br and args.dtype == "bfloat16" and args.decode_steps == 1024 and \
-                        not args.kv_dtype and args.model == "mt3":
-                    ratio = pmc["dec_attn_self_append"]["n_keys_513"]["traffic_over_algorithmic"]
-                    traffic = ratio * self_bytes / launches
-                    traffic_src = "profiles/%s (kernel sources %s; measured traffic/algorithmic = %.4f at the mean " \
-                                  "launch)" % (name, pmc["kernel_source_hash"], ratio)
-                    break
-            except (OSError, KeyError, ValueError):
-                continue
-        roof = {"bound": "hbm", "kernel": "mt3k::dec_attn_fp8_kernel<APPEND=true> (decode self-attention over the e4m3 "
-                                          "K/V cache)" if args.kv_dtype else
-                "mt3k::dec_attn_kernel<%s, APPEND=true> (decode self-attention over the K/V cache)"
-                % ("bf16" if esize == 2 else "f32"),
-                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "traffic_source": traffic_src,
-                "avg_launch_us": self_us, "algorithmic_bytes_per_launch": self_bytes / launches, "launches": launches,
-                "method": "HIP events on the launch stream around the whole graph-replayed decode, with and "
-                          "without this kernel in the step graph; (difference)/launches",
-                "decode_ms_single_chain": t_full, "decode_ms_without_self_attn": t_noself,
-                "decode_ms_without_cross_attn": t_nocross,
-                "whole_step_hbm_frac": (self_bytes + cross_bytes) / (t_full * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "cross_attn": {"achieved": cross_bytes / launches / (cross_us * 1e-6) / 1e9, "avg_launch_us": cross_us,
-                               "algorithmic_bytes_per_launch": cross_bytes / launches}}
+        roof = attention_roofline(eng, cfg)
 
-        if not args.no_extras and not corpus and args.model == "mt3" and not args.kv_dtype and not args.dense_dtype:
+        main_line = not corpus and args.model == "mt3" and not args.kv_dtype and not args.dense_dtype and world == 1
+        if not args.no_extras and main_line:
             # ---- stage extras, driver-timed (HIP events on the launch stream, inputs in HBM)
+            esize = 2 if args.dtype == "bfloat16" else 4
             peak = MFMA_BF16_PEAK_TFLOPS if esize == 2 else MFMA_F32_PEAK_TFLOPS
             a256 = audio[:Br]
             lm256 = spectrograms.compute_spectrogram_batch(a256, None)
             fe_ms = timed(lambda: spectrograms.compute_spectrogram_batch(a256, None), reps=20)
             enc_ms = min(timed(lambda: eng.encode(lm256), reps=5) for _ in range(2))
             fe_gbs = FRONTEND_BYTES_PER_SEGMENT * Br / (fe_ms * 1e-3) / 1e9
+            fe_ratio, fe_name, fe_hash = pmc_ratio("logmel_kernel_256_segments", None)
             extras["frontend"] = {"kernel": "mt3::logmel_kernel", "segments": Br, "ms": fe_ms, "bound": "hbm",
                                   "achieved": fe_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fe_gbs / HBM_PEAK_GBS,
-                                  "algorithmic_bytes_per_segment": FRONTEND_BYTES_PER_SEGMENT}
+                                  "algorithmic_bytes_per_segment": FRONTEND_BYTES_PER_SEGMENT,
+                                  "traffic": fe_ratio * FRONTEND_BYTES_PER_SEGMENT * Br if fe_ratio else None,
+                                  "traffic_source": "profiles/%s (frontend sources %s)" % (fe_name, fe_hash)
+                                  if fe_ratio else "no PMC summary for these frontend sources"}
             enc_tf = ENC_GFLOP_PER_SEGMENT * Br / (enc_ms * 1e-3) / 1e3
             extras["encoder"] = {"segments": Br, "ms": enc_ms, "bound": "mfma", "achieved": enc_tf, "peak": peak,
                                  "unit": "TFLOP/s", "frac": enc_tf / peak,
@@ -408,79 +445,93 @@ def main():
             with torch.cuda.stream(stream):
                 eng.encode(lm256)                                    # leave the engine at the bench batch
 
-            # ---- the same workload at the reference's own precision (f32 MFMA operands, f32 K/V cache): one
-            # warm-up + one timed step, printed beside the bf16 value (precision ruling)
-            if args.dtype == "bfloat16" and world == 1:
-                try:
-                    cfg32 = network.T5Config(dtype="float32")
-                    e32 = network.Transformer(cfg32, input_length=256, max_decode_length=L, max_batch=Br)
-                    e32.load_params(network.init_random_params(cfg32, seed=0))
+            free_running = {}          # key -> the token rows [Br, L] of that engine's free-running decode of a256
 
-                    def f32_step():
+            def other_engine(key, ecfg, label, n_steps, with_roofline):
+                """the SAME pipeline as the headline on another engine configuration: one warm-up step, then `n_steps`
+                timed steps (wall clock, synchronised both sides, host note decoding inside)"""
+                try:
+                    e2 = network.Transformer(ecfg, input_length=256, max_decode_length=L, max_batch=Br)
+                    e2.load_params(network.init_random_params(ecfg, seed=0))
+
+                    def one_step():
                         with torch.cuda.stream(stream):
-                            e32.encode(spectrograms.compute_spectrogram_batch(a256, None))
-                            ids = e32.decode(num_steps=args.decode_steps)
+                            e2.encode(spectrograms.compute_spectrogram_batch(a256, None))
+                            ids = e2.decode(num_steps=args.decode_steps)
                             host = vocab.decode_tf(ids).cpu().numpy()
-                        return sum(f.result() for f in host_stage(host))
-                    with torch.cuda.stream(stream):
-                        e32.encode(lm256)
-                        e32.decode(num_steps=2)
+                        free_running[key] = host
+                        return host_stage(host)
+                    for f in one_step():
+                        f.result()
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    f32_step()
+                    futs = []
+                    for _ in range(n_steps):
+                        futs += one_step()
+                    for f in futs:
+                        f.result()
                     torch.cuda.synchronize()
-                    d32 = time.perf_counter() - t1
-                    extras["f32"] = {"value": Br * SEG_SECONDS / d32, "unit": "audio-s/s", "ms_per_step": d32 * 1e3,
-                                     "steps": 1, "dtype": "f32",
-                                     "note": "same workload, reference precision (model.gin:50 dtype float32): f32 "
-                                             "MFMA operands, f32 K/V cache; token-exact vs the oracle "
-                                             "(tests/test_gpu_parity_deep.py)"}
-                    del e32
-                except Exception as ex:                              # the bf16 line must not die with the extra
-                    extras["f32"] = {"value": None, "error": repr(ex)[:300]}
+                    d = (time.perf_counter() - t1) / n_steps
+                    e_ms = min(timed(lambda: e2.encode(lm256), reps=5) for _ in range(2))
+                    rec = {"value": Br * SEG_SECONDS / d, "unit": "audio-s/s", "ms_per_step": d * 1e3, "steps": n_steps,
+                           "warmup": 1, "dtype": ("bf16" if ecfg.dtype == "bfloat16" else "f32") +
+                           (" compute + fp8 (e4m3) K/V caches" if ecfg.kv_dtype else "") +
+                           (" + MXFP8 encoder dense layers" if ecfg.dense_dtype else ""),
+                           "workload": "%s, batch=%d, %d greedy steps, same pipeline as the headline"
+                                       % (label, Br, args.decode_steps),
+                           "encoder_ms": e_ms, "device_bytes": e2.device_bytes,
+                           "graph_fallbacks": e2.status(_lib.STATUS_GRAPH_FALLBACKS)}
+                    if with_roofline:
+                        rec["roofline"] = attention_roofline(e2, ecfg, reps=1)
+                    extras[key] = rec
+                    del e2
+                    return rec
+                except Exception as ex:                              # the headline must not die with an extra
+                    extras[key] = {"value": None, "error": repr(ex)[:300]}
+                    return extras[key]
 
-            # ---- BASELINE configs[4] ingredients, one warm-up + one timed step each (not the headline):
-            #   fp8_kv    : this workload with e4m3 K/V caches (half the bytes of the HBM-bound decode stream)
-            #   fp8_kv_mx8: the same plus the encoder's dense layers / cross-K/V projections as MXFP8 on the scaled MFMA
-            #   configs4  : the ismir2022/base.gin shape (emb 768, 12 heads, 12+12 layers, mlp 2048) with both
-            if args.dtype == "bfloat16" and world == 1:
-                for key, shp, dense, label in (("fp8_kv", network.MT3_SMALL, "", "MT3 (model.gin) shape"),
-                                               ("fp8_kv_mx8", network.MT3_SMALL, "fp8_e4m3", "MT3 (model.gin) shape"),
-                                               ("configs4", network.MT3_BASE, "fp8_e4m3", "ismir2022/base.gin shape")):
+            if args.dtype == "bfloat16":
+                # ---- the same workload at the REFERENCE'S OWN precision (gin/model.gin:50 `dtype = 'float32'`): f32 MFMA
+                # operands, f32 K/V caches, token-exact against the oracle (tests/test_gpu_parity_deep.py); >= 5 timed
+                # steps and its own roofline block (VERDICT r2, next #1a)
+                r32 = other_engine("f32", network.T5Config(dtype="float32"), "MT3 (model.gin) shape, reference precision",
+                                   max(5, min(args.steps, 8)), True)
+                if r32.get("value"):
+                    r32["note"] = ("reference precision (model.gin:50 dtype float32): f32 MFMA operands "
+                                   "(4 x v_mfma_f32_16x16x4_f32 per chunk), f32 K/V cache; token-exact vs the oracle")
+                # ---- BASELINE configs[4] ingredients, one warm-up + 3 timed steps each (not the headline):
+                #   fp8_kv    : this workload with e4m3 K/V caches (half the bytes of the HBM-bound decode stream)
+                #   fp8_kv_mx8: the same plus the encoder's dense layers / cross-K/V projections as MXFP8 on the scaled MFMA
+                #   configs4  : the ismir2022/base.gin shape (emb 768, 12 heads, 12+12 layers, mlp 2048) with both
+                for key, shp, dense, label, wr in (
+                        ("fp8_kv", network.MT3_SMALL, "", "MT3 (model.gin) shape", True),
+                        ("fp8_kv_mx8", network.MT3_SMALL, "fp8_e4m3", "MT3 (model.gin) shape", False),
+                        ("configs4", network.MT3_BASE, "fp8_e4m3", "BASELINE configs[4]: ismir2022/base.gin shape", True)):
+                    c8 = dataclasses.replace(shp, dtype="bfloat16", kv_dtype="fp8_e4m3", dense_dtype=dense)
+                    rec = other_engine(key, c8, label, 3, wr)
+                    if key == "fp8_kv_mx8" and rec.get("value"):
+                        tf8 = ENC_GFLOP_PER_SEGMENT * Br / (rec["encoder_ms"] * 1e-3) / 1e3
+                        extras["encoder_mx8"] = {"segments": Br, "ms": rec["encoder_ms"], "bound": "mfma", "achieved": tf8,
+                                                 "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                 "frac": tf8 / MFMA_FP8_PEAK_TFLOPS,
+                                                 "note": "encoder + cross-K/V projections with MXFP8 operands "
+                                                         "(v_mfma_scale_f32_16x16x128_f8f6f4); attention stays bf16"}
+                # ---- how far the reduced-precision engines' FREE-RUNNING decodes drift from the f32 engine's on the
+                # same 256 segments x 1024 steps (random-init weights: one flipped arg-max re-rolls the rest of a row,
+                # so this is an upper bound on what trained, peaked distributions would show); VERDICT r2 #1c
+                if "f32" in free_running:
                     try:
-                        c8 = dataclasses.replace(shp, dtype="bfloat16", kv_dtype="fp8_e4m3", dense_dtype=dense)
-                        e8 = network.Transformer(c8, input_length=256, max_decode_length=L, max_batch=Br)
-                        e8.load_params(network.init_random_params(c8, seed=0))
+                        from mt3_amd import metrics
                         with torch.cuda.stream(stream):
-                            e8.encode(lm256)
-                            e8.decode(num_steps=2)
-                        torch.cuda.synchronize()
-                        t1 = time.perf_counter()
-                        with torch.cuda.stream(stream):
-                            e8.encode(spectrograms.compute_spectrogram_batch(a256, None))
-                            ids = e8.decode(num_steps=args.decode_steps)
-                            host = vocab.decode_tf(ids).cpu().numpy()
-                        for f in host_stage(host):
-                            f.result()
-                        torch.cuda.synchronize()
-                        d8 = time.perf_counter() - t1
-                        e8_ms = min(timed(lambda: e8.encode(lm256), reps=5) for _ in range(2))
-                        extras[key] = {"value": Br * SEG_SECONDS / d8, "unit": "audio-s/s", "ms_per_step": d8 * 1e3,
-                                       "steps": 1, "dtype": "bf16 compute + fp8 (e4m3) K/V caches" +
-                                                            (" + MXFP8 encoder dense layers" if dense else ""),
-                                       "workload": "%s, batch=%d, %d greedy steps, same pipeline as the headline"
-                                                   % (label, Br, args.decode_steps),
-                                       "encoder_ms": e8_ms, "device_bytes": e8.device_bytes}
-                        if key == "fp8_kv_mx8":
-                            tf8 = ENC_GFLOP_PER_SEGMENT * Br / (e8_ms * 1e-3) / 1e3
-                            extras["encoder_mx8"] = {"segments": Br, "ms": e8_ms, "bound": "mfma", "achieved": tf8,
-                                                     "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                     "frac": tf8 / MFMA_FP8_PEAK_TFLOPS,
-                                                     "note": "encoder + cross-K/V projections with MXFP8 operands "
-                                                             "(v_mfma_scale_f32_16x16x128_f8f6f4); attention stays bf16"}
-                        del e8
+                            free_running["bf16"] = transcribe(lo, Br).cpu().numpy()
+                        extras["divergence_vs_f32"] = {
+                            k: metrics.token_stream_divergence(free_running["f32"], free_running[k], codec)
+                            for k in ("bf16", "fp8_kv", "fp8_kv_mx8") if k in free_running}
+                        extras["divergence_vs_f32"]["note"] = (
+                            "free-running greedy decode of the same %d segments x %d steps, reference = this repo's f32 "
+                            "engine (token-exact vs the oracle); random-init weights" % (Br, args.decode_steps))
                     except Exception as ex:
-                        extras[key] = {"value": None, "error": repr(ex)[:300]}
+                        extras["divergence_vs_f32"] = {"error": repr(ex)[:300]}
 
     if rank == 0:
         segs = n_global * args.steps
@@ -508,7 +559,8 @@ def main():
             "config": {"workload": workload,
                        "segments_per_gpu": n_local, "segments_total": n_global, "decode_steps": args.decode_steps,
                        "segment_seconds": SEG_SECONDS, "decode_chains": args.chains, "decoding": args.decoding,
-                       "parallelism": "dp%d (segments sharded, weights replicated, RCCL all-gather of token rows)"
+                       "file_segments": args.file_segments,
+                       "parallelism": "dp%d (segments sharded, weights replicated, ONE RCCL gather of the token rows to rank 0)"
                                       % world if world > 1 else "single GPU",
                        "step_graph": "hipGraph replay" if used_graph else "DIRECT LAUNCHES (graph capture failed)",
                        "graph_fallbacks": graph_fallbacks,
@@ -517,6 +569,7 @@ def main():
             "rccl_world": dist.get_world_size() if world > 1 else 1,
             "per_rank_ms_per_step": per_rank_ms, "gather_ms": gather_ms,
             "f32_value": extras.get("f32", {}).get("value"),
+            "f32": extras.get("f32"),
             "roofline": roof,
             "extra": extras,
         }
@@ -524,7 +577,8 @@ def main():
             # separate process, hard wall-clock bound: the bench must finish in minutes on any host
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-segments",
-                                    str(args.cpu_segments), "--cpu-enc-segments", str(args.cpu_enc_segments),
+                                    str(args.cpu_segments), "--cpu-small-segments", str(args.cpu_small_segments),
+                                    "--cpu-enc-segments", str(args.cpu_enc_segments),
                                     "--decode-steps", str(args.decode_steps)],
                                    capture_output=True, text=True, timeout=300)
                 line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]

@@ -74,7 +74,9 @@ int mt3_frontend_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segmen
 /* The same with the per-segment frame counts already in DEVICE memory (caller-owned, must stay valid until the
  * launch has run).  mt3_frontend_logmel copies h_n_frames into a pre-sized ring inside the frontend (65536
  * counts, device + pinned mirror, created with the first call's tables): no allocation on the call path, the
- * caller's host buffer is free when the call returns, and calls on different streams never share a slot. */
+ * caller's host buffer is free when the call returns, and calls never share a slot -- slot assignment is serialised
+ * by a mutex (calls may come from several host threads), and when the ring wraps (once per 65536 ragged segments)
+ * the call first waits for the device, so that no queued copy or launch still reads the slots it reuses. */
 int mt3_frontend_logmel_dev(mt3_frontend* fe, const float* d_audio, int32_t n_segments,
                             int32_t frames_per_segment, const int32_t* d_n_frames /* may be NULL */,
                             float* d_logmel, void* stream);
@@ -112,7 +114,20 @@ typedef struct mt3_engine_config {   /* network.T5Config (network.py:25-41), mod
                                    elements on v_mfma_scale_f32_16x16x128_f8f6f4, weights quantised once at finalize,
                                    activations by the producing epilogue; the decode step's M = batch GEMMs stay bf16
                                    (they are launch-latency-bound) */
+  int32_t options;              /* bit set of MT3_OPT_* below; 0 = the defaults every number in DESIGN.md is quoted on */
 } mt3_engine_config;
+
+/* mt3_engine_config.options: numerics-relevant choices of HOW the same function is evaluated (all variants stay inside
+ * the tolerances of DESIGN.md section 4; the tests compare them with each other) */
+enum {
+  /* keep the residual stream as ONE f32 stream with in-kernel RMSNorm statistics (the f32 engine always does; the
+   * bf16 engine otherwise carries f32 rows + bf16 copy + per-16-column sums of squares) */
+  MT3_OPT_SINGLE_RESIDUAL_STREAM = 1,
+  /* decoder: the projections that consume a freshly updated residual row (cross-attention query; next layer's
+   * q/k/v) get a launch of their own instead of riding as extra output columns in the neighbouring launches
+   * (linearity of the residual update) */
+  MT3_OPT_SEPARATE_PROJECTIONS = 2
+};
 
 typedef struct mt3_engine mt3_engine;
 
@@ -150,13 +165,9 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch,
 enum {
   MT3_DECODE_NO_GRAPH = 1,
   MT3_DECODE_EARLY_EXIT = 2,
-  MT3_DECODE_BEAM1 = 4,
-  /* profiling only: drop the self / cross decode-attention launches from every step (output invalid);
-   * (full decode time) - (time without the kernel) = in-situ time of that kernel, measured with two
-   * HIP events around the whole graph-replayed decode instead of 8192 per-launch event pairs */
-  MT3_DECODE_SKIP_SELF_ATTN = 8,
-  MT3_DECODE_SKIP_CROSS_ATTN = 16
-  /* bits 8..11: number of decode chains for this call (1..8); 0 = the engine's configured default */
+  MT3_DECODE_BEAM1 = 4
+  /* bits 8..11: number of decode chains for this call (1..8); 0 = the engine's configured default.
+   * Any other bit is rejected with MT3_ERR_INVALID (profiling variants live in mt3_hip_debug.h). */
 };
 #define MT3_DECODE_CHAINS(n) (((n) & 0xF) << 8)
 int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags,
@@ -216,8 +227,9 @@ int mt3_op_encoder_attention(int32_t dtype, const void* d_qkv, void* d_out, int3
  * attending positions 0..n_keys-1; if d_new_kv != NULL its [B, 2, H, 64]-strided K/V rows (row stride
  * kv_stride, K at +0 and V at +H*64) are first appended at position n_keys-1.  With d_step != NULL the key
  * count is read PER ROW from device memory: n_keys = d_step[b] + 1.  The kernel requests its first group of
- * keys before it knows the row's length and masks what lies past it: cache rows beyond n_keys (up to `cap`) must
- * hold FINITE values (zero-fill the cache once; the engine does). */
+ * keys before it knows the row's length; what lies past the row's length is discarded BY POSITION (selected away,
+ * never multiplied by a zero weight), so cache rows beyond n_keys may hold anything, NaN / Inf patterns included
+ * (they only have to be addressable up to `cap`). */
 int mt3_op_decode_attention(int32_t dtype, const void* d_q, int32_t q_stride, void* d_kcache, void* d_vcache,
                             int32_t cap, const void* d_new_k, const void* d_new_v, int32_t kv_stride,
                             const int32_t* d_step, int32_t n_keys, void* d_out, int32_t B, int32_t H, void* stream);

@@ -1,0 +1,43 @@
+/*
+ * mt3_hip_debug.h -- measurement and fault-injection entry points of libmt3hip.so.
+ *
+ * NOT part of the product ABI (include/mt3_hip.h): nothing here has a counterpart in the reference
+ * (magenta/mt3), a drop-in caller never needs it, and results of the "skip" variants are meaningless.
+ * bench.py uses mt3_debug_engine_decode for the in-situ duration of the decode-attention kernels
+ * (a difference of whole-decode times instead of 8192 per-launch event pairs), tests use
+ * mt3_debug_engine_poison_caches to prove that stale cache contents cannot leak into results, and
+ * tools/ sweeps launch shapes with mt3_debug_set_knob.  Same conventions as mt3_hip.h.
+ */
+#ifndef MT3_HIP_DEBUG_H_
+#define MT3_HIP_DEBUG_H_
+
+#include <stdint.h>
+
+#include "mt3_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mt3_engine_decode with kernels LEFT OUT of every step (ids are garbage): `skip` is a bit set of the values
+ * below.  flags as for mt3_engine_decode. */
+enum { MT3_DEBUG_SKIP_SELF_ATTN = 1, MT3_DEBUG_SKIP_CROSS_ATTN = 2 };
+int mt3_debug_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t skip,
+                            int32_t* d_ids, void* stream);
+
+/* Fill the engine's self-attention K/V caches (and, with fp8 caches, their scale arrays) with the byte `pattern`
+ * (0xFF = NaN in bf16 / f32 / e4m3; 0x7F.. etc.), and with cross != 0 also the cross-attention K/V buffers
+ * (call it BEFORE mt3_engine_encode then: encode rewrites the rows of its batch).  A decode that follows must
+ * return exactly the ids it returns over zero-filled caches. */
+int mt3_debug_engine_poison_caches(mt3_engine* e, int32_t pattern, int32_t cross, void* stream);
+
+/* Process-wide launch-shape knobs (results do not change, only speed); value 0 = back to the default.
+ *   DEC_ATTN_WAVES / DEC_ATTN_FP8_WAVES: waves per (row, head) workgroup of the decode attention (2, 3, 4)
+ *   NO_LDS_DMA_GEMM: encoder GEMMs on the register-staged tile instead of the LDS-DMA ring */
+enum { MT3_DEBUG_KNOB_DEC_ATTN_WAVES = 0, MT3_DEBUG_KNOB_DEC_ATTN_FP8_WAVES = 1, MT3_DEBUG_KNOB_NO_LDS_DMA_GEMM = 2 };
+int mt3_debug_set_knob(int32_t knob, int32_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MT3_HIP_DEBUG_H_ */

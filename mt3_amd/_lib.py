@@ -16,7 +16,11 @@ LIB_PATH = os.path.join(HERE, "libmt3hip.so")
 MT3_OK, MT3_ERR_INVALID, MT3_ERR_HIP, MT3_ERR_CAPACITY, MT3_ERR_MISSING = 0, -1, -2, -3, -4
 MT3_BF16, MT3_F32, MT3_FP8_E4M3 = 0, 1, 2
 EPI_STORE, EPI_RESID, EPI_GEGLU, EPI_POS, EPI_F32, EPI_HEADS = range(6)
-DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SKIP_SELF_ATTN, DECODE_SKIP_CROSS_ATTN = 1, 2, 4, 8, 16
+DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1 = 1, 2, 4
+OPT_SINGLE_RESIDUAL_STREAM, OPT_SEPARATE_PROJECTIONS = 1, 2                   # mt3_engine_config.options
+# include/mt3_hip_debug.h (measurement / fault injection; not the product ABI)
+DEBUG_SKIP_SELF_ATTN, DEBUG_SKIP_CROSS_ATTN = 1, 2
+DEBUG_KNOB_DEC_ATTN_WAVES, DEBUG_KNOB_DEC_ATTN_FP8_WAVES, DEBUG_KNOB_NO_LDS_DMA_GEMM = 0, 1, 2
 (STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8, STATUS_Q_FOLD,
  STATUS_DENSE_FP8) = range(6)
 EV_SHIFT, EV_PITCH, EV_VELOCITY, EV_TIE, EV_PROGRAM, EV_DRUM = range(6)
@@ -39,7 +43,7 @@ class EngineConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "vocab_size", "emb_dim", "num_heads", "head_dim", "mlp_dim", "num_encoder_layers",
         "num_decoder_layers", "input_depth", "input_length", "max_decode_len", "max_batch", "compute_dtype",
-        "decode_chains", "kv_cache_dtype", "dense_dtype")]
+        "decode_chains", "kv_cache_dtype", "dense_dtype", "options")]
 
 
 class EventRange(C.Structure):
@@ -56,7 +60,7 @@ class NoteStruct(C.Structure):
                 ("instrument", C.c_int32), ("reserved", C.c_int32)]
 
 
-# every symbol include/mt3_hip.h declares: (name, restype, argtypes)
+# every symbol include/mt3_hip.h and include/mt3_hip_debug.h declare: (name, restype, argtypes)
 _P = C.c_void_p
 SIGNATURES = {
     "mt3_last_error": (C.c_char_p, []),
@@ -75,6 +79,9 @@ SIGNATURES = {
     "mt3_engine_decode": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), _P]),
     "mt3_engine_decode_forced": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "mt3_engine_status": (C.c_int, [_P, C.c_int32]),
+    "mt3_debug_engine_decode": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mt3_debug_engine_poison_caches": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "mt3_debug_set_knob": (C.c_int, [C.c_int32, C.c_int32]),
     "mt3_ids_to_tokens": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mt3_op_gemm": (C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                               C.c_int32, _P, C.c_int32, C.c_int32, _P]),

@@ -27,8 +27,6 @@
 //     layers.py:272-292).
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "common.h"
 #include "device.h"
 #include "kernels.h"
@@ -401,8 +399,8 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   const CT* vc = static_cast<const CT*>(a.vcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;
   // The first group of keys is requested BEFORE the row's position counter is known (its load would otherwise sit
   // in front of every cache load: one dependent memory round trip per launch): positions past the row's length are
-  // masked below, the memory behind them is always valid (the cache is allocated to `cap` rows and zero-filled at
-  // engine creation; whatever an earlier, longer decode left there is finite and gets weight 0).
+  // discarded below, the memory behind them is always addressable (the cache is allocated to `cap` rows); its
+  // CONTENTS do not matter (tests/test_gpu_kernels.py poisons them with NaN patterns).
   u32x4 kv0[UNROLL], vv0[UNROLL];
 #pragma unroll
   for (int u = 0; u < UNROLL; ++u) {
@@ -413,6 +411,12 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   const int n_keys = a.step ? (a.step[b] + 1) : a.n_keys;      // per-row position counter
   const int pos = n_keys - 1;
   const int n_cache = APPEND ? pos : n_keys;                   // keys that come from the cache
+  // what the speculative loads fetched from beyond the row's length is DISCARDED BY POSITION: the V chunk is replaced
+  // by zeros (a zero weight alone would turn a stale Inf / NaN pattern into NaN through 0 * x), the score is never
+  // looked at (selects in `fold`).  Later groups clamp their addresses to the row's own last cached key instead.
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u)
+    if (wave * KPW + slot + u * STRIDE >= n_cache) vv0[u] = u32x4{0u, 0u, 0u, 0u};
 
   u32x4 new_k = {0u, 0u, 0u, 0u}, new_v = {0u, 0u, 0u, 0u};
   if constexpr (APPEND) {
@@ -597,11 +601,13 @@ __device__ __forceinline__ u32x4 fp8_quantize_quad(float* v, float* scale_out) {
   float am = 0.f;
 #pragma unroll
   for (int j = 0; j < 16; ++j) am = fmaxf(am, fabsf(v[j]));
-  am = quad_max(am);
+  am = fminf(quad_max(am), 3.0e38f);                                           // Inf / NaN inputs: a finite scale
   const float sc = fp8_row_scale(am), inv = 1.f / sc;                          // exact: powers of two
   float t[16];
+  // (clamped to e4m3fn's finite range: a non-finite activation must not leave NaN bytes in the cache for every
+  // later step to read; finite rows are untouched, their |v / sc| is < 256)
 #pragma unroll
-  for (int j = 0; j < 16; ++j) t[j] = v[j] * inv;
+  for (int j = 0; j < 16; ++j) t[j] = fminf(fmaxf(v[j] * inv, -448.f), 448.f);
   const u32x4 c = f32x16_to_fp8(t);
   fp8x16_to_f32(c, t);
 #pragma unroll
@@ -628,8 +634,8 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
   const uint8_t* kc = static_cast<const uint8_t*>(a.kcache) + head * D;
   const uint8_t* vc = static_cast<const uint8_t*>(a.vcache) + head * D;
   const float2* sc2 = a.kv_scale + head;
-  // first key group requested before the row's position counter is known (see dec_attn_kernel): the cache and its
-  // scale array are zero-filled at engine creation, so what lies past the row's length is finite and gets weight 0
+  // first key group requested before the row's position counter is known (see dec_attn_kernel); discarded by
+  // position below, so the contents of the cache and of its scale array past the row's length do not matter
   u32x4 kv0[UNROLL], vv0[UNROLL];
   float2 ss0[UNROLL];
 #pragma unroll
@@ -642,6 +648,13 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
   const int n_keys = a.step ? (a.step[b] + 1) : a.n_keys;
   const int pos = n_keys - 1;
   const int n_cache = APPEND ? pos : n_keys;
+  // discard by position what the speculative loads fetched from beyond the row's length (see dec_attn_kernel)
+#pragma unroll
+  for (int u = 0; u < UNROLL; ++u)
+    if (wave * KPW + slot + u * STRIDE >= n_cache) {
+      vv0[u] = u32x4{0u, 0u, 0u, 0u};
+      ss0[u] = make_float2(0.f, 0.f);
+    }
 
   // q: 16 bf16 of this lane's slice -> f32, pre-multiplied by log2(e) (base-2 softmax)
   float q[EPL];
@@ -836,21 +849,12 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
   // waves per (batch, head) workgroup.  B*H workgroups must all be resident for an even HBM stream:
   // at 84 VGPRs a CU holds 20 waves, so 3 waves per workgroup keeps B*H = 1536 groups (4608 waves)
   // co-resident on 256 CUs, while 4 would leave a 256-group second round running at 1/5 occupancy.
-  static const int nw = [] {
-    const char* v = getenv("MT3_DEC_ATTN_WAVES");
-    const int n = v ? atoi(v) : 3;
-    return (n == 2 || n == 3 || n == 4) ? n : 3;
-  }();
+  const int nw = g_knobs.dec_attn_waves ? g_knobs.dec_attn_waves : 3;
   if (a.kv_scale) {
     // waves per (row, head) workgroup, measured on MI355X at B = 256 (tools/gpu_fp8.sh): the growing self-attention
     // cache streams best with 3 (22.8 us against 23.7 / 24.0 with 2 / 4 at the mean depth); the fixed 256-key
     // cross-attention with 4 (one whole 64-key x 4 pass per wave: 12.4 us against 13.4 with 3)
-    static const int nw_env = [] {
-      const char* v = getenv("MT3_DEC_ATTN_FP8_WAVES");
-      const int n = v ? atoi(v) : 0;
-      return (n == 2 || n == 3 || n == 4) ? n : 0;
-    }();
-    const int nw = nw_env ? nw_env : (append ? 3 : 4);
+    const int nw = g_knobs.dec_attn_fp8_waves ? g_knobs.dec_attn_fp8_waves : (append ? 3 : 4);
     const dim3 grid(a.B * a.H), block(nw * 64);
     // fp8 (e4m3) K/V cache; activations (q, new rows, out) are bf16
     if (dtype != MT3_BF16) return mt3::fail(MT3_ERR_INVALID, "decode_attention: the fp8 K/V cache needs bf16 activations");

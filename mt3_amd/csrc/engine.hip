@@ -38,6 +38,7 @@
 #include "kernels.h"
 #include "mx8.h"
 #include "mt3_hip.h"
+#include "mt3_hip_debug.h"
 
 namespace {
 
@@ -582,6 +583,8 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: dense_dtype must be 0 (= compute dtype) or MT3_FP8_E4M3");
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
+  if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS))
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
   e->cfg = *cfg;
@@ -659,8 +662,9 @@ int mt3_engine_finalize(mt3_engine* e) {
     if ((rc = upload_f32(e, w->data, &e->embedding))) return rc;
   }
   e->dec.resize(c.num_decoder_layers);
-  const bool q_fold = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && (emb <= 512 || emb == 768) && emb <= 1024 &&
-                      !getenv("MT3_NO_Y_SPLIT") && !getenv("MT3_NO_QFOLD");
+  const bool single_stream = (c.options & MT3_OPT_SINGLE_RESIDUAL_STREAM) != 0;
+  const bool q_fold = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && (emb <= 512 || emb == 768) && !single_stream &&
+                      !(c.options & MT3_OPT_SEPARATE_PROJECTIONS);
   e->q_fold = q_fold;
   for (int l = 0; l < c.num_decoder_layers; ++l) {
     const std::string P = "decoder/layers_" + std::to_string(l);
@@ -716,7 +720,7 @@ int mt3_engine_finalize(mt3_engine* e) {
   // ---- workspaces
   const size_t M = static_cast<size_t>(Bm) * T;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x), M * emb * 4))) return rc;
-  e->x_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && emb <= 1024 && !getenv("MT3_NO_X_SPLIT") && !e->dense_fp8;
+  e->x_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && emb <= 1024 && !single_stream && !e->dense_fp8;
   if (e->x_split) {
     if ((rc = dmalloc(e, &e->x_ct, M * emb * 2))) return rc;
     if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x_ss), M * (emb / 16) * 4))) return rc;
@@ -737,7 +741,7 @@ int mt3_engine_finalize(mt3_engine* e) {
   if ((rc = dmalloc(e, &e->hbuf, M * c.mlp_dim * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->enc_out, M * emb * e->esize))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y), static_cast<size_t>(Bm) * emb * 4))) return rc;
-  e->y_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && (emb <= 512 || emb == 768) && !getenv("MT3_NO_Y_SPLIT");
+  e->y_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && (emb <= 512 || emb == 768) && !single_stream;
   if (e->y_split) {
     if ((rc = dmalloc(e, &e->y_ct, static_cast<size_t>(Bm) * emb * 2))) return rc;
     if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y_ss), static_cast<size_t>(Bm) * (emb / 16) * 4))) return rc;
@@ -844,7 +848,9 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
     e->cur_batch = batch;
     return MT3_OK;
   }
-  const bool xs = e->x_split;
+  // the split residual form feeds the LDS-DMA tile (K <= 1024); the decode-sized tile a small batch selects holds the
+  // partial sums of K <= 512 or K = 768 only, so a small batch of a wider model stays on the single f32 stream
+  const bool xs = e->x_split && !(small && !(emb <= 512 || emb == 768));
   if (xs) MT3_TRY(mt3k::launch_residual_split(e->x, e->x_ct, e->x_ss, M, emb, s));
   auto normed = [&](const void* Wt, void* out, int N, int ldo) {
     mt3k::GemmArgs g = gemm_args(xs ? static_cast<const void*>(e->x_ct) : static_cast<const void*>(e->x), Wt, out, M,
@@ -882,15 +888,17 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
 }
 
 // shared body of mt3_engine_decode / mt3_engine_decode_forced
-static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, const int32_t* d_forced,
-                       float* d_step_logits, int32_t* d_ids, float* d_first_logits, int32_t* h_steps_run,
-                       void* stream) {
+static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t debug_skip,
+                       const int32_t* d_forced, float* d_step_logits, int32_t* d_ids, float* d_first_logits,
+                       int32_t* h_steps_run, void* stream) {
   if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: engine not finalized");
   if (batch <= 0 || batch != e->cur_batch)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: batch must equal the batch of the preceding encode");
   const mt3_engine_config& c = e->cfg;
   if (num_steps <= 0 || num_steps > c.max_decode_len || !d_ids)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: num_steps out of range or null ids");
+  if (flags & ~(MT3_DECODE_NO_GRAPH | MT3_DECODE_EARLY_EXIT | MT3_DECODE_BEAM1 | MT3_DECODE_CHAINS(0xF)))
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: unknown flag bit");
   const bool beam1 = (flags & MT3_DECODE_BEAM1) != 0;
   if (d_forced && (beam1 || (flags & MT3_DECODE_EARLY_EXIT)))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode_forced: not combinable with BEAM1 / EARLY_EXIT");
@@ -907,10 +915,9 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
   MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y, e->y_ct, e->y_ss, batch, c.emb_dim,
                              s));
 
-  // profiling-only variants: leave the self (1) / cross (2) attention launches out of the step, so that
-  // their in-situ cost can be read as a DIFFERENCE of whole-decode times (results are garbage)
-  const int skip = ((flags & MT3_DECODE_SKIP_SELF_ATTN) ? 1 : 0) | ((flags & MT3_DECODE_SKIP_CROSS_ATTN) ? 2 : 0) |
-                   (beam1 ? 4 : 0) | (d_forced ? 8 : 0);
+  // step-graph variant: bits 1 / 2 = mt3_debug_engine_decode's skipped kernels (mt3_hip_debug.h; never set by the
+  // product entry points), 4 = beam-1 selection, 8 = teacher forcing
+  const int skip = (debug_skip & 3) | (beam1 ? 4 : 0) | (d_forced ? 8 : 0);
   if (beam1) {
     // t5x beam_search(alpha = 0.6): live log-prob 0, nothing finished; the loop bound uses the brevity
     // penalty of max_decode_len + 1 (the dummy start token extends the length by one).  The value travels as a
@@ -952,13 +959,39 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
 
 int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t* d_ids,
                       float* d_first_logits, int32_t* h_steps_run, void* stream) {
-  return decode_impl(e, batch, num_steps, flags, nullptr, nullptr, d_ids, d_first_logits, h_steps_run, stream);
+  return decode_impl(e, batch, num_steps, flags, 0, nullptr, nullptr, d_ids, d_first_logits, h_steps_run, stream);
 }
 
 int mt3_engine_decode_forced(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags,
                              const int32_t* d_forced_ids, float* d_step_logits, int32_t* d_ids, void* stream) {
   if (!d_forced_ids) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode_forced: null forced ids");
-  return decode_impl(e, batch, num_steps, flags, d_forced_ids, d_step_logits, d_ids, nullptr, nullptr, stream);
+  return decode_impl(e, batch, num_steps, flags, 0, d_forced_ids, d_step_logits, d_ids, nullptr, nullptr, stream);
+}
+
+// ---- mt3_hip_debug.h
+int mt3_debug_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t skip,
+                            int32_t* d_ids, void* stream) {
+  if (skip & ~(MT3_DEBUG_SKIP_SELF_ATTN | MT3_DEBUG_SKIP_CROSS_ATTN))
+    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode: unknown skip bit");
+  return decode_impl(e, batch, num_steps, flags, skip, nullptr, nullptr, d_ids, nullptr, nullptr, stream);
+}
+
+int mt3_debug_engine_poison_caches(mt3_engine* e, int32_t pattern, int32_t cross, void* stream) {
+  if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_poison_caches: engine not finalized");
+  const mt3_engine_config& c = e->cfg;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t heads = static_cast<size_t>(c.max_batch) * c.num_heads;
+  for (LayerDev& L : e->dec) {
+    const size_t kvb = heads * c.max_decode_len * 64 * e->kv_esize;
+    MT3_HIP_CHECK(hipMemsetAsync(L.self_k, pattern, kvb, s));
+    MT3_HIP_CHECK(hipMemsetAsync(L.self_v, pattern, kvb, s));
+    if (L.self_scale) MT3_HIP_CHECK(hipMemsetAsync(L.self_scale, pattern, heads * c.max_decode_len * sizeof(float2), s));
+    if (cross) {
+      MT3_HIP_CHECK(hipMemsetAsync(L.cross_kv, pattern, 2 * heads * c.input_length * 64 * e->kv_esize, s));
+      if (L.cross_scale) MT3_HIP_CHECK(hipMemsetAsync(L.cross_scale, pattern, heads * c.input_length * sizeof(float2), s));
+    }
+  }
+  return MT3_OK;
 }
 
 int mt3_engine_status(const mt3_engine* e, int32_t what) {

@@ -2,6 +2,8 @@
 #include <string>
 
 #include "common.h"
+#include "knobs.h"
+#include "mt3_hip_debug.h"
 
 namespace {
 thread_local std::string g_last_error;
@@ -14,7 +16,26 @@ int fail(int code, const std::string& msg) {
 }
 }  // namespace mt3
 
+namespace mt3k {
+Knobs g_knobs = {0, 0, 0};
+}
+
 extern "C" {
 const char* mt3_last_error(void) { return g_last_error.c_str(); }
-int mt3_abi_version(void) { return 1; }
+int mt3_abi_version(void) { return 2; }   // 2: mt3_engine_config.options; profiling flags moved to mt3_hip_debug.h
+
+int mt3_debug_set_knob(int32_t knob, int32_t value) {
+  switch (knob) {
+    case MT3_DEBUG_KNOB_DEC_ATTN_WAVES:
+    case MT3_DEBUG_KNOB_DEC_ATTN_FP8_WAVES:
+      if (value != 0 && (value < 2 || value > 4)) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_set_knob: waves must be 0, 2, 3 or 4");
+      (knob == MT3_DEBUG_KNOB_DEC_ATTN_WAVES ? mt3k::g_knobs.dec_attn_waves : mt3k::g_knobs.dec_attn_fp8_waves) = value;
+      return MT3_OK;
+    case MT3_DEBUG_KNOB_NO_LDS_DMA_GEMM:
+      mt3k::g_knobs.no_lds_dma_gemm = value != 0;
+      return MT3_OK;
+    default:
+      return mt3::fail(MT3_ERR_INVALID, "mt3_debug_set_knob: unknown knob");
+  }
+}
 }

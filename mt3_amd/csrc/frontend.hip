@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -170,6 +171,7 @@ struct mt3_frontend {
   int* d_nframes = nullptr;
   int* h_nframes = nullptr;
   int ring_pos = 0;
+  std::mutex ring_mutex;         // ring_pos / first-call table upload: calls may come from several host threads
   bool on_device = false;
 };
 
@@ -217,8 +219,7 @@ int mt3_frontend_mel_matrix(const mt3_frontend* fe, float* h_out, int64_t* nnz) 
 
 constexpr int kNFramesRing = 1 << 16;   // segments' worth of frame counts that can be in flight at once
 
-static int ensure_device_tables(mt3_frontend* fe) {
-  if (fe->on_device) return MT3_OK;
+static int upload_all(mt3_frontend* fe) {
   int rc;
   if ((rc = upload(fe->host.hann, &fe->d_hann))) return rc;
   if ((rc = upload(fe->host.tw1024, &fe->d_tw1024))) return rc;
@@ -229,6 +230,26 @@ static int ensure_device_tables(mt3_frontend* fe) {
   if ((rc = upload(fe->wpad, &fe->d_w))) return rc;
   MT3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&fe->d_nframes), sizeof(int) * kNFramesRing));
   MT3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&fe->h_nframes), sizeof(int) * kNFramesRing, hipHostMallocDefault));
+  return MT3_OK;
+}
+
+static int ensure_device_tables(mt3_frontend* fe) {
+  std::lock_guard<std::mutex> lock(fe->ring_mutex);
+  if (fe->on_device) return MT3_OK;
+  const int rc = upload_all(fe);
+  if (rc != MT3_OK) {
+    // a failed first call leaves nothing behind: the next call starts from scratch instead of leaking the tables
+    // that did get uploaded (the error message of the failing step is kept)
+    void** ptrs[] = {&fe->d_hann, &fe->d_tw1024, &fe->d_tw2048, &fe->d_k0, &fe->d_cnt, &fe->d_off, &fe->d_w,
+                     reinterpret_cast<void**>(&fe->d_nframes)};
+    for (void** p : ptrs) {
+      if (*p) (void)hipFree(*p);
+      *p = nullptr;
+    }
+    if (fe->h_nframes) (void)hipHostFree(fe->h_nframes);
+    fe->h_nframes = nullptr;
+    return rc;
+  }
   fe->on_device = true;
   return MT3_OK;
 }
@@ -268,8 +289,18 @@ int mt3_frontend_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segmen
     for (int i = 0; i < n_segments; ++i)
       if (h_n_frames[i] < 0 || h_n_frames[i] > frames_per_segment)
         return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_logmel: n_frames out of range");
-    const int at = fe->ring_pos + n_segments <= kNFramesRing ? fe->ring_pos : 0;
-    fe->ring_pos = at + n_segments;
+    int at;
+    {
+      std::lock_guard<std::mutex> lock(fe->ring_mutex);
+      at = fe->ring_pos;
+      if (at + n_segments > kNFramesRing) {
+        // the ring wraps: slots from the previous lap may still be read by copies / launches queued on ANY stream.
+        // Once per 65536 ragged segments the call waits for the device instead of overwriting them.
+        MT3_HIP_CHECK(hipDeviceSynchronize());
+        at = 0;
+      }
+      fe->ring_pos = at + n_segments;
+    }
     std::memcpy(fe->h_nframes + at, h_n_frames, sizeof(int) * n_segments);      // the caller's buffer is free again
     MT3_HIP_CHECK(hipMemcpyAsync(fe->d_nframes + at, fe->h_nframes + at, sizeof(int) * n_segments,
                                  hipMemcpyHostToDevice, s));

@@ -23,8 +23,6 @@
 // pairs swap over DPP); XCD-aware block remap so that the column tiles of one row panel share an L2.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
-
 #include "common.h"
 #include "device.h"
 #include "kernels.h"
@@ -718,8 +716,7 @@ static int launch_glds(const GemmArgs& g, hipStream_t s) {
 }
 // big tile, bf16, both operands bf16 in memory, K a multiple of 64 (<= 1024 with norm 2), N of 128
 static bool glds_eligible(const GemmArgs& g, bool a_f32, int norm, int epi) {
-  static const bool off = getenv("MT3_NO_GLDS") != nullptr;
-  if (off || a_f32 || norm == 1 || g.K % 64 || g.N % 128 || g.lda % 8) return false;   // (K % 64: norm-2 partials)
+  if (g_knobs.no_lds_dma_gemm || a_f32 || norm == 1 || g.K % 64 || g.N % 128 || g.lda % 8) return false;   // (K % 64: norm-2 partials)
   if (norm == 2 && (!g.a_ss || g.K > 1024)) return false;
   return epi == MT3_EPI_STORE || epi == MT3_EPI_RESID || epi == MT3_EPI_GEGLU || epi == MT3_EPI_HEADS ||
          epi == MT3_EPI_F32;
@@ -770,6 +767,8 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
       return launch_cfg<CT, 32, 32, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
     }
   }
+  if constexpr (!NORM && !A_F32)
+    if (g.a_ss && g.K > 512) return launch_cfg<CT, 128, 128, KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
   return launch_cfg<CT, 128, 128, KG, 2, 2, A_F32, NORM, EPI>(g, s);
 }
 
@@ -777,8 +776,9 @@ template <typename CT>
 static int launch_typed(const GemmArgs& g, bool a_f32, int norm, int epi, bool small, hipStream_t s) {
   // Only the combinations the engine uses are instantiated.
   if (norm == 2) {
-    if (a_f32 || !g.a_ss || g.K % 64 || (g.K > 512 && g.K != 768))
-      return mt3::fail(MT3_ERR_INVALID, "gemm: norm 2 needs a compute-type A, a_ss and K = 64n <= 512 (or 768)");
+    if (a_f32 || !g.a_ss || g.K % 64 || (small ? (g.K > 512 && g.K != 768) : g.K > 1024))
+      return mt3::fail(MT3_ERR_INVALID, "gemm: norm 2 needs a compute-type A, a_ss and K = 64n <= 512 or 768 (decode-sized "
+                                        "tile) / <= 1024 (encoder-sized tiles)");
     switch (epi) {
       case MT3_EPI_STORE: return launch_tile<CT, false, false, MT3_EPI_STORE>(g, small, s);
       case MT3_EPI_GEGLU: return launch_tile<CT, false, false, MT3_EPI_GEGLU>(g, small, s);

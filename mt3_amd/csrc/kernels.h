@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "knobs.h"
 #include "mt3_hip.h"
 
 namespace mt3k {

@@ -1,0 +1,16 @@
+// Launch-shape knobs behind mt3_debug_set_knob (include/mt3_hip_debug.h; defined in errors.cpp).
+// 0 = the measured default.  The product never reads an environment variable.
+#ifndef MT3_KNOBS_H_
+#define MT3_KNOBS_H_
+
+namespace mt3k {
+
+struct Knobs {
+  int dec_attn_waves;       // waves per decode-attention workgroup (2 / 3 / 4)
+  int dec_attn_fp8_waves;
+  int no_lds_dma_gemm;      // encoder GEMMs on the register-staged tile
+};
+extern Knobs g_knobs;
+
+}  // namespace mt3k
+#endif  // MT3_KNOBS_H_

@@ -188,11 +188,55 @@ class InferenceModel(object):
         return trim_eos(tokens)
 
 
+def _varint(buf: bytes, i: int):
+    v, shift = 0, 0
+    while True:
+        b = buf[i]
+        i += 1
+        v |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return v, i
+        shift += 7
+
+
+def note_sequence_id(sequence) -> str:
+    """`NoteSequence.id` of the task example's 'sequence' feature (mt3/inference.py:83-86,133: the reference parses the
+    serialized proto with note_seq and writes `ref_ns.id`).  Accepts an object with an `.id`, a str (taken as the id),
+    or the SERIALIZED proto bytes: `string id = 1` of note_seq's music.proto [field number from memory], read straight
+    off the protobuf wire format (tag = field << 3 | wire type; 0 varint, 1 fixed64, 2 length-delimited, 5 fixed32)."""
+    if hasattr(sequence, "id"):
+        return str(sequence.id)
+    if isinstance(sequence, str):
+        return sequence
+    buf = bytes(sequence)
+    i = 0
+    while i < len(buf):
+        tag, i = _varint(buf, i)
+        field, wt = tag >> 3, tag & 7
+        if wt == 0:
+            _, i = _varint(buf, i)
+        elif wt == 1:
+            i += 8
+        elif wt == 5:
+            i += 4
+        elif wt == 2:
+            n, i = _varint(buf, i)
+            if field == 1:
+                return buf[i:i + n].decode("utf-8")
+            i += n
+        else:
+            raise ValueError("note_sequence_id: unsupported protobuf wire type %d" % wt)
+    return ""                                     # proto3 default: an unset id is the empty string
+
+
 def write_inferences_to_file(path: str, inferences: Sequence[Any], task_ds, mode: str, vocabulary=None,
                              vocab_config=None, onsets_only=None, use_ties=None) -> None:
     """mt3/inference.py:34-138: one JSON line {"id", "est_notes": [...]} per track.
-    `task_ds`: iterable of dicts with 'input_times', 'unique_id' (and optionally 'raw_inputs');
-    `inferences`: one int32 id row per example (model ids, before decode_tf)."""
+    `task_ds`: iterable of dicts with 'input_times', 'unique_id' (and optionally 'raw_inputs', 'sequence');
+    `inferences`: one int32 id row per example (model ids, before decode_tf).
+    "id": as in the reference (:83-86,133) the `id` of the NoteSequence the track's examples carry in 'sequence'
+    (first non-empty one per `unique_id`; every track must then have one: the reference asserts it, :114); a task
+    dataset WITHOUT a 'sequence' feature (plain inference, no ground truth) writes the `unique_id` itself."""
     if mode == "score":
         raise ValueError("`score` mode currently not supported in MT3")
     if not vocabulary:
@@ -213,20 +257,31 @@ def write_inferences_to_file(path: str, inferences: Sequence[Any], task_ds, mode
         x = np.asarray(x)
         return x.reshape(-1)[0] if x.ndim else x[()]
 
-    predictions = []
+    predictions, ref_ids, any_sequence = [], {}, False
     for inp, output in zip(task_ds, inferences):
         tokens = trim_eos(vocabulary.decode_tf(np.asarray(output, np.int32)))
         start_time = float(first(inp["input_times"]))
         start_time -= start_time % (1 / codec.steps_per_second)
         uid = first(inp["unique_id"])
-        predictions.append({"unique_id": uid.decode() if isinstance(uid, bytes) else str(uid),
+        uid = uid.decode() if isinstance(uid, bytes) else str(uid)
+        if "sequence" in inp:
+            any_sequence = True
+            seq = inp["sequence"]
+            seq = seq if hasattr(seq, "id") or isinstance(seq, (str, bytes)) else first(seq)
+            if isinstance(seq, (bytes, str)) and len(seq) == 0:
+                seq = None                        # later segments of a track carry an empty string (:85)
+            if seq is not None:
+                ref_ids[uid] = note_sequence_id(seq)          # (the reference keeps the last one it sees as well, :104-108)
+        predictions.append({"unique_id": uid,
                             "est_tokens": tokens, "start_time": start_time,
                             "raw_inputs": inp.get("raw_inputs", [])})
     full = metrics_utils.combine_predictions_by_id(
         predictions, lambda preds: metrics_utils.event_predictions_to_ns(preds, codec=codec,
                                                                          encoding_spec=encoding_spec))
+    if any_sequence:
+        assert sorted(ref_ids.keys()) == sorted(full.keys())          # mt3/inference.py:114
     with open(path, "w") as f:
         for uid in sorted(full.keys()):
             notes = [{"start_time": n.start_time, "end_time": n.end_time, "pitch": n.pitch, "velocity": n.velocity,
                       "program": n.program, "is_drum": n.is_drum} for n in full[uid]["est_ns"].notes]
-            f.write(json.dumps({"id": uid, "est_notes": notes}) + "\n")
+            f.write(json.dumps({"id": ref_ids[uid] if any_sequence else uid, "est_notes": notes}) + "\n")

@@ -114,7 +114,10 @@ class Transformer:
     """One engine per (device, stream)."""
 
     def __init__(self, config: T5Config, input_length: int = 256, max_decode_length: int = 1024,
-                 max_batch: int = 8, decode_chains: int = 1):
+                 max_batch: int = 8, decode_chains: int = 1, options: int = 0):
+        """options: bit set of _lib.OPT_* (mt3_engine_config.options): how the same function is evaluated --
+        OPT_SINGLE_RESIDUAL_STREAM (no bf16 copy / partial sums of the residual rows), OPT_SEPARATE_PROJECTIONS
+        (no folding of projections into neighbouring launches).  0 = the defaults."""
         self.config = config
         self.input_length, self.max_decode_length, self.max_batch = input_length, max_decode_length, max_batch
         if config.dtype not in ("bfloat16", "float32"):
@@ -129,7 +132,7 @@ class Transformer:
                                input_length, max_decode_length, max_batch,
                                _lib.MT3_BF16 if config.dtype == "bfloat16" else _lib.MT3_F32, decode_chains,
                                _lib.MT3_FP8_E4M3 if config.kv_dtype == "fp8_e4m3" else 0,
-                               _lib.MT3_FP8_E4M3 if config.dense_dtype == "fp8_e4m3" else 0)
+                               _lib.MT3_FP8_E4M3 if config.dense_dtype == "fp8_e4m3" else 0, options)
         self._ec = ec
         self._h = None
         self._create()
@@ -150,8 +153,10 @@ class Transformer:
     def load_params(self, params: Dict[str, np.ndarray]):
         """`params`: flat dict in the reference's names/orientation (f32).  Names outside the network's
         parameter tree (optimizer state, other heads of a larger checkpoint) are ignored; kernels stored with
-        split head axes ([in, heads, head_dim] / [heads, head_dim, out]) are flattened to the 2-D DenseGeneral
-        form; a second call re-restores (the engine is rebuilt), as the reference's restore_from_checkpoint allows."""
+        split head axes (exactly [in, heads, head_dim] or [heads, head_dim, out]) are flattened to the 2-D DenseGeneral
+        form, any other shape is an error; names outside the tree are listed in `self.ignored_params`; a second call
+        re-restores (the engine is rebuilt and the encoded batch of the old one is gone), as the reference's
+        restore_from_checkpoint allows."""
         if self._loaded:
             self._create()
         want = param_shapes(self.config)
@@ -159,11 +164,15 @@ class Transformer:
         if missing:
             raise _lib.Mt3Error(_lib.MT3_ERR_MISSING, "weights missing from the checkpoint: %s%s"
                                 % (", ".join(missing[:4]), " ..." if len(missing) > 4 else ""))
+        self.ignored_params = sorted(n for n in params if n not in want)     # reported, not silently dropped
+        H, D = self.config.num_heads, self.config.head_dim
         for name, shape in want.items():
             arr = np.asarray(params[name])
             if arr.shape != shape:
-                if arr.size == int(np.prod(shape)) and arr.ndim == 3:
-                    arr = arr.reshape(shape)            # (in, heads, head_dim) or (heads, head_dim, out)
+                # DenseGeneral kernels with split head axes (layers.py:373-418): ONLY the two layouts flax produces
+                # -- q/k/v [in, heads, head_dim], out [heads, head_dim, out] -- whose C-order flattening is the 2-D form
+                if arr.ndim == 3 and len(shape) == 2 and (arr.shape == (shape[0], H, D) or arr.shape == (H, D, shape[1])):
+                    arr = arr.reshape(shape)
                 else:
                     raise _lib.Mt3Error(_lib.MT3_ERR_INVALID, "weight %s has shape %s, expected %s"
                                         % (name, tuple(arr.shape), shape))
@@ -192,8 +201,7 @@ class Transformer:
         return enc
 
     def decode(self, num_steps: Optional[int] = None, use_graph: bool = True, early_exit: bool = False,
-               return_first_logits: bool = False, skip_self_attn: bool = False,
-               skip_cross_attn: bool = False, chains: int = 0, beam1: bool = False):
+               return_first_logits: bool = False, chains: int = 0, beam1: bool = False):
         """Decode for the batch of the last `encode`: greedy until EOS, or with `beam1` the selection
         rule of t5x beam_search(num_decodes=1, alpha=0.6) that the reference's predict_tokens runs.
         Returns int32 CUDA [B, L] ids (and the step-0 logits [B, V] if asked)."""
@@ -203,15 +211,32 @@ class Transformer:
         logits = torch.empty((B, self.config.vocab_size), device="cuda", dtype=torch.float32) \
             if return_first_logits else None
         flags = (0 if use_graph else _lib.DECODE_NO_GRAPH) | (_lib.DECODE_EARLY_EXIT if early_exit else 0) | \
-            (_lib.DECODE_SKIP_SELF_ATTN if skip_self_attn else 0) | \
-            (_lib.DECODE_SKIP_CROSS_ATTN if skip_cross_attn else 0) | ((chains & 0xF) << 8) | \
-            (_lib.DECODE_BEAM1 if beam1 else 0)                                            # skip_*: profiling only
+            ((chains & 0xF) << 8) | (_lib.DECODE_BEAM1 if beam1 else 0)
         ran = C.c_int32()
         _lib.check(self._lib.mt3_engine_decode(self._h, B, num_steps or L, flags, ids.data_ptr(),
                                                logits.data_ptr() if logits is not None else None, C.byref(ran),
                                                torch.cuda.current_stream().cuda_stream))
         self.steps_run = ran.value
         return (ids, logits) if return_first_logits else ids
+
+    def debug_decode(self, num_steps: Optional[int] = None, skip_self_attn: bool = False,
+                     skip_cross_attn: bool = False, chains: int = 0, use_graph: bool = True):
+        """mt3_debug_engine_decode (include/mt3_hip_debug.h): a decode with kernels left out of every step, for
+        differential timing only -- the ids it returns are meaningless."""
+        import torch
+        B, L = self._batch, self.max_decode_length
+        ids = torch.empty((B, L), device="cuda", dtype=torch.int32)
+        skip = (_lib.DEBUG_SKIP_SELF_ATTN if skip_self_attn else 0) | (_lib.DEBUG_SKIP_CROSS_ATTN if skip_cross_attn else 0)
+        flags = (0 if use_graph else _lib.DECODE_NO_GRAPH) | ((chains & 0xF) << 8)
+        _lib.check(self._lib.mt3_debug_engine_decode(self._h, B, num_steps or L, flags, skip, ids.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream))
+        return ids
+
+    def debug_poison_caches(self, pattern: int = 0xFF, cross: bool = False):
+        """mt3_debug_engine_poison_caches: fill the K/V caches with a byte pattern (0xFF = NaN in every cache format)."""
+        import torch
+        _lib.check(self._lib.mt3_debug_engine_poison_caches(self._h, pattern, 1 if cross else 0,
+                                                            torch.cuda.current_stream().cuda_stream))
 
     def decode_forced(self, forced_ids, num_steps: Optional[int] = None, use_graph: bool = True,
                       return_logits: bool = True, chains: int = 0):

@@ -152,3 +152,69 @@ def test_directory_names_with_dots_resolve_against_the_expected_tree(tmp_path):
     got = checkpoints.load_t5x_checkpoint(str(d), expected=["enc/v1.5/kernel", "enc/plain/kernel"])
     assert set(got) == {"enc/v1.5/kernel", "enc/plain/kernel"}
     assert np.array_equal(got["enc/v1.5/kernel"], a) and np.array_equal(got["enc/plain/kernel"], a + 1)
+
+
+def test_hand_typed_checkpoint_directory(tmp_path):
+    """A checkpoint directory in which nothing was produced by this package or by the msgpack library: the index is
+    typed out byte by byte from the msgpack specification (fixmap 0x80|n, fixstr 0xA0|n, fixarray 0x90|n, positive
+    fixint, bin 8 = 0xC4 len, ext 8 = 0xC7 len type), the array metadata is literal zarr-v2 JSON text
+    (https://zarr.readthedocs.io/en/stable/spec/v2.html: shape / chunks / dtype '<f4' / compressor / fill_value / order /
+    filters / zarr_format), chunks are raw little-endian bytes (one gzip member written by Python's gzip module).
+    Layout after t5x [from memory: PARITY UNPINNED against a real checkpoint, see tests/golden/external/README.md]:
+    {'version', 'optimizer': {'target': tree, 'state': {...}}}; a leaf is an inline flax ndarray (ext type 1 holding
+    msgpack [shape, dtype name, bytes]) or a TensorStore zarr spec pointing at `target.<dotted path>`."""
+    import struct
+    d = tmp_path / "hand"
+    os.makedirs(d)
+
+    def s(txt):                                  # fixstr
+        b = txt.encode()
+        assert len(b) < 32
+        return bytes([0xA0 | len(b)]) + b
+
+    def s8(txt):                                 # str 8
+        b = txt.encode()
+        return bytes([0xD9, len(b)]) + b
+
+    scale = struct.pack("<4f", 1.0, 0.5, -2.0, 3.25)
+    inline = bytes([0x93, 0x91, 0x04]) + s("float32") + bytes([0xC4, len(scale)]) + scale   # [[4], 'float32', bin]
+    ext = bytes([0xC7, len(inline), 0x01]) + inline                                          # ext 8, type 1 = ndarray
+    path = "target.decoder.logits_dense.kernel"
+    spec = (bytes([0x83]) + s("driver") + s("zarr") +
+            s("kvstore") + bytes([0x82]) + s("driver") + s("file") + s("path") + s8(path) +
+            s("metadata") + bytes([0x82]) + s("shape") + bytes([0x92, 0x04, 0x06]) + s("dtype") + s("<f4"))
+    index = (bytes([0x82]) + s("version") + bytes([0x03]) +
+             s("optimizer") + bytes([0x82]) +
+             s("target") + bytes([0x81]) + s("decoder") + bytes([0x82]) +
+             s("decoder_norm") + bytes([0x81]) + s("scale") + ext +
+             s("logits_dense") + bytes([0x81]) + s("kernel") + spec +
+             s("state") + bytes([0x81]) + s("step") + bytes([0x05]))
+    (d / "checkpoint").write_bytes(index)
+    kernel = (np.arange(24, dtype=np.float32).reshape(4, 6) - 7.5) / 4.0
+    os.makedirs(d / path)
+    (d / path / ".zarray").write_text(
+        '{\n  "chunks": [3, 4],\n  "compressor": {"id": "gzip", "level": 6},\n  "dtype": "<f4",\n'
+        '  "fill_value": null,\n  "filters": null,\n  "order": "C",\n  "shape": [4, 6],\n  "zarr_format": 2\n}\n')
+    for (i, j) in ((0, 0), (0, 1), (1, 0), (1, 1)):                 # edge chunks are stored full size (3 x 4)
+        block = np.zeros((3, 4), "<f4")
+        part = kernel[3 * i: 3 * i + 3, 4 * j: 4 * j + 4]
+        block[: part.shape[0], : part.shape[1]] = part
+        (d / path / f"{i}.{j}").write_bytes(gzip.compress(struct.pack("<12f", *block.reshape(-1).tolist())))
+    # the msgpack library reads the hand-typed bytes as the tree they spell
+    idx = CK.read_index(str(d))
+    assert idx["version"] == 3 and idx["optimizer"]["state"]["step"] == 5
+    assert idx["optimizer"]["target"]["decoder"]["logits_dense"]["kernel"]["kvstore"]["path"] == path
+    got = CK.load_t5x_checkpoint(str(d))
+    assert set(got) == {"decoder/decoder_norm/scale", "decoder/logits_dense/kernel"}
+    assert got["decoder/decoder_norm/scale"].tolist() == [1.0, 0.5, -2.0, 3.25]
+    assert np.array_equal(got["decoder/logits_dense/kernel"], kernel)
+    # and what save_t5x_checkpoint writes for the same tree is byte-compatible in the parts the format fixes:
+    # the same key set, the same .zarray fields
+    CK.save_t5x_checkpoint(str(tmp_path / "ours"), got, step=5, inline_below=5)
+    ours = CK.read_index(str(tmp_path / "ours"))
+    assert set(ours) == set(idx) and set(ours["optimizer"]) == set(idx["optimizer"])
+    assert np.array_equal(ours["optimizer"]["target"]["decoder"]["decoder_norm"]["scale"],
+                          idx["optimizer"]["target"]["decoder"]["decoder_norm"]["scale"])
+    meta_ours = json.loads((tmp_path / "ours" / path / ".zarray").read_text())
+    meta_hand = json.loads((d / path / ".zarray").read_text())
+    assert set(meta_ours) == set(meta_hand) and meta_ours["dtype"] == "<f4" and meta_ours["shape"] == [4, 6]

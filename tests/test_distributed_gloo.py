@@ -70,3 +70,101 @@ def test_two_rank_gather_and_decode(n_items):
     res = metrics_utils.event_predictions_to_ns(preds, codec, note_sequences.NoteEncodingWithTiesSpec)
     assert got == (len(res["est_ns"].notes), res["est_invalid_events"], res["est_dropped_events"],
                    res["est_ns"].total_time)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The job bench.py runs at N > 1 (mt3_amd.distributed.ShardedTranscriber: shard -> engine calls -> ONE gather to
+# rank 0 -> per-file host note decoding), driven by a STUB engine on gloo: rank 0's notes must equal a single-rank run
+# of the same corpus, for a ragged corpus (10,001 segments: shards of 5001 + 5000; 40 files, the last of 17 segments),
+# with start times mapped per global segment.  Reference split: NB:270-275 (batch axis only).
+L_STUB = 48
+
+
+def _stub_rows(first, count):
+    """deterministic token rows of global segments [first, first + count): MT3-style (tie token, then shift / pitch /
+    program tokens drawn from a per-segment generator, a -1 tail of random length)"""
+    out = np.empty((count, L_STUB), np.int32)
+    for i in range(count):
+        rng = np.random.default_rng(1_000_003 * (first + i) + 7)
+        row = rng.integers(0, 1388, L_STUB).astype(np.int32)
+        row[0] = 1131
+        row[rng.integers(L_STUB // 2, L_STUB + 1):] = -1
+        out[i] = row
+    return out
+
+
+def _notes_of_file_factory():
+    from mt3_amd import metrics_utils, note_sequences, vocabularies
+    codec = vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1))
+
+    def notes_of_file(rows, first):
+        eos = rows == -1
+        n_tok = np.where(eos.any(1), eos.argmax(1), rows.shape[1])
+        starts = [(first + i) * 2.048 - ((first + i) * 2.048) % 0.01 for i in range(len(rows))]
+        ns, inv, drop = metrics_utils._run(codec, note_sequences.NoteEncodingWithTiesSpec.spec_id,
+                                           [r[:n] for r, n in zip(rows, n_tok)], starts)
+        h = hash(tuple((n.start_time, n.end_time, n.pitch, n.program, n.is_drum) for n in ns.notes))
+        return (first, len(ns.notes), inv, drop, h)
+    return notes_of_file
+
+
+def _job_worker(rank, world, port, n_items, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from mt3_amd import distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def transcribe(first, count):
+        calls.append((first, count))
+        return torch.from_numpy(_stub_rows(first, count))
+    collectives = []
+    job = distributed.ShardedTranscriber(n_items, rank, world, transcribe, _notes_of_file_factory(), call_segments=1250,
+                                         file_segments=256, host_threads=4, on_gather=lambda ph: collectives.append(ph))
+    job.step()
+    job.step()                                             # two passes: the pending queue and the pool are reused
+    res = job.drain()
+    lo, hi = distributed.shard_range(n_items, rank, world)
+    assert calls[: len(calls) // 2] == [(s, min(1250, hi - s)) for s in range(lo, hi, 1250)], calls
+    assert collectives == [0, 1, 0, 1]                     # exactly one collective per pass
+    if rank == 0:
+        q.put(res)
+    else:
+        assert res == []
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_job_matches_a_single_rank_run_on_a_ragged_corpus():
+    from mt3_amd import distributed
+    n_items = 10_001
+    assert distributed.shard_range(n_items, 0, 2) == (0, 5001) and distributed.shard_range(n_items, 1, 2) == (5001, 10001)
+    assert distributed.file_ranges(n_items, 256)[-1] == (9984, 10001) and len(distributed.file_ranges(n_items, 256)) == 40
+    # single rank, no process group: gather is the identity
+    single = distributed.ShardedTranscriber(n_items, 0, 1, lambda f, c: torch.from_numpy(_stub_rows(f, c)),
+                                            _notes_of_file_factory(), call_segments=1250, file_segments=256, host_threads=4)
+    single.step()
+    want = single.drain()
+    assert len(want) == 40 and want[0][0] == 0 and want[-1][0] == 9984 and sum(w[1] for w in want) > 1_000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert got == want
+
+
+def test_gather_needs_no_size_exchange_and_rejects_wrong_shards():
+    """Shard sizes come from shard_range on every rank; without a process group the call is the identity."""
+    from mt3_amd import distributed
+    t = torch.arange(12, dtype=torch.int32).reshape(3, 4)
+    assert distributed.gather_token_rows(t, 3) is t and distributed.gather_token_rows(t, 3, dst=0) is t
+    src = open(os.path.join(ROOT, "mt3_amd", "distributed.py")).read()
+    assert ".item()" not in src and src.count("dist.all_gather(") == 1 and "dist.gather(" in src

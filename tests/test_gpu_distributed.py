@@ -49,7 +49,10 @@ def _worker(rank, world, port, n_items, steps, q):
     local = _decode_rows(audio[lo:hi].contiguous(), steps)
     allrows = distributed.gather_token_rows(local, n_items)               # CUDA branch: all_gather_into_tensor
     assert allrows.is_cuda and allrows.shape == (n_items, 1024)
+    to0 = distributed.gather_token_rows(local, n_items, dst=0)            # what bench.py issues: ONE gather to rank 0
+    assert (to0 is None) == (rank != 0)
     if rank == 0:
+        assert torch.equal(to0, allrows)
         q.put(allrows.cpu().numpy())
     dist.barrier()
     dist.destroy_process_group()

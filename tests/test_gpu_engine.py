@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
-from mt3_amd import network  # noqa: E402
+from mt3_amd import _lib, network  # noqa: E402
 from oracle import frontend as OF  # noqa: E402
 from oracle import network as ON  # noqa: E402
 
@@ -56,9 +56,9 @@ def setup():
     return dict(params=params, x=x, enc_ref=enc_ref.numpy(), ids_ref=ids_ref, logits_ref=logits_ref.numpy())
 
 
-def _engine(dtype, params, B):
+def _engine(dtype, params, B, options=0):
     cfg = network.T5Config(dtype=dtype)
-    eng = network.Transformer(cfg, input_length=T, max_decode_length=L, max_batch=B)
+    eng = network.Transformer(cfg, input_length=T, max_decode_length=L, max_batch=B, options=options)
     eng.load_params(params)
     return eng
 
@@ -201,21 +201,19 @@ def test_decode_chains_are_bit_identical(setup):
     assert np.array_equal(a, b)
 
 
-def test_split_residual_stream_matches_the_single_f32_stream(setup, monkeypatch):
+def test_split_residual_stream_matches_the_single_f32_stream(setup):
     """bf16 decode keeps the residual rows as f32 + a bf16 copy + exact per-16-column sums of squares (DESIGN.md
-    section 2); MT3_NO_Y_SPLIT=1 (read when an engine is finalized) keeps the single f32 stream with in-kernel
+    section 2); options = MT3_OPT_SINGLE_RESIDUAL_STREAM keeps the single f32 stream with in-kernel
     statistics.  Same MFMA operands, row scales equal up to the summation order: step-0 logits must agree to
     f32 round-off (a wrong partial sum would show as a percent-level shift that the bf16 tolerances could hide),
     and the greedy tokens must be identical."""
     x = torch.from_numpy(np.repeat(setup["x"], 12, axis=0)[:34]).cuda()          # ragged: 34 rows = 32 + 2
     out = {}
-    monkeypatch.setenv("MT3_NO_QFOLD", "1")          # (the folded q-projection rounds differently: its own test below)
-    for name, env in (("split", None), ("single", "1")):
-        if env is None:
-            monkeypatch.delenv("MT3_NO_Y_SPLIT", raising=False)
-        else:
-            monkeypatch.setenv("MT3_NO_Y_SPLIT", env)
-        eng = _engine("bfloat16", setup["params"], 34)
+    # (the folded projections round differently: their own test below)
+    for name, opt in (("split", _lib.OPT_SEPARATE_PROJECTIONS),
+                      ("single", _lib.OPT_SEPARATE_PROJECTIONS | _lib.OPT_SINGLE_RESIDUAL_STREAM)):
+        eng = _engine("bfloat16", setup["params"], 34, options=opt)
+        assert eng.status(_lib.STATUS_RESIDUAL_SPLIT) == (1 if name == "split" else 0)
         eng.encode(x)
         ids, logits0 = eng.decode(num_steps=40, return_first_logits=True)
         out[name] = (ids.cpu().numpy(), logits0.cpu().numpy())
@@ -233,20 +231,17 @@ def test_split_residual_stream_matches_the_single_f32_stream(setup, monkeypatch)
     assert np.array_equal(out["split"][0][clean], out["single"][0][clean])
 
 
-def test_folded_cross_query_projection_matches_the_separate_launch(setup, monkeypatch):
+def test_folded_cross_query_projection_matches_the_separate_launch(setup):
     """bf16 decode folds the cross-attention q-projection into the QKV and self out-projection launches
     (y_new.Wq' = y_old.Wq' + attn.(Wo.Wq'), 1/rms applied by the cross-attention kernel from the partial sums): the
-    same function of the same weights, rounded in different places.  Against the separate launch (MT3_NO_QFOLD=1):
+    same function of the same weights, rounded in different places.  Against the separate launch
+    (options = MT3_OPT_SEPARATE_PROJECTIONS):
     step-0 logits within bf16 noise on every row; against the f32 oracle both stay inside the bf16 bound."""
     x = torch.from_numpy(np.repeat(setup["x"], 12, axis=0)[:34]).cuda()
     out = {}
-    for name, env in (("fold", None), ("separate", "1")):
-        if env is None:
-            monkeypatch.delenv("MT3_NO_QFOLD", raising=False)
-        else:
-            monkeypatch.setenv("MT3_NO_QFOLD", env)
-        eng = _engine("bfloat16", setup["params"], 34)
-        assert eng.status(4) == (1 if env is None else 0)
+    for name, opt in (("fold", 0), ("separate", _lib.OPT_SEPARATE_PROJECTIONS)):
+        eng = _engine("bfloat16", setup["params"], 34, options=opt)
+        assert eng.status(_lib.STATUS_Q_FOLD) == (1 if opt == 0 else 0)
         eng.encode(x)
         ids, logits0 = eng.decode(num_steps=24, return_first_logits=True)
         out[name] = (ids.cpu().numpy(), logits0.cpu().numpy())

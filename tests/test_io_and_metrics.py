@@ -52,23 +52,99 @@ def test_wav_ingest_and_resample():
 
 
 def test_note_matching_vs_brute_force():
+    """The maximum matching against an exhaustive search over permutations, the pairing rule written out
+    independently (rounded distances, non-strict comparisons, cents on the values passed)."""
     rng = np.random.default_rng(1)
-    for _ in range(20):
+    for _ in range(30):
         n = int(rng.integers(1, 6))
         ref_iv = np.sort(rng.uniform(0, 1, (n, 2)), 1)
         est_iv = ref_iv + rng.normal(0, 0.04, (n, 2))
-        pitch = rng.integers(60, 62, n)
+        pitch = 440.0 * 2.0 ** (rng.integers(-3, 3, n) / 12.0)              # Hz: neighbours are 100 cents apart
         est_pitch = pitch.copy()
         got = metrics.match_notes(ref_iv, pitch, est_iv, est_pitch)
         tol = np.maximum(0.05, 0.2 * (ref_iv[:, 1] - ref_iv[:, 0]))
-        ok = (np.abs(ref_iv[:, None, 0] - est_iv[None, :, 0]) <= 0.05) & (pitch[:, None] == est_pitch[None]) & \
-             (np.abs(ref_iv[:, None, 1] - est_iv[None, :, 1]) <= tol[:, None])
+        ok = (np.round(np.abs(ref_iv[:, None, 0] - est_iv[None, :, 0]), 6) <= 0.05) & \
+             (np.abs(1200 * np.log2(pitch[:, None] / est_pitch[None])) <= 50.0) & \
+             (np.round(np.abs(ref_iv[:, None, 1] - est_iv[None, :, 1]), 6) <= tol[:, None])
         best = max(sum(ok[i, p[i]] for i in range(n)) for p in itertools.permutations(range(n)))
         assert got == best
-    a = NoteSequence(notes=[Note(0.0, 1.0, 60, 100), Note(1.0, 2.0, 62, 100), Note(0.0, 0.5, 36, 100, 0, True, 9)])
-    b = NoteSequence(notes=[Note(0.03, 1.3, 60, 100), Note(1.2, 2.0, 62, 100)])
-    s = metrics.transcription_scores(a, b)
-    assert s["Onset F1"] == 0.5 and s["Onset + offset F1"] == 0.0 and s["Onset recall"] == 0.5
+    a = NoteSequence(notes=[Note(0.0, 1.0, 60, 100), Note(1.0, 2.0, 64, 100), Note(0.0, 0.5, 36, 100, 0, True, 9)])
+    b = NoteSequence(notes=[Note(0.03, 1.3, 60, 100), Note(1.2, 2.0, 64, 100)])
+    for unit in ("note_number", "hz"):
+        s = metrics.transcription_scores(a, b, pitch_unit=unit)
+        assert s["Onset F1"] == 0.5 and s["Onset + offset F1"] == 0.0 and s["Onset recall"] == 0.5
+
+
+def _prf(ref, est, **kw):
+    ri = np.array([[r[0], r[1]] for r in ref], np.float64).reshape(-1, 2)
+    ei = np.array([[e[0], e[1]] for e in est], np.float64).reshape(-1, 2)
+    return metrics.precision_recall_f1_overlap(ri, np.array([r[2] for r in ref], np.float64), ei,
+                                               np.array([e[2] for e in est], np.float64), **kw)
+
+
+def test_mir_eval_boundary_comparisons():
+    """mir_eval.transcription.match_notes' exact boundary behaviour (called by mt3/metrics.py:267-290 with the
+    defaults onset_tolerance 0.05, offset_ratio 0.2, offset_min_tolerance 0.05, strict False), from its documented
+    algorithm: distances are rounded to 6 decimals and compared with <= (strict: <)."""
+    hz = 440.0
+    # onset exactly 50 ms late: in floats 1.05 - 1.0 = 0.050000000000000044 > 0.05, and it still matches (rounding)
+    assert 1.05 - 1.0 > 0.05
+    assert _prf([(1.0, 2.0, hz)], [(1.05, 2.0, hz)], offset_ratio=None) == (1.0, 1.0, 1.0)
+    assert _prf([(1.0, 2.0, hz)], [(1.05, 2.0, hz)], offset_ratio=None, strict=True) == (0.0, 0.0, 0.0)
+    assert _prf([(1.0, 2.0, hz)], [(1.0500004, 2.0, hz)], offset_ratio=None)[2] == 1.0        # rounds to 0.05
+    assert _prf([(1.0, 2.0, hz)], [(1.050001, 2.0, hz)], offset_ratio=None)[2] == 0.0         # 0.050001 > 0.05
+    assert _prf([(1.0, 2.0, hz)], [(0.95, 2.0, hz)], offset_ratio=None)[2] == 1.0             # early by exactly 50 ms
+    # offset: tolerance = max(20 % of the REFERENCE duration, 50 ms); exactly at the tolerance matches
+    assert _prf([(0.0, 2.0, hz)], [(0.0, 2.4, hz)])[2] == 1.0                                 # 0.4 = 20 % of 2.0
+    assert _prf([(0.0, 2.0, hz)], [(0.0, 2.400001, hz)])[2] == 0.0
+    assert _prf([(0.0, 2.0, hz)], [(0.0, 1.6, hz)])[2] == 1.0
+    assert _prf([(0.0, 2.0, hz)], [(0.0, 2.4, hz)], strict=True)[2] == 0.0
+    assert _prf([(0.0, 0.1, hz)], [(0.0, 0.15, hz)])[2] == 1.0                                # short note: the 50 ms floor
+    assert _prf([(0.0, 0.1, hz)], [(0.0, 0.151, hz)])[2] == 0.0
+    assert _prf([(0.0, 2.0, hz)], [(0.0, 2.3, hz)], offset_ratio=0.1)[2] == 0.0               # the ratio is the reference's
+    # the estimated note's own duration does not enter: a long estimate of a short reference fails
+    assert _prf([(0.0, 0.2, hz)], [(0.0, 1.0, hz)])[2] == 0.0 and _prf([(0.0, 0.2, hz)], [(0.0, 1.0, hz)], offset_ratio=None)[2] == 1.0
+    # pitch: 50 cents, non-strict, on the values passed
+    assert _prf([(0.0, 1.0, hz)], [(0.0, 1.0, hz * 2 ** (50 / 1200))], offset_ratio=None)[2] == 1.0
+    assert _prf([(0.0, 1.0, hz)], [(0.0, 1.0, hz * 2 ** (51 / 1200))], offset_ratio=None)[2] == 0.0
+    # one estimate cannot serve two references (maximum matching), and empty sides score zero
+    p, r, f = _prf([(0.0, 1.0, hz), (0.01, 1.0, hz)], [(0.0, 1.0, hz)], offset_ratio=None)
+    assert (p, r) == (1.0, 0.5) and abs(f - 2 / 3) < 1e-12
+    assert _prf([], [(0.0, 1.0, hz)]) == (0.0, 0.0, 0.0) and _prf([(0.0, 1.0, hz)], []) == (0.0, 0.0, 0.0)
+    assert metrics.f_measure(0.0, 0.0) == 0.0 and abs(metrics.f_measure(0.5, 1.0, beta=2.0) - 5 * 0.5 / (4 * 0.5 + 1.0)) < 1e-12
+
+
+def test_the_reference_passes_note_numbers_to_the_cents_rule():
+    """mt3/metrics.py:255-290 hands `sequence_to_valued_intervals`' note NUMBERS to mir_eval unconverted: the 50-cent
+    rule then lets neighbouring numbers >= 35 through (1200 log2(61/60) = 28.6 cents) -- reproduced by
+    pitch_unit="note_number", while "hz" demands the same key.  Zero-length notes are dropped on both sides, drums
+    are not part of the non-drum scores."""
+    ref = NoteSequence(notes=[Note(0.0, 1.0, 60, 100), Note(2.0, 2.0, 70, 100), Note(3.0, 3.5, 34, 100),
+                              Note(0.0, 0.5, 36, 100, 0, True, 9)])
+    est = NoteSequence(notes=[Note(0.0, 1.0, 61, 100), Note(3.0, 3.5, 35, 100)])
+    s = metrics.transcription_scores(ref, est, pitch_unit="note_number")
+    assert s["Onset recall"] == 0.5 and s["Onset precision"] == 0.5          # 60~61 pass, 34~35 (50.2 cents) do not
+    assert metrics.transcription_scores(ref, est, pitch_unit="hz")["Onset F1"] == 0.0
+    iv, pitches, vel = metrics.sequence_to_valued_intervals(ref, drums=False)
+    assert list(pitches) == [60.0, 34.0] and iv.shape == (2, 2)
+
+
+def test_token_stream_divergence_report():
+    from mt3_amd import vocabularies
+    codec = vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1))
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 1388, size=(6, 64)).astype(np.int32)
+    b = a.copy()
+    b[1, 10:] = rng.integers(0, 1388, size=54)
+    b[1, 10] = (a[1, 10] + 1) % 1388
+    b[4, 40] = (a[4, 40] + 1) % 1388
+    d = metrics.token_stream_divergence(a, b, codec)
+    assert d["rows"] == 6 and abs(d["identical_rows_frac"] - 4 / 6) < 1e-12
+    assert d["median_first_divergence_step"] == 25.0 and d["first_divergence_quartiles"][0] == 17.5
+    assert 0.0 <= d["onset_f1_hz"] <= d["onset_f1_note_number"] <= 1.0
+    same = metrics.token_stream_divergence(a, a, codec)
+    assert same["identical_rows_frac"] == 1.0 and same["median_first_divergence_step"] is None
+    assert same["onset_offset_f1_hz"] in (0.0, 1.0) and same["ref_notes"] == same["est_notes"]
 
 
 def test_midi_bytes_of_a_one_note_sequence_follow_the_smf_specification():

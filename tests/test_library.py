@@ -13,14 +13,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_every_declared_symbol_is_exported_and_typed():
-    header = open(os.path.join(ROOT, "include", "mt3_hip.h")).read()
+    inc = os.path.join(ROOT, "include")
+    header = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     declared = set(re.findall(r"\b(mt3_[a-z0-9_]+)\s*\(", header))
     declared -= {"mt3_status"}
+    # the product header carries no profiling / fault-injection switch
+    product = open(os.path.join(inc, "mt3_hip.h")).read()
+    assert "SKIP" not in product and "mt3_debug" not in product
     lib = _lib.load()
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in mt3_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.mt3_abi_version() == 1
+    assert lib.mt3_abi_version() == 2
 
 
 def test_argument_errors_are_reported_not_swallowed():
@@ -31,8 +35,19 @@ def test_argument_errors_are_reported_not_swallowed():
     assert b"hop_width" in lib.mt3_last_error()
     cfg = _lib.EngineConfig(1536, 512, 6, 32, 1024, 8, 8, 512, 256, 1024, 8, _lib.MT3_BF16, 1)   # head_dim 32
     assert lib.mt3_engine_create(C.byref(cfg), C.byref(h)) == _lib.MT3_ERR_INVALID
+    cfg = _lib.EngineConfig(1536, 512, 6, 64, 1024, 8, 8, 512, 256, 1024, 8, _lib.MT3_BF16, 1, 0, 0, 1 << 7)      # unknown option
+    assert lib.mt3_engine_create(C.byref(cfg), C.byref(h)) == _lib.MT3_ERR_INVALID
+    assert lib.mt3_debug_set_knob(99, 1) == _lib.MT3_ERR_INVALID
+    assert lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_DEC_ATTN_WAVES, 7) == _lib.MT3_ERR_INVALID
     with pytest.raises(_lib.Mt3Error):
         _lib.check(lib.mt3_ids_to_tokens(None, 1, 1, 1, None, None))
+
+
+def test_the_product_reads_no_environment_variable():
+    """Tuning switches are config fields (mt3_engine_config.options) or debug knobs (mt3_hip_debug.h), never getenv."""
+    csrc = os.path.join(ROOT, "mt3_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
 
 
 @pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="checks the no-GPU failure mode")
@@ -78,3 +93,30 @@ def test_bench_refuses_to_fake_ranks_it_cannot_place():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-cpu-baseline"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "GPU" in r.stderr and "{" not in r.stdout
+
+
+def test_load_params_accepts_only_the_two_flax_head_layouts():
+    """A 3-D kernel is flattened only if it is [in, heads, head_dim] (q/k/v) or [heads, head_dim, out] (out); the
+    same number of elements in another axis order is an error, not a silent scramble; names outside
+    the parameter tree are reported."""
+    import numpy as np
+    from mt3_amd import network
+    cfg = network.T5Config(num_encoder_layers=1, num_decoder_layers=1)
+    params = network.init_random_params(cfg, seed=0)
+    q = "encoder/layers_0/attention/query/kernel"
+    bad = dict(params)
+    bad[q] = params[q].reshape(512, 6, 64).transpose(1, 0, 2).copy()          # [heads, in, head_dim]
+    eng = network.Transformer(cfg, max_batch=1)
+    with pytest.raises(_lib.Mt3Error) as ei:
+        eng.load_params(bad)
+    assert ei.value.code == _lib.MT3_ERR_INVALID and "query/kernel" in str(ei.value)
+    ok = dict(params)
+    ok[q] = params[q].reshape(512, 6, 64)
+    ok["encoder/layers_0/attention/out/kernel"] = params["encoder/layers_0/attention/out/kernel"].reshape(6, 64, 512)
+    ok["optimizer/state/step"] = np.zeros(1)
+    eng = network.Transformer(cfg, max_batch=1)
+    try:
+        eng.load_params(ok)                       # shapes accepted; without a GPU the upload then fails loudly
+    except _lib.Mt3Error as e:
+        assert e.code == _lib.MT3_ERR_HIP
+    assert eng.ignored_params == ["optimizer/state/step"]

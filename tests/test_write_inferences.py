@@ -161,3 +161,43 @@ def test_decode_tf_host_path_matches_the_reference_literals():
     assert vocab.decode_tf(ids).tolist() == [[0, 1, 2, -1, -1, -1], [9, -2, -2, -2, -1, -1]]
     assert vocab.decode_tf(np.zeros((2, 0), np.int32)).shape == (2, 0)
     assert vocab.decode([3, 4, 1, 5]) == [0, 1, -1]
+
+
+def _proto_note_sequence(ident: str, filename: str = "a.mid") -> bytes:
+    """a serialized note_seq.NoteSequence written by hand from the protobuf wire format: field 2 (filename) FIRST,
+    a varint field (ticks_per_quarter = 4: 220) and a fixed64 one in between, then field 1 (id) -- order is free on
+    the wire, the reader must skip what it does not want"""
+    def ld(field, payload):
+        assert len(payload) < 128
+        return bytes([(field << 3) | 2, len(payload)]) + payload
+    return (ld(2, filename.encode()) + bytes([(4 << 3) | 0, 0xDC, 0x01]) +
+            bytes([(6 << 3) | 1]) + b"\0" * 8 + ld(1, ident.encode()))
+
+
+def test_id_comes_from_the_reference_note_sequence(tmp_path):
+    """mt3/inference.py:83-86,104-108,133: when the task dataset carries the ground-truth `sequence` (first segment
+    of each track; later ones are empty), the line's "id" is that NoteSequence's `id`, not the `unique_id`; lines are
+    ordered by `unique_id`; a track without any sequence trips the reference's assertion (:114)."""
+    cfg = V.VocabularyConfig(num_velocity_bins=1)
+    vocab = V.vocabulary_from_codec(V.build_codec(cfg))
+    rng = np.random.default_rng(11)
+    ds, infs = [], []
+    for uid, ref_id, case in (("u2", "/id/slakh/Track00017", _cases("ties", 1, 2)[0]),
+                              ("u1", "/id/maestro/zzz", _cases("ties", 1, 2)[1])):
+        e, r = _track(case, uid, rng, shuffle=False)
+        for k, ex in enumerate(e):
+            ex["sequence"] = np.array([_proto_note_sequence(ref_id) if k == 0 else b""], dtype=object)
+        ds += e
+        infs += r
+    assert inference.note_sequence_id(_proto_note_sequence("abc")) == "abc"
+    assert inference.note_sequence_id(b"") == "" and inference.note_sequence_id("plain") == "plain"
+    p = str(tmp_path / "ids.jsonl")
+    inference.write_inferences_to_file(p, infs, ds, mode="predict", vocabulary=vocab, vocab_config=cfg,
+                                       onsets_only=False, use_ties=True)
+    assert [json.loads(l)["id"] for l in open(p)] == ["/id/maestro/zzz", "/id/slakh/Track00017"]      # sorted by unique_id
+    for ex in ds:
+        if ex["unique_id"][0] == b"u1":
+            ex["sequence"] = np.array([b""], dtype=object)
+    with pytest.raises(AssertionError):
+        inference.write_inferences_to_file(p, infs, ds, mode="predict", vocabulary=vocab, vocab_config=cfg,
+                                           onsets_only=False, use_ties=True)

@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mt3_amd import network, spectrograms, synthetic  # noqa: E402
+from mt3_amd import _lib, network, spectrograms, synthetic  # noqa: E402
 
 B = int(os.environ.get("PROBE_B", "256"))
 import dataclasses  # noqa: E402
@@ -36,12 +36,8 @@ if os.environ.get("PROBE_SPLIT"):
     # split vs single decode residual stream on two engine INSTANCES (tests/test_gpu_engine.py::test_split_residual...)
     Bs = 34
     res = {}
-    for name, env in (("split", None), ("single", "1")):
-        if env is None:
-            os.environ.pop("MT3_NO_Y_SPLIT", None)
-        else:
-            os.environ["MT3_NO_Y_SPLIT"] = env
-        e2 = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=Bs)
+    for name, opt in (("split", 0), ("single", _lib.OPT_SINGLE_RESIDUAL_STREAM)):
+        e2 = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=Bs, options=opt)
         e2.load_params(params)
         enc = e2.encode(lm[:Bs], return_encoded=True).clone()
         ids, lg = e2.decode(num_steps=4, return_first_logits=True)

@@ -3,7 +3,7 @@
 hash differs from the sources it runs):
 HBM traffic per decode-attention launch = FETCH_SIZE x 2 (gfx950 tallies 128-byte requests as 64: calibrated on
 the 1 GiB copy of the same run) + WRITE_SIZE, against the algorithmic bytes of the launch.
-Usage: python tools/pmc_summary.py gpurun_out/pmc profiles [round-prefix, default r2]"""
+Usage: python tools/pmc_summary.py gpurun_out/pmc profiles [round-prefix, default r3]"""
 import csv
 import glob
 import json
@@ -12,10 +12,10 @@ import shutil
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-RND = sys.argv[3] if len(sys.argv) > 3 else "r2"
+RND = sys.argv[3] if len(sys.argv) > 3 else "r3"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import kernel_source_hash  # noqa: E402
-B, H, D, ES, CAP = 256, 6, 64, 2, 1024
+from bench import FRONTEND_SOURCES, kernel_source_hash  # noqa: E402
+B, H, D, CAP = 256, 6, 64, 1024
 
 
 def rows(counter):
@@ -42,37 +42,48 @@ is_copy = lambda n, g: "copyBuffer" in n and g >= 131072
 cal_f, cal_w = pick(fetch, is_copy)[-1], pick(write, is_copy)[-1]
 factor = (1 << 30) / (cal_f * 1024.0)
 
-is_attn = lambda n, g: "dec_attn_kernel" in n
-af, aw = pick(fetch, is_attn), pick(write, is_attn)
-# launch order of pmc_attn.py: (1024, 513, 129) x 2 rounds x 4 layers of self/append, then 8 cross launches
-assert len(af) == 32 and len(aw) == 32, (len(af), len(aw))
 summary = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python tools/pmc_attn.py "
               "(tools/gpu_pmc.sh, reduced by tools/pmc_summary.py), MI355X, " + RND,
     "kernel_source_hash": kernel_source_hash(),
+    "frontend_source_hash": kernel_source_hash(FRONTEND_SOURCES),
     "units": "counter values are KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B: "
              "MI355X_MICROARCH.md, HBM section), WRITE_SIZE is used as is",
     "calibration_1GiB_copy": {"FETCH_SIZE_KiB": cal_f, "WRITE_SIZE_KiB": cal_w, "read_bytes_true": 1 << 30,
                               "fetch_correction_factor": factor},
-    "shape": {"B": B, "H": H, "head_dim": D, "dtype": "bf16", "cap": CAP},
-    "dec_attn_self_append": {},
+    "shape": {"B": B, "H": H, "head_dim": D, "cap": CAP},
 }
 
 
-def entry(f_kib, w_kib, n_keys, append):
-    # algorithmic: K and V rows of every cached key, the query, the output (+ the new K/V row read and written)
-    alg = B * H * (2 * (n_keys - (1 if append else 0)) * D * ES + D * ES + D * ES + (4 * D * ES if append else 0))
+def entry(f_kib, w_kib, n_keys, append, kind):
+    # algorithmic: K and V rows of every cached key, the query, the output (+ the new K/V row read and written);
+    # fp8: 64 e4m3 bytes per K / V row + the 8-byte scale pair of the position; q / out / new rows bf16
+    es = 4 if kind == "f32" else 2
+    n_cached = n_keys - (1 if append else 0)
+    if kind == "fp8":
+        alg = B * H * (n_cached * (2 * D + 8) + 2 * D * es + (2 * D * es + 2 * D + 8 if append else 0))
+    else:
+        alg = B * H * (2 * n_cached * D * es + D * es + D * es + (4 * D * es if append else 0))
     traffic = f_kib * 1024 * 2 + w_kib * 1024
     return {"FETCH_SIZE_KiB": f_kib, "WRITE_SIZE_KiB": w_kib, "traffic_bytes": traffic, "algorithmic_bytes": alg,
             "traffic_over_algorithmic": traffic / alg}
 
 
-for i, n_keys in enumerate((1024, 513, 129)):
-    sel = list(range(12 + i * 4, 12 + i * 4 + 4))            # second round: caches hold nothing of these layers
-    summary["dec_attn_self_append"]["n_keys_%d" % n_keys] = entry(
-        sum(af[j] for j in sel) / 4, sum(aw[j] for j in sel) / 4, n_keys, True)
-summary["dec_attn_cross_256_keys"] = entry(sum(af[24:]) / 8, sum(aw[24:]) / 8, 256, False)
-# log-mel frontend: 3 launches of 256 full segments (4096 workgroups of 256 threads)
+# launch order of pmc_attn.py per cache format: (1024, 513, 129) x 2 rounds x 4 layers of self/append, then 8 cross
+KIND = {"bf16": lambda n, g: "dec_attn_kernel<__bf16" in n, "f32": lambda n, g: "dec_attn_kernel<float" in n,
+        "fp8": lambda n, g: "dec_attn_fp8_kernel" in n}
+for kind, pred in KIND.items():
+    af, aw = pick(fetch, pred), pick(write, pred)
+    if len(af) != 32 or len(aw) != 32:
+        print("skipping %s: %d / %d dispatches (expected 32)" % (kind, len(af), len(aw)))
+        continue
+    sec = {}
+    for i, n_keys in enumerate((1024, 513, 129)):
+        sel = list(range(12 + i * 4, 12 + i * 4 + 4))        # second round: caches hold nothing of these layers
+        sec["n_keys_%d" % n_keys] = entry(sum(af[j] for j in sel) / 4, sum(aw[j] for j in sel) / 4, n_keys, True, kind)
+    summary["dec_attn_self_append_" + kind] = sec
+    summary["dec_attn_cross_256_keys_" + kind] = entry(sum(af[24:]) / 8, sum(aw[24:]) / 8, 256, False, kind)
+# log-mel frontend: 3 launches of 256 full segments
 is_fe = lambda n, g: "logmel_kernel" in n
 ff, fw = pick(fetch, is_fe), pick(write, is_fe)
 if ff and fw:

@@ -15,10 +15,10 @@ audio = synthetic.synth_audio(B, seed=1)
 
 def ms(**kw):
     with torch.cuda.stream(stream):
-        eng.decode(num_steps=2, **kw)
+        eng.debug_decode(num_steps=2, **kw)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream)
-        eng.decode(num_steps=1024, **kw)
+        eng.debug_decode(num_steps=1024, **kw)
         b.record(stream)
     b.synchronize()
     return a.elapsed_time(b)
