@@ -120,9 +120,11 @@ typedef struct mt3_engine_config {   /* network.T5Config (network.py:25-41), mod
 /* mt3_engine_config.options: numerics-relevant choices of HOW the same function is evaluated (all variants stay inside
  * the tolerances of DESIGN.md section 4; the tests compare them with each other) */
 enum {
-  /* keep the residual stream as ONE f32 stream with in-kernel RMSNorm statistics (the f32 engine always does; the
-   * bf16 engine otherwise carries f32 rows + bf16 copy + per-16-column sums of squares) */
+  /* DECODER: keep the residual stream as ONE f32 stream with in-kernel RMSNorm statistics (the f32 engine always
+   * does; the bf16 engine otherwise carries f32 rows + bf16 copy + per-16-column sums of squares) */
   MT3_OPT_SINGLE_RESIDUAL_STREAM = 1,
+  /* the same choice for the ENCODER's residual rows (the split form is what feeds the LDS-DMA staged GEMM tile) */
+  MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM = 4,
   /* decoder: the projections that consume a freshly updated residual row (cross-attention query; next layer's
    * q/k/v) get a launch of their own instead of riding as extra output columns in the neighbouring launches
    * (linearity of the residual update) */

@@ -436,10 +436,15 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   if constexpr (QF32) {
     // the query as unnormalised f32 + the partial sums of squares of its residual row: 1/rms here
     const float* qp = a.q_f32 + static_cast<size_t>(b) * a.q_stride + h * D + sub * KPL;
-    const float4 q0 = *reinterpret_cast<const float4*>(qp), q1 = *reinterpret_cast<const float4*>(qp + 4);
+    const float4 q0 = *reinterpret_cast<const float4*>(qp);
     const float rs = row_rs_from_partials(a.q_ss + static_cast<size_t>(b) * a.q_ss_n, a.q_ss_n, lane);
-    const float f[8] = {q0.x * rs, q0.y * rs, q0.z * rs, q0.w * rs, q1.x * rs, q1.y * rs, q1.z * rs, q1.w * rs};
-    qc = pack_bf16x8(f);
+    if constexpr (KPL == 8) {
+      const float4 q1 = *reinterpret_cast<const float4*>(qp + 4);
+      const float f[8] = {q0.x * rs, q0.y * rs, q0.z * rs, q0.w * rs, q1.x * rs, q1.y * rs, q1.z * rs, q1.w * rs};
+      qc = pack_bf16x8(f);
+    } else {
+      qc = pack_f32x4(q0.x * rs, q0.y * rs, q0.z * rs, q0.w * rs);
+    }
   } else {
     qc = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.q) + static_cast<size_t>(b) * a.q_stride + h * D +
                                          sub * KPL);
@@ -841,8 +846,9 @@ int launch_kv_quantize_fp8(const void* src_bf16, void* dst_fp8, void* scales, in
 int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
   if ((!a.q && !a.q_f32) || !a.kcache || !a.vcache || !a.out || a.B <= 0 || a.H <= 0 || a.cap <= 0)
     return mt3::fail(MT3_ERR_INVALID, "decode_attention: bad arguments");
-  if (a.q_f32 && (dtype != MT3_BF16 || a.new_k || !a.q_ss || a.q_ss_n <= 0 || a.q_ss_n > 64 || (a.q_ss_n & 3)))
-    return mt3::fail(MT3_ERR_INVALID, "decode_attention: the f32 query form is the bf16 cross-attention's");
+  if (a.q_f32 && (a.new_k || !a.q_ss || a.q_ss_n <= 0 || a.q_ss_n > 64 || (a.q_ss_n & 3)))
+    return mt3::fail(MT3_ERR_INVALID, "decode_attention: the unnormalised f32 query form is the cross-attention's "
+                                      "(no append), with the row's partial sums of squares");
   if (!a.step && (a.n_keys <= 0 || a.n_keys > a.cap)) return mt3::fail(MT3_ERR_INVALID, "decode_attention: n_keys");
   const bool append = a.new_k != nullptr;
   if (append && !a.new_v) return mt3::fail(MT3_ERR_INVALID, "decode_attention: new_k without new_v");
@@ -884,6 +890,10 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
   } else if (dtype == MT3_BF16) {
     if (append) MT3_LAUNCH_DEC(__bf16, true);
     else MT3_LAUNCH_DEC(__bf16, false);
+  } else if (dtype == MT3_F32 && a.q_f32) {
+    if (nw == 2) hipLaunchKernelGGL((dec_attn_kernel<float, false, 2, true>), grid, block, 0, s, a);
+    else if (nw == 3) hipLaunchKernelGGL((dec_attn_kernel<float, false, 3, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((dec_attn_kernel<float, false, 4, true>), grid, block, 0, s, a);
   } else if (dtype == MT3_F32) {
     if (append) MT3_LAUNCH_DEC(float, true);
     else MT3_LAUNCH_DEC(float, false);

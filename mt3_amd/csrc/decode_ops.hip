@@ -64,14 +64,17 @@ int launch_rmsnorm(int dtype, const float* x, const float* scale, void* out_ct, 
   return MT3_OK;
 }
 
-// one float4 of a decoder-input row: the f32 value, and for the bf16 decode path its compute-type copy and the
-// exact sum of squares of its 16-column group (4 consecutive lanes = one quad own one group)
+// one float4 of a decoder-input row: the f32 value, for the split residual form the exact sum of squares of its
+// 16-column group (4 consecutive lanes = one quad own one group), and for the bf16 path also its compute-type copy
+// (y_ct == nullptr with y_ss != nullptr: the f32 engine, whose compute-type rows ARE the f32 rows)
 __device__ __forceinline__ void put_row_piece(float4 v, float* y, void* y_ct, float* y_ss, size_t row, int dim, int i) {
   *reinterpret_cast<float4*>(y + row * dim + i) = v;
-  if (y_ct) {
+  if (y_ss) {
     float t = __builtin_fmaf(v.w, v.w, __builtin_fmaf(v.z, v.z, __builtin_fmaf(v.y, v.y, v.x * v.x)));
     t = quad_sum(t);
     if ((threadIdx.x & 3) == 0) y_ss[row * (dim >> 4) + (i >> 4)] = t;
+  }
+  if (y_ct) {
     uint2 pk;
     pk.x = pack_bf16x2(v.x, v.y);
     pk.y = pack_bf16x2(v.z, v.w);
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(128) void embed_kernel(const float* __restrict__ ta
 
 int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, void* y_ct,
                  float* y_ss, int B, int dim, hipStream_t s) {
-  if (y_ct && (!y_ss || dim % 16)) return mt3::fail(MT3_ERR_INVALID, "embed: y_ct needs y_ss and dim % 16 == 0");
+  if ((y_ct || y_ss) && (!y_ss || dim % 16)) return mt3::fail(MT3_ERR_INVALID, "embed: the split form needs y_ss and dim % 16 == 0");
   hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(128), 0, s, table, pos, tok, step, y, y_ct, y_ss, dim);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;

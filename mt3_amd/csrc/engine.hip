@@ -374,7 +374,8 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   // residual rows as the norm-fused GEMMs see them: f32 with in-kernel statistics, or (bf16 path) the
   // compute-type copy with the producer's partial sums
   const bool split = e->y_split;
-  char* y_ct = split ? static_cast<char*>(e->y_ct) + static_cast<size_t>(row0) * emb * es : nullptr;
+  char* y_ct = split ? static_cast<char*>(e->y_ct) + static_cast<size_t>(row0) * emb * es : nullptr;   // f32: == y
+  char* y_copy = split && dt == MT3_BF16 ? y_ct : nullptr;       // where producers of a residual row leave its bf16 copy
   float* y_ss = split ? e->y_ss + static_cast<size_t>(row0) * (emb / 16) : nullptr;
   auto normed = [&](const void* Wt, void* out, int N, int ldo) {
     mt3k::GemmArgs g = gemm_args(split ? static_cast<const void*>(y_ct) : static_cast<const void*>(y), Wt, out, rows, N,
@@ -384,7 +385,7 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   };
   auto resid = [&](const void* A, const void* Wt, int K) {
     mt3k::GemmArgs g = gemm_args(A, Wt, y, rows, emb, K, emb);
-    g.out_ct = y_ct;
+    g.out_ct = y_copy;
     g.out_ss = y_ss;
     return g;
   };
@@ -403,7 +404,7 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     const mt3k::BeamState beam{e->beam_f + row0, e->beam_len + row0, e->beam_cfg, c.max_batch};
     return mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
                                     e->cur_tok + row0, e->done + row0, e->n_done, step, e->embedding, e->pos_table,
-                                    kMaxPos, y, y_ct, y_ss, emb, rows, (skip & 4) ? &beam : nullptr,
+                                    kMaxPos, y, y_copy, y_ss, emb, rows, (skip & 4) ? &beam : nullptr,
                                     (skip & 8) ? e->forced + static_cast<size_t>(row0) * Lmax : nullptr, Lmax, s);
   }
   LayerDev& L = e->dec[op >> 3];
@@ -583,7 +584,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: dense_dtype must be 0 (= compute dtype) or MT3_FP8_E4M3");
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
-  if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS))
+  if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -663,7 +664,7 @@ int mt3_engine_finalize(mt3_engine* e) {
   }
   e->dec.resize(c.num_decoder_layers);
   const bool single_stream = (c.options & MT3_OPT_SINGLE_RESIDUAL_STREAM) != 0;
-  const bool q_fold = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && (emb <= 512 || emb == 768) && !single_stream &&
+  const bool q_fold = emb % 64 == 0 && (emb <= 512 || emb == 768) && !single_stream &&
                       !(c.options & MT3_OPT_SEPARATE_PROJECTIONS);
   e->q_fold = q_fold;
   for (int l = 0; l < c.num_decoder_layers; ++l) {
@@ -720,7 +721,8 @@ int mt3_engine_finalize(mt3_engine* e) {
   // ---- workspaces
   const size_t M = static_cast<size_t>(Bm) * T;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x), M * emb * 4))) return rc;
-  e->x_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && emb <= 1024 && !single_stream && !e->dense_fp8;
+  e->x_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && emb <= 1024 &&
+               !(c.options & MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM) && !e->dense_fp8;
   if (e->x_split) {
     if ((rc = dmalloc(e, &e->x_ct, M * emb * 2))) return rc;
     if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x_ss), M * (emb / 16) * 4))) return rc;
@@ -741,9 +743,16 @@ int mt3_engine_finalize(mt3_engine* e) {
   if ((rc = dmalloc(e, &e->hbuf, M * c.mlp_dim * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->enc_out, M * emb * e->esize))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y), static_cast<size_t>(Bm) * emb * 4))) return rc;
-  e->y_split = c.compute_dtype == MT3_BF16 && emb % 64 == 0 && (emb <= 512 || emb == 768) && !single_stream;
+  // the split residual form in the decode loop.  bf16: f32 rows + bf16 copy + per-16-column sums of squares; f32 (round
+  // 3): the compute-type rows ARE the f32 rows, so only the sums travel with them (y_ct aliases y and is never written
+  // as a copy) -- the norm-fused GEMMs then need no statistics pass and the folded projections work as in bf16
+  e->y_split = emb % 64 == 0 && (emb <= 512 || emb == 768) && !single_stream;
   if (e->y_split) {
-    if ((rc = dmalloc(e, &e->y_ct, static_cast<size_t>(Bm) * emb * 2))) return rc;
+    if (c.compute_dtype == MT3_BF16) {
+      if ((rc = dmalloc(e, &e->y_ct, static_cast<size_t>(Bm) * emb * 2))) return rc;
+    } else {
+      e->y_ct = e->y;
+    }
     if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y_ss), static_cast<size_t>(Bm) * (emb / 16) * 4))) return rc;
   }
   if (e->q_fold && !e->y_split) e->q_fold = false;
@@ -912,8 +921,8 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
   if (d_forced)    // engine-owned copy: the step graph holds ITS address, whatever buffer the caller passes
     MT3_HIP_CHECK(hipMemcpyAsync(e->forced, d_forced, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
   // decoder input of step 0: Embed(BOS) + FixedEmbed[0]; later steps get theirs from the argmax kernel
-  MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y, e->y_ct, e->y_ss, batch, c.emb_dim,
-                             s));
+  MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y,
+                             c.compute_dtype == MT3_BF16 ? e->y_ct : nullptr, e->y_ss, batch, c.emb_dim, s));
 
   // step-graph variant: bits 1 / 2 = mt3_debug_engine_decode's skipped kernels (mt3_hip_debug.h; never set by the
   // product entry points), 4 = beam-1 selection, 8 = teacher forcing

@@ -199,9 +199,9 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm
         }
       }
     }
-  } else if constexpr (EPI == MT3_EPI_RESID && sizeof(CT) == 2) {
-    // residual update; on request also the compute-type copy of the new rows (dword stores of column pairs) and
-    // the sum of squares of each row over this fragment's 16 columns (exact f32, reduced on the DPP row)
+  } else if constexpr (EPI == MT3_EPI_RESID) {
+    // residual update; on request also the sum of squares of each row over this fragment's 16 columns (exact f32,
+    // reduced on the DPP row) and -- bf16 -- the compute-type copy of the new rows (dword stores of column pairs)
     const int odd = frag_row & 1;
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -217,25 +217,28 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm
           vnew[r] = (PRE ? pre[i][j][r] : static_cast<float*>(c.out)[at]) + acc[i][j][r];
           if (row < c.M) static_cast<float*>(c.out)[at] = vnew[r];
         }
-        if (c.out_ct) {
+        if (c.out_ss) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            other[r] = lane_xor1(vnew[r]);
-            part[r] = row16_sum(vnew[r] * vnew[r]);
-          }
+          for (int r = 0; r < 4; ++r) part[r] = row16_sum(vnew[r] * vnew[r]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = m0 + lrow0 + r;
             if (frag_row == 0 && row < c.M)
               c.out_ss[static_cast<size_t>(row) * (c.N >> 4) + ((n0 + wn * FN * 16 + j * 16) >> 4)] = part[r];
           }
+        }
+        if constexpr (sizeof(CT) == 2) {
+          if (c.out_ct) {
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int row = m0 + lrow0 + odd * 2 + h;
-            if (row >= c.M) continue;
-            const float lo = odd ? other[2 + h] : vnew[h], hi = odd ? vnew[2 + h] : other[h];
-            *reinterpret_cast<unsigned*>(static_cast<CT*>(c.out_ct) + static_cast<size_t>(row) * c.ldo + col - odd) =
-                pack_bf16x2(lo, hi);
+            for (int r = 0; r < 4; ++r) other[r] = lane_xor1(vnew[r]);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int row = m0 + lrow0 + odd * 2 + h;
+              if (row >= c.M) continue;
+              const float lo = odd ? other[2 + h] : vnew[h], hi = odd ? vnew[2 + h] : other[h];
+              *reinterpret_cast<unsigned*>(static_cast<CT*>(c.out_ct) + static_cast<size_t>(row) * c.ldo + col - odd) =
+                  pack_bf16x2(lo, hi);
+            }
           }
         }
       }
@@ -286,9 +289,14 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm
   }
 }
 
-template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
-  constexpr int NT = WM * WN * 64;
+// WK > 1: the K-groups of every slice are dealt to WK wave groups (split-K inside the workgroup; partial accumulators
+// meet in LDS).  For the decode-sized f32 tiles: a wave's 16x16 fragment over K = 512 is 128 dependent
+// v_mfma_f32_16x16x4_f32 = 1.7 us of matrix-pipe time on ONE of the CU's four SIMDs while the launch has fewer waves
+// than the chip has SIMDs -- eight waves per tile halve that chain.
+template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8, int WK = 1>
+__global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
+  constexpr int NT = WM * WN * WK * 64;
+  static_assert(WK == 1 || (!NORM && (BK / CTraits<CT>::KGROUP) % WK == 0), "split-K: norm-free tiles, K-groups divisible");
   constexpr int KPL = CTraits<CT>::KPL;
   constexpr int KG = CTraits<CT>::KGROUP;
   constexpr int CPR = BK / KPL;          // 16-byte chunks per tile row
@@ -324,10 +332,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
 
   MT3_PROF_MARK(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
+  const int wk = wave / (WM * WN), wmn = wave % (WM * WN);
+  const int wm = wmn / WN, wn = wmn % WN;
   const int tiles_n = gN / BN;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+  int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+  if (g.n_major) {
+    const int tiles_m = gridDim.x / tiles_n;
+    m0 = (lid % tiles_m) * BM;
+    n0 = (lid / tiles_m) * BN;
+  }
 
   const int ld_row = tid / CPR, ld_chunk = tid % CPR;
   // norm == 2: the K/16 (<= 4 * NPV) exact partial sums of squares of this thread's tile row, requested up front
@@ -342,9 +356,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
       pv[u] = (scale_rows && u < (gK >> 6)) ? p4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // decode-sized RESID tiles (bf16): this lane's elements of the residual rows, requested before anything else
-  constexpr bool kPre = (EPI == MT3_EPI_RESID || EPI == kEpiResidQ) && sizeof(CT) == 2 && FM * FN <= 2;
+  constexpr bool kPre = (EPI == MT3_EPI_RESID || EPI == kEpiResidQ) && FM * FN <= 2;
   float xpre[FM][FN][4];
-  if constexpr (kPre) {
+  if constexpr (kPre) if (wk == 0) {
     const float* src = static_cast<const float*>(gO);
     int ld = gLdo, c0 = n0;
     if constexpr (EPI == kEpiResidQ) {
@@ -408,8 +422,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
     if (k0 + BK < gK)                   // next slice in flight while the MFMAs below run
       gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg, b_reg, ss, gA, gW, m0, n0, tid, gM, gLda, gK,
                                                                     k0 + BK);
+    constexpr int KSTEPS = BK / KG / WK;
 #pragma unroll
-    for (int kk = 0; kk < BK / KG; ++kk) {
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int kk = wk * KSTEPS + ks;
       u32x4 af[FM], bf[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(a_base + i * 16 * ROWE + kk * KG);
@@ -422,6 +438,32 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
     }
   }
   MT3_PROF_MARK(3);
+  if constexpr (WK > 1) {
+    // the wave groups' partial accumulators meet in the (now idle) A tile; group 0 carries on alone
+    static_assert(sizeof(CT) * BM * ROWE >= sizeof(float) * (WK - 1) * WM * WN * FM * FN * 256, "split-K scratch");
+    float* red = reinterpret_cast<float*>(As);
+    __syncthreads();
+    if (wk > 0) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            red[(((wk - 1) * WM * WN + wmn) * FM * FN + i * FN + j) * 256 + r * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int q = 1; q < WK; ++q)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[i][j][r] += red[(((q - 1) * WM * WN + wmn) * FM * FN + i * FN + j) * 256 + r * 64 + lane];
+  }
 
   if constexpr (NORM) {
     // Each tile row was streamed by CPR consecutive lanes.  Their partial sums of squares meet on the DPP
@@ -723,13 +765,13 @@ static bool glds_eligible(const GemmArgs& g, bool a_f32, int norm, int epi) {
 }
 
 // ------------------------------------------------------------------ dispatch
-template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8>
+template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8, int WK = 1>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   if (g.N % BN != 0 || g.K % BK != 0) return mt3::fail(MT3_ERR_INVALID, "gemm: N/K not a multiple of the tile");
   if (g.a_ss && g.K > 64 * NPV) return mt3::fail(MT3_ERR_INVALID, "gemm: K too large for this tile's partial-sum registers");
   const int grid = ((g.M + BM - 1) / BM) * (g.N / BN);
-  hipLaunchKernelGGL((gemm_kernel<CT, BM, BN, BK, WM, WN, A_F32, NORM, EPI, NPV>), dim3(grid), dim3(WM * WN * 64), 0,
-                     s, g);
+  hipLaunchKernelGGL((gemm_kernel<CT, BM, BN, BK, WM, WN, A_F32, NORM, EPI, NPV, WK>), dim3(grid),
+                     dim3(WM * WN * WK * 64), 0, s, g);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }
@@ -746,6 +788,18 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
   constexpr int KG = CTraits<CT>::KGROUP;
   if (small) {
     const bool deep = g.K % (16 * KG) == 0;
+    if constexpr (!NORM && !A_F32 && KG == 16 && EPI != MT3_EPI_HEADS && EPI != MT3_EPI_POS) {
+      // f32 operands arriving in the compute type (the split residual form / plain activations): eight waves per
+      // tile, K-groups split two ways (see gemm_kernel)
+      if (!g_knobs.no_f32_split_k) {
+        if constexpr (EPI == MT3_EPI_GEGLU) {
+          if (deep) return launch_cfg<CT, 32, 64, 16 * KG, 2, 2, A_F32, NORM, EPI, 8, 2>(g, s);
+        } else {
+          if (g.K == 24 * KG) return launch_cfg<CT, 32, 32, 12 * KG, 2, 2, A_F32, NORM, EPI, 8, 2>(g, s);
+          if (deep) return launch_cfg<CT, 32, 32, 16 * KG, 2, 2, A_F32, NORM, EPI, 8, 2>(g, s);
+        }
+      }
+    }
     if constexpr (!NORM && !A_F32 && KG == 32 && EPI != MT3_EPI_HEADS && EPI != MT3_EPI_POS) {
       // ismir2022/base.gin shape (emb = heads * 64 = 768): K = 768 as ONE slice too, with room for its 48 partial
       // sums of squares when the rows arrive as the bf16 residual copy (norm 2)
@@ -762,6 +816,10 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
         // the attention out-projections (K = 384 = 12 K-groups) as ONE slice as well (-1 % of the decode; the
         // same for wo, K = 1024 in 133 KB of LDS, measured slower than its two 512-slices)
         if (g.K == 12 * KG) return launch_cfg<CT, 32, 32, 12 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
+      }
+      if constexpr (!NORM && !A_F32 && KG == 16) {
+        // f32 operands: the attention out-projections (K = 384) in two slices of 192 instead of six of 64
+        if (g.K == 24 * KG) return launch_cfg<CT, 32, 32, 12 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
       }
       if (deep) return launch_cfg<CT, 32, 32, 16 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 32, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
@@ -784,9 +842,7 @@ static int launch_typed(const GemmArgs& g, bool a_f32, int norm, int epi, bool s
       case MT3_EPI_GEGLU: return launch_tile<CT, false, false, MT3_EPI_GEGLU>(g, small, s);
       case MT3_EPI_F32: return launch_tile<CT, false, false, MT3_EPI_F32>(g, small, s);
       case kEpiStoreQ:
-        if constexpr (sizeof(CT) == 2) {
-          if (small) return launch_tile<CT, false, false, kEpiStoreQ>(g, small, s);
-        }
+        if (small) return launch_tile<CT, false, false, kEpiStoreQ>(g, small, s);
         break;
       default: break;
     }
@@ -812,9 +868,7 @@ static int launch_typed(const GemmArgs& g, bool a_f32, int norm, int epi, bool s
     switch (epi) {
       case MT3_EPI_RESID: return launch_tile<CT, false, false, MT3_EPI_RESID>(g, small, s);
       case kEpiResidQ:
-        if constexpr (sizeof(CT) == 2) {
-          if (small) return launch_tile<CT, false, false, kEpiResidQ>(g, small, s);
-        }
+        if (small) return launch_tile<CT, false, false, kEpiResidQ>(g, small, s);
         break;
       case MT3_EPI_HEADS: return launch_tile<CT, false, false, MT3_EPI_HEADS>(g, small, s);
       case MT3_EPI_STORE: return launch_tile<CT, false, false, MT3_EPI_STORE>(g, small, s);
@@ -842,8 +896,10 @@ int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, int norm, int epi, boo
       default: return launch_glds<MT3_EPI_F32>(g, s);
     }
   }
-  if (dtype == MT3_BF16) return launch_typed<__bf16>(g, a_f32, norm, epi, small, s);
-  if (dtype == MT3_F32) return launch_typed<float>(g, a_f32, norm, epi, small, s);
+  GemmArgs gg = g;
+  gg.n_major = small && g_knobs.xcd_n_major ? 1 : 0;
+  if (dtype == MT3_BF16) return launch_typed<__bf16>(gg, a_f32, norm, epi, small, s);
+  if (dtype == MT3_F32) return launch_typed<float>(gg, a_f32, norm, epi, small, s);
   return mt3::fail(MT3_ERR_INVALID, "gemm: unknown dtype");
 }
 
@@ -868,8 +924,9 @@ extern "C" int mt3_op_gemm_ex(int32_t dtype, const void* d_A, int32_t a_is_f32, 
   g.a_ss = norm == 2 ? d_a_ss : nullptr;
   g.out_ct = d_out_ct;
   g.out_ss = d_out_ss;
-  if ((d_out_ct != nullptr) != (d_out_ss != nullptr))
-    return mt3::fail(MT3_ERR_INVALID, "gemm: out_ct and out_ss come together");
+  if (dtype == MT3_BF16 ? (d_out_ct != nullptr) != (d_out_ss != nullptr) : d_out_ct != nullptr)
+    return mt3::fail(MT3_ERR_INVALID, "gemm: bf16: out_ct and out_ss come together; f32: out_ss alone (the rows are their "
+                                      "own compute-type copy)");
   return mt3k::launch_gemm(dtype, g, a_is_f32 != 0, norm, epilogue, small != 0, static_cast<hipStream_t>(stream));
 }
 

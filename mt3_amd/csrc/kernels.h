@@ -28,6 +28,9 @@ struct GemmArgs {
   // out2 (f32 [M][N - n_split], unscaled; ResidQ accumulates into it), columns [0, n_split) take the STORE / RESID path
   float* out2;
   int n_split;
+  // tile -> XCD dealing: 0 = an XCD owns a run of row blocks (all weight columns pass through its L2), 1 = an XCD
+  // owns a run of weight-column tiles for ALL row blocks (its L2 sees 1/8 of the weights; set by launch_gemm)
+  int n_major;
 };
 // internal epilogues (not part of the C ABI): STORE / RESID with a second f32 output region, see GemmArgs::out2
 constexpr int kEpiStoreQ = 6, kEpiResidQ = 7;

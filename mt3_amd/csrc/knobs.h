@@ -9,6 +9,8 @@ struct Knobs {
   int dec_attn_waves;       // waves per decode-attention workgroup (2 / 3 / 4)
   int dec_attn_fp8_waves;
   int no_lds_dma_gemm;      // encoder GEMMs on the register-staged tile
+  int no_f32_split_k;       // decode-sized f32 GEMM tiles with four waves (no split-K inside the workgroup)
+  int xcd_n_major;          // decode-sized GEMM tiles: an XCD owns a column slice of the weights instead of a row block
 };
 extern Knobs g_knobs;
 

@@ -116,7 +116,8 @@ class Transformer:
     def __init__(self, config: T5Config, input_length: int = 256, max_decode_length: int = 1024,
                  max_batch: int = 8, decode_chains: int = 1, options: int = 0):
         """options: bit set of _lib.OPT_* (mt3_engine_config.options): how the same function is evaluated --
-        OPT_SINGLE_RESIDUAL_STREAM (no bf16 copy / partial sums of the residual rows), OPT_SEPARATE_PROJECTIONS
+        OPT_SINGLE_RESIDUAL_STREAM / OPT_ENCODER_SINGLE_RESIDUAL_STREAM (no bf16 copy / partial sums of the decoder's /
+        encoder's residual rows), OPT_SEPARATE_PROJECTIONS
         (no folding of projections into neighbouring launches).  0 = the defaults."""
         self.config = config
         self.input_length, self.max_decode_length, self.max_batch = input_length, max_decode_length, max_batch

@@ -1,0 +1,37 @@
+"""stdin: bench.py's JSON line -> the handful of figures worth reading in a gpurun tail."""
+import json
+import sys
+
+line = sys.stdin.read().strip().splitlines()
+try:
+    d = json.loads(line[-1])
+except Exception as e:
+    print("no JSON line:", e, line[-3:] if line else "")
+    sys.exit(0)
+r = d.get("roofline") or {}
+print("HEADLINE %s %.1f %s  ms/step %.1f  n_gpus %d steps %d | attn %.2f us frac %.3f traffic %s | cross %.2f us | small %.1f us/step "
+      "| whole-step hbm %.3f" % (d["dtype"], d["value"], d["unit"], d["ms_per_step"], d["n_gpus"], d["steps"],
+                               r.get("avg_launch_us", 0), r.get("frac", 0), r.get("traffic"),
+                               (r.get("cross_attn") or {}).get("avg_launch_us", 0), r.get("small_kernel_us_per_step", 0),
+                               r.get("whole_step_hbm_frac", 0)))
+for k, v in (d.get("extra") or {}).items():
+    if not isinstance(v, dict):
+        continue
+    if k == "divergence_vs_f32":
+        for kk, vv in v.items():
+            if isinstance(vv, dict):
+                print("  DIVERGENCE %s:" % kk, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in vv.items()})
+        continue
+    rr = v.get("roofline") or {}
+    s = "  %s: " % k + ", ".join("%s=%s" % (a, round(b, 4) if isinstance(b, float) else b) for a, b in v.items()
+                                 if a in ("value", "ms_per_step", "steps", "ms", "achieved", "frac", "encoder_ms",
+                                          "segments_per_s", "traffic", "error"))
+    if rr:
+        s += " | attn %.2f us frac %.3f traffic %s small %.1f us/step whole-step %.3f" % (
+            rr["avg_launch_us"], rr["frac"], rr.get("traffic"), rr.get("small_kernel_us_per_step", 0),
+            rr["whole_step_hbm_frac"])
+    print(s[:600])
+c = d.get("cpu_baseline")
+if c:
+    print("  CPU:", {k: v for k, v in c.items() if k in ("value", "cores", "nproc")}, c.get("sample", "")[-60:],
+          {k: v.get("value") for k, v in c.items() if isinstance(v, dict)})

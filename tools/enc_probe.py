@@ -36,7 +36,7 @@ if os.environ.get("PROBE_SPLIT"):
     # split vs single decode residual stream on two engine INSTANCES (tests/test_gpu_engine.py::test_split_residual...)
     Bs = 34
     res = {}
-    for name, opt in (("split", 0), ("single", _lib.OPT_SINGLE_RESIDUAL_STREAM)):
+    for name, opt in (("split", 0), ("single", _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_ENCODER_SINGLE_RESIDUAL_STREAM)):
         e2 = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=Bs, options=opt)
         e2.load_params(params)
         enc = e2.encode(lm[:Bs], return_encoded=True).clone()

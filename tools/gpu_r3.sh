@@ -1,0 +1,67 @@
+#!/bin/bash
+# Round-3 GPU session driver (run through gpurun): STAGES is a space-separated subset of
+#   test   pytest -m gpu (TESTS = extra pytest args, e.g. a -k filter)
+#   pmc    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_attn.py (bf16 / f32 / fp8 decode attention +
+#          frontend) -> gpurun_out/pmc/r3_pmc_summary.json (+ the two counter csv files)
+#   prof   rocprofv3 --kernel-trace --stats of `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras` for the bf16
+#          headline and for --dtype float32 -> gpurun_out/prof/{r3,r3_f32}_kernel_stats.csv + trace digests
+#   bench  python bench.py $BENCH_ARGS -> gpurun_out/bench_r3.log
+# Everything lands under gpurun_out/; copy what should be judged into profiles/.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+R="$PWD"
+STAGES="${STAGES:-test bench}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for st in $STAGES; do
+  case $st in
+    test)
+      timeout ${TEST_TIMEOUT:-900} python -m pytest tests -m gpu -x -q $TESTS > gpurun_out/pytest_r3.log 2>&1
+      echo "exit $? : pytest -m gpu $TESTS"; tail -5 gpurun_out/pytest_r3.log; grep -h "rel-L2\|token-exact\|agreement\|benched" gpurun_out/pytest_r3.log | cut -c1-300 | tail -20
+      ;;
+    pmc)
+      rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
+      cd /tmp
+      for c in FETCH_SIZE WRITE_SIZE; do
+        timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmc" -o $c -- python "$R/tools/pmc_attn.py" > "$R/gpurun_out/pmc/$c.log" 2>&1
+        echo "exit $? : pmc $c"
+      done
+      cd "$R"
+      python tools/pmc_summary.py gpurun_out/pmc gpurun_out/pmc r3 > gpurun_out/pmc/summary.log 2>&1; tail -12 gpurun_out/pmc/summary.log
+      python - <<'PY'
+import json
+try:
+    s = json.load(open("gpurun_out/pmc/r3_pmc_summary.json"))
+    for k, v in s.items():
+        if k.startswith("dec_attn_self"):
+            print(k, {n: round(e["traffic_over_algorithmic"], 4) for n, e in v.items()})
+        elif k.startswith(("dec_attn_cross", "logmel")):
+            print(k, round(v["traffic_over_algorithmic"], 4))
+except Exception as e:
+    print("no pmc summary:", e)
+PY
+      find gpurun_out/pmc -name "*.db" -delete; find gpurun_out/pmc -name "*kernel_trace.csv" -size +4M -delete
+      ;;
+    prof)
+      rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
+      for v in "r3:" "r3_f32:--dtype float32"; do
+        name="${v%%:*}"; flags="${v#*:}"
+        cd /tmp
+        timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o $name -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-extras $flags > "$R/gpurun_out/bench_prof_$name.log" 2>&1
+        echo "exit $? : rocprof bench $flags"
+        cd "$R"
+        f=$(find gpurun_out/prof -name "${name}_kernel_stats.csv" | head -1)
+        [ -n "$f" ] && head -12 "$f" | cut -c1-200
+        mkdir -p gpurun_out/prof_$name && find gpurun_out/prof -name "${name}_kernel_trace.csv" -exec cp {} gpurun_out/prof_$name/ \;
+        python tools/trace_digest.py gpurun_out/prof_$name > gpurun_out/${name}_trace_digest.txt 2>&1
+        rm -rf gpurun_out/prof_$name
+        tail -1 "$R/gpurun_out/bench_prof_$name.log" | cut -c1-400
+      done
+      find gpurun_out/prof -name "*kernel_trace.csv" -delete; find gpurun_out/prof -name "*.db" -delete
+      ;;
+    bench)
+      timeout ${BENCH_TIMEOUT:-900} python bench.py $BENCH_ARGS > gpurun_out/bench_r3.log 2>&1
+      echo "exit $? : bench $BENCH_ARGS"; tail -1 gpurun_out/bench_r3.log | python tools/bench_digest.py
+      ;;
+    *) echo "unknown stage $st";;
+  esac
+done
