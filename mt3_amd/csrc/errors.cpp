@@ -17,7 +17,7 @@ int fail(int code, const std::string& msg) {
 }  // namespace mt3
 
 namespace mt3k {
-Knobs g_knobs = {0, 0, 0, 0, 0};
+Knobs g_knobs = {0, 0, 0, 0, 0, 0};
 }
 
 extern "C" {
@@ -38,7 +38,11 @@ int mt3_debug_set_knob(int32_t knob, int32_t value) {
       mt3k::g_knobs.no_f32_split_k = value != 0;
       return MT3_OK;
     case MT3_DEBUG_KNOB_XCD_N_MAJOR:
-      mt3k::g_knobs.xcd_n_major = value != 0;
+      if (value < 0 || value > 2) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_set_knob: XCD_N_MAJOR is 0 (auto), 1 or 2");
+      mt3k::g_knobs.xcd_n_major = value;
+      return MT3_OK;
+    case MT3_DEBUG_KNOB_NO_PREFETCH2:
+      mt3k::g_knobs.no_prefetch2 = value != 0;
       return MT3_OK;
     default:
       return mt3::fail(MT3_ERR_INVALID, "mt3_debug_set_knob: unknown knob");

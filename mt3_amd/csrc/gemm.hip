@@ -23,6 +23,8 @@
 // pairs swap over DPP); XCD-aware block remap so that the column tiles of one row panel share an L2.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "device.h"
 #include "kernels.h"
@@ -293,8 +295,14 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm
 // meet in LDS).  For the decode-sized f32 tiles: a wave's 16x16 fragment over K = 512 is 128 dependent
 // v_mfma_f32_16x16x4_f32 = 1.7 us of matrix-pipe time on ONE of the CU's four SIMDs while the launch has fewer waves
 // than the chip has SIMDs -- eight waves per tile halve that chain.
-template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8, int WK = 1>
+// PF = 2: TWO K slices in flight (a second set of staging registers): the loads of slice t + 2 are issued while slice t
+// is multiplied, and the first two slices are requested back to back at kernel entry -- a latency-bound tile with K in
+// 2 .. 4 slices (f32 operands: K = 512 / 1024; bf16: K = 1024 / 2048) pays one dependent memory round trip less per
+// pair of slices.
+template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8, int WK = 1,
+          int PF = 1>
 __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
+  static_assert(PF == 1 || PF == 2, "prefetch depth");
   constexpr int NT = WM * WN * WK * 64;
   static_assert(WK == 1 || (!NORM && (BK / CTraits<CT>::KGROUP) % WK == 0), "split-K: norm-free tiles, K-groups divisible");
   constexpr int KPL = CTraits<CT>::KPL;
@@ -378,7 +386,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
           xpre[i][j][r] = src[static_cast<size_t>(row < gM ? row : gM - 1) * ld + c0 + wn * FN * 16 + j * 16 + (lane & 15)];
         }
   }
-  u32x4 a_reg[A_PASSES], b_reg[B_PASSES];
+  u32x4 a_reg[PF][A_PASSES], b_reg[PF][B_PASSES];
   float ss[A_PASSES];
 #pragma unroll
   for (int p = 0; p < A_PASSES; ++p) ss[p] = 0.f;
@@ -393,7 +401,11 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
   const CT* a_base = &As[(wm * FM * 16 + frag_row) * ROWE + frag_g * KPL];
   const CT* b_base = &Bs[(wn * FN * 16 + frag_row) * ROWE + frag_g * KPL];
 
-  gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg, b_reg, ss, gA, gW, m0, n0, tid, gM, gLda, gK, 0);
+  gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg[0], b_reg[0], ss, gA, gW, m0, n0, tid, gM, gLda, gK, 0);
+  if constexpr (PF == 2)
+    if (BK < gK)
+      gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg[1], b_reg[1], ss, gA, gW, m0, n0, tid, gM, gLda,
+                                                                    gK, BK);
   if constexpr (!NORM) {
     if (scale_rows) {
       float t = 0.f;
@@ -402,26 +414,28 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
       rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);                               // read after the K loop's barriers
     }
   }
-  for (int k0 = 0; k0 < gK; k0 += BK) {
+  // one K slice: staging registers of `slot` -> LDS, refill the slot with slice k0 + PF * BK, multiply
+  auto slice = [&](auto slot_c, int k0) {
+    constexpr int SLOT = decltype(slot_c)::value;
     __syncthreads();                    // every wave is done reading the previous tile
     MT3_PROF_MARK(1);
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       int r, ch;
       tile_chunk<CPR, NT>(tid, p, &r, &ch);
-      *reinterpret_cast<u32x4*>(&As[r * ROWE + ch * KPL]) = a_reg[p];
+      *reinterpret_cast<u32x4*>(&As[r * ROWE + ch * KPL]) = a_reg[SLOT][p];
     }
 #pragma unroll
     for (int p = 0; p < B_PASSES; ++p) {
       int r, ch;
       tile_chunk<CPR, NT>(tid, p, &r, &ch);
-      *reinterpret_cast<u32x4*>(&Bs[r * ROWE + ch * KPL]) = b_reg[p];
+      *reinterpret_cast<u32x4*>(&Bs[r * ROWE + ch * KPL]) = b_reg[SLOT][p];
     }
     __syncthreads();
     MT3_PROF_MARK(2);
-    if (k0 + BK < gK)                   // next slice in flight while the MFMAs below run
-      gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg, b_reg, ss, gA, gW, m0, n0, tid, gM, gLda, gK,
-                                                                    k0 + BK);
+    if (k0 + PF * BK < gK)              // a later slice in flight while the MFMAs below run
+      gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg[SLOT], b_reg[SLOT], ss, gA, gW, m0, n0, tid, gM,
+                                                                    gLda, gK, k0 + PF * BK);
     constexpr int KSTEPS = BK / KG / WK;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -435,6 +449,14 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) mfma_chunk<CT>(af[i], bf[j], acc[i][j]);
+    }
+  };
+  if constexpr (PF == 1) {
+    for (int k0 = 0; k0 < gK; k0 += BK) slice(std::integral_constant<int, 0>{}, k0);
+  } else {
+    for (int k0 = 0; k0 < gK; k0 += 2 * BK) {
+      slice(std::integral_constant<int, 0>{}, k0);
+      if (k0 + BK < gK) slice(std::integral_constant<int, 1>{}, k0 + BK);
     }
   }
   MT3_PROF_MARK(3);
@@ -765,12 +787,13 @@ static bool glds_eligible(const GemmArgs& g, bool a_f32, int norm, int epi) {
 }
 
 // ------------------------------------------------------------------ dispatch
-template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8, int WK = 1>
+template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8, int WK = 1,
+          int PF = 1>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   if (g.N % BN != 0 || g.K % BK != 0) return mt3::fail(MT3_ERR_INVALID, "gemm: N/K not a multiple of the tile");
   if (g.a_ss && g.K > 64 * NPV) return mt3::fail(MT3_ERR_INVALID, "gemm: K too large for this tile's partial-sum registers");
   const int grid = ((g.M + BM - 1) / BM) * (g.N / BN);
-  hipLaunchKernelGGL((gemm_kernel<CT, BM, BN, BK, WM, WN, A_F32, NORM, EPI, NPV, WK>), dim3(grid),
+  hipLaunchKernelGGL((gemm_kernel<CT, BM, BN, BK, WM, WN, A_F32, NORM, EPI, NPV, WK, PF>), dim3(grid),
                      dim3(WM * WN * WK * 64), 0, s, g);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
@@ -783,6 +806,13 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
 //         >= 100 workgroups on the chip, and the K step is as deep as LDS allows (16 K-groups = 512 bf16
 //         elements: K = 512 in ONE slice) so that every global load of the block is in flight at once
 //         instead of 8-16 dependent load->barrier->MFMA rounds.
+// decode-sized tile BMxBN with K slice BK; more than one slice: two slices in flight (PF = 2)
+template <typename CT, int BM, int BN, int BK, bool A_F32, bool NORM, int EPI, int NPV = 8, int WK = 1>
+static int launch_small(const GemmArgs& g, hipStream_t s) {
+  if (g.K > BK && !g_knobs.no_prefetch2) return launch_cfg<CT, BM, BN, BK, 2, 2, A_F32, NORM, EPI, NPV, WK, 2>(g, s);
+  return launch_cfg<CT, BM, BN, BK, 2, 2, A_F32, NORM, EPI, NPV, WK, 1>(g, s);
+}
+
 template <typename CT, bool A_F32, bool NORM, int EPI>
 static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
   constexpr int KG = CTraits<CT>::KGROUP;
@@ -790,13 +820,13 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
     const bool deep = g.K % (16 * KG) == 0;
     if constexpr (!NORM && !A_F32 && KG == 16 && EPI != MT3_EPI_HEADS && EPI != MT3_EPI_POS) {
       // f32 operands arriving in the compute type (the split residual form / plain activations): eight waves per
-      // tile, K-groups split two ways (see gemm_kernel)
+      // tile, K-groups split two ways (see gemm_kernel; halves the staging registers per thread as well)
       if (!g_knobs.no_f32_split_k) {
         if constexpr (EPI == MT3_EPI_GEGLU) {
-          if (deep) return launch_cfg<CT, 32, 64, 16 * KG, 2, 2, A_F32, NORM, EPI, 8, 2>(g, s);
+          if (deep) return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI, 8, 2>(g, s);
         } else {
-          if (g.K == 24 * KG) return launch_cfg<CT, 32, 32, 12 * KG, 2, 2, A_F32, NORM, EPI, 8, 2>(g, s);
-          if (deep) return launch_cfg<CT, 32, 32, 16 * KG, 2, 2, A_F32, NORM, EPI, 8, 2>(g, s);
+          if (g.K == 24 * KG) return launch_small<CT, 32, 32, 12 * KG, A_F32, NORM, EPI, 8, 2>(g, s);
+          if (deep) return launch_small<CT, 32, 32, 16 * KG, A_F32, NORM, EPI, 8, 2>(g, s);
         }
       }
     }
@@ -809,7 +839,7 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
       }
     }
     if constexpr (EPI == MT3_EPI_GEGLU) {
-      if (deep) return launch_cfg<CT, 32, 64, 16 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
+      if (deep) return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 64, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
     } else {
       if constexpr (!NORM && !A_F32 && KG == 32) {
@@ -819,9 +849,9 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
       }
       if constexpr (!NORM && !A_F32 && KG == 16) {
         // f32 operands: the attention out-projections (K = 384) in two slices of 192 instead of six of 64
-        if (g.K == 24 * KG) return launch_cfg<CT, 32, 32, 12 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
+        if (g.K == 24 * KG) return launch_small<CT, 32, 32, 12 * KG, A_F32, NORM, EPI>(g, s);
       }
-      if (deep) return launch_cfg<CT, 32, 32, 16 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
+      if (deep) return launch_small<CT, 32, 32, 16 * KG, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 32, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
     }
   }
@@ -897,7 +927,11 @@ int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, int norm, int epi, boo
     }
   }
   GemmArgs gg = g;
-  gg.n_major = small && g_knobs.xcd_n_major ? 1 : 0;
+  // an XCD's 4 MB L2 sees every weight column when tiles are dealt by row block; above ~3 MB per matrix (base.gin
+  // shape, f32 operands) dealing by column slice keeps an eighth of it there instead (measured: base.gin decode
+  // without attention 644 -> 603 us per step; MT3 shape bf16, weights <= 2 MB: 198 -> 203, hence the threshold)
+  const size_t w_bytes = static_cast<size_t>(g.N) * g.K * (dtype == MT3_BF16 ? 2 : 4);
+  gg.n_major = small && (g_knobs.xcd_n_major == 1 || (g_knobs.xcd_n_major == 0 && w_bytes > (3u << 20))) ? 1 : 0;
   if (dtype == MT3_BF16) return launch_typed<__bf16>(gg, a_f32, norm, epi, small, s);
   if (dtype == MT3_F32) return launch_typed<float>(gg, a_f32, norm, epi, small, s);
   return mt3::fail(MT3_ERR_INVALID, "gemm: unknown dtype");

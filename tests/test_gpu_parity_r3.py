@@ -191,7 +191,7 @@ def test_poisoned_caches_do_not_leak_into_results(dtype, kv):
         assert torch.equal(tf, clean_tf)
 
 
-def test_kernel_decode_attention_ignores_what_lies_past_the_row(ctx=None):
+def test_kernel_decode_attention_ignores_what_lies_past_the_row():
     """mt3_op_decode_attention / _fp8 on caller-owned caches whose rows past n_keys hold NaN / Inf bit patterns
     (what torch.empty may hand out): same output as over zero-filled tails, bit for bit."""
     lib = _lib.load()
@@ -265,3 +265,44 @@ def test_wide_bf16_engine_encodes_at_batch_one():
             assert r < 2e-2, (nb, b, r)
         ids = eng.decode(num_steps=6).cpu().numpy()
         assert ids[:, :6].max() < cfg.vocab_size
+
+
+def test_f32_engine_variants_agree_at_f32_round_off():
+    """Round 3 moved the f32 decode loop onto the split residual form (f32 rows + per-16-column sums of squares), folded
+    the cross-attention q-projection into its neighbours and gave the decode-sized f32 tiles eight waves with the
+    K-groups split two ways.  Every variant is the same function with different summation orders: against the r2 path
+    (options = SINGLE_RESIDUAL_STREAM | SEPARATE_PROJECTIONS, four-wave tiles) teacher-forced logits at 96 positions
+    agree to 2e-5 rel-L2 per (step, row), and each variant stays inside 1e-4 of the f32 oracle."""
+    cfg = network.T5Config(dtype="float32")
+    params = network.init_random_params(cfg, seed=0, norm_scale_jitter=0.2)
+    B, S = 5, 96
+    x = _inputs(B, seed=31)
+    x[4, 50:] = 0.0
+    forced = _forced(B, S, 3)
+    _, ref = _teacher_forced_ref(_oracle(cfg, params), x, forced)
+    lib = _lib.load()
+    outs = {}
+    try:
+        for name, opt, no_split_k in (("r3", 0, 0), ("r3 four-wave tiles", 0, 1), ("separate projections", _lib.OPT_SEPARATE_PROJECTIONS, 0),
+                                      ("r2 path", _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_SEPARATE_PROJECTIONS, 1)):
+            _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_F32_SPLIT_K, no_split_k))
+            eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=opt)
+            eng.load_params(params)
+            assert eng.status(_lib.STATUS_Q_FOLD) == (1 if opt == 0 else 0)
+            assert eng.status(_lib.STATUS_RESIDUAL_SPLIT) == (0 if opt & _lib.OPT_SINGLE_RESIDUAL_STREAM else 1)
+            eng.encode(torch.from_numpy(x).cuda())
+            ids, logits = eng.decode_forced(forced, num_steps=S)
+            outs[name] = logits.cpu().numpy()
+            r = _rel_rows(outs[name], ref)
+            print(f"f32 engine [{name}]: teacher-forced logits vs f32 oracle, {S} positions: max {r.max():.3e}")
+            assert r.max() < 1e-4, (name, r.max())
+            g = eng.decode(num_steps=24).cpu().numpy()
+            outs[name + " ids"] = g
+            del eng
+    finally:
+        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_F32_SPLIT_K, 0))
+    for name in ("r3", "r3 four-wave tiles", "separate projections"):
+        d = _rel_rows(outs[name], outs["r2 path"])
+        print(f"f32 engine [{name}] vs the r2 path: max rel-L2 {d.max():.3e}")
+        assert d.max() < 2e-5, (name, d.max())
+        assert np.array_equal(outs[name + " ids"], outs["r2 path ids"])

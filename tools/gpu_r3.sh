@@ -6,6 +6,7 @@
 #   prof   rocprofv3 --kernel-trace --stats of `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras` for the bf16
 #          headline and for --dtype float32 -> gpurun_out/prof/{r3,r3_f32}_kernel_stats.csv + trace digests
 #   bench  python bench.py $BENCH_ARGS -> gpurun_out/bench_r3.log
+#   ab     python tools/ab_decode.py $AB_ARGS (decode-loop variants, one process) -> gpurun_out/ab_decode.log
 # Everything lands under gpurun_out/; copy what should be judged into profiles/.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R="$PWD"
@@ -61,6 +62,10 @@ PY
     bench)
       timeout ${BENCH_TIMEOUT:-900} python bench.py $BENCH_ARGS > gpurun_out/bench_r3.log 2>&1
       echo "exit $? : bench $BENCH_ARGS"; tail -1 gpurun_out/bench_r3.log | python tools/bench_digest.py
+      ;;
+    ab)
+      timeout ${AB_TIMEOUT:-600} python tools/ab_decode.py $AB_ARGS > gpurun_out/ab_decode.log 2>&1
+      echo "exit $? : ab_decode $AB_ARGS"; grep -v "^/opt\|Warning" gpurun_out/ab_decode.log | tail -20
       ;;
     *) echo "unknown stage $st";;
   esac
