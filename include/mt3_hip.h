@@ -128,7 +128,11 @@ enum {
   /* decoder: the projections that consume a freshly updated residual row (cross-attention query; next layer's
    * q/k/v) get a launch of their own instead of riding as extra output columns in the neighbouring launches
    * (linearity of the residual update) */
-  MT3_OPT_SEPARATE_PROJECTIONS = 2
+  MT3_OPT_SEPARATE_PROJECTIONS = 2,
+  /* decoder: only the q / k / v (+ cross-query) projection of a layer's INPUT row keeps its own launch (otherwise it
+   * rides in the previous layer's MLP out-projection launch, and layer 0's comes from two table rows); the
+   * cross-attention query stays folded */
+  MT3_OPT_SEPARATE_QKV_PROJECTION = 8
 };
 
 typedef struct mt3_engine mt3_engine;
@@ -192,7 +196,8 @@ int mt3_engine_decode_forced(mt3_engine* e, int32_t batch, int32_t num_steps, in
  * residual rows as f32 + bf16 copy + partial sums of squares. */
 enum { MT3_STATUS_GRAPH_FALLBACKS = 0, MT3_STATUS_LAST_DECODE_USED_GRAPH = 1, MT3_STATUS_RESIDUAL_SPLIT = 2,
        MT3_STATUS_KV_FP8 = 3, MT3_STATUS_Q_FOLD = 4 /* cross q-projection folded into the neighbouring launches */,
-       MT3_STATUS_DENSE_FP8 = 5 /* encoder dense layers on the MXFP8 path */ };
+       MT3_STATUS_DENSE_FP8 = 5 /* encoder dense layers on the MXFP8 path */,
+       MT3_STATUS_QKV_FOLD = 6 /* the decoder layers' q/k/v projections folded into the preceding launches */ };
 int mt3_engine_status(const mt3_engine* e, int32_t what);
 
 /* GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271): -1 from the

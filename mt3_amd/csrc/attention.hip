@@ -418,13 +418,33 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   for (int u = 0; u < UNROLL; ++u)
     if (wave * KPW + slot + u * STRIDE >= n_cache) vv0[u] = u32x4{0u, 0u, 0u, 0u};
 
+  // QF32: q (and with APPEND the step's new K/V row) arrive as UNNORMALISED f32 products plus the partial sums of
+  // squares of the residual row they were projected from (the projection rode in the neighbouring GEMM launches):
+  // 1/rms is applied here, then the values are rounded to the compute type exactly where the GEMM epilogue would have
+  float rs = 1.f;
+  if constexpr (QF32) rs = row_rs_from_partials(a.q_ss + static_cast<size_t>(b) * a.q_ss_n, a.q_ss_n, lane);
+  auto scaled_chunk = [&](const float* p) -> u32x4 {
+    const float4 v0 = *reinterpret_cast<const float4*>(p);
+    if constexpr (KPL == 8) {
+      const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+      const float f[8] = {v0.x * rs, v0.y * rs, v0.z * rs, v0.w * rs, v1.x * rs, v1.y * rs, v1.z * rs, v1.w * rs};
+      return pack_bf16x8(f);
+    } else {
+      return pack_f32x4(v0.x * rs, v0.y * rs, v0.z * rs, v0.w * rs);
+    }
+  };
   u32x4 new_k = {0u, 0u, 0u, 0u}, new_v = {0u, 0u, 0u, 0u};
   if constexpr (APPEND) {
     // this step's K/V row: folded in below from registers, persisted for the later steps
-    new_k = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride +
-                                            h * D + sub * KPL);
-    new_v = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride +
-                                            h * D + sub * KPL);
+    if constexpr (QF32) {
+      new_k = scaled_chunk(static_cast<const float*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * KPL);
+      new_v = scaled_chunk(static_cast<const float*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * KPL);
+    } else {
+      new_k = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride +
+                                              h * D + sub * KPL);
+      new_v = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride +
+                                              h * D + sub * KPL);
+    }
     if (tid < LPK) {
       const size_t at = ((static_cast<size_t>(b) * a.H + h) * a.cap + pos) * D + sub * KPL;
       *reinterpret_cast<u32x4*>(static_cast<CT*>(a.kcache) + at) = new_k;
@@ -434,17 +454,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
 
   u32x4 qc;
   if constexpr (QF32) {
-    // the query as unnormalised f32 + the partial sums of squares of its residual row: 1/rms here
-    const float* qp = a.q_f32 + static_cast<size_t>(b) * a.q_stride + h * D + sub * KPL;
-    const float4 q0 = *reinterpret_cast<const float4*>(qp);
-    const float rs = row_rs_from_partials(a.q_ss + static_cast<size_t>(b) * a.q_ss_n, a.q_ss_n, lane);
-    if constexpr (KPL == 8) {
-      const float4 q1 = *reinterpret_cast<const float4*>(qp + 4);
-      const float f[8] = {q0.x * rs, q0.y * rs, q0.z * rs, q0.w * rs, q1.x * rs, q1.y * rs, q1.z * rs, q1.w * rs};
-      qc = pack_bf16x8(f);
-    } else {
-      qc = pack_f32x4(q0.x * rs, q0.y * rs, q0.z * rs, q0.w * rs);
-    }
+    qc = scaled_chunk(a.q_f32 + static_cast<size_t>(b) * a.q_stride + h * D + sub * KPL);
   } else {
     qc = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.q) + static_cast<size_t>(b) * a.q_stride + h * D +
                                          sub * KPL);
@@ -683,12 +693,23 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
   }
   float nk[EPL], nv[EPL];
   if constexpr (APPEND) {
-    const __bf16* kp = static_cast<const __bf16*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
-    const __bf16* vp = static_cast<const __bf16*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
-    unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(kp), nk);
-    unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(kp + 8), nk + 8);
-    unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(vp), nv);
-    unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(vp + 8), nv + 8);
+    if (a.q_f32) {   // (wave-uniform) the new row as unnormalised f32 products too: scale, round to bf16 as the GEMM would
+      const float* kp = static_cast<const float*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
+      const float* vp = static_cast<const float*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
+      const float rs1 = row_rs_from_partials(a.q_ss + static_cast<size_t>(b) * a.q_ss_n, a.q_ss_n, lane);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        nk[j] = static_cast<float>(static_cast<__bf16>(kp[j] * rs1));
+        nv[j] = static_cast<float>(static_cast<__bf16>(vp[j] * rs1));
+      }
+    } else {
+      const __bf16* kp = static_cast<const __bf16*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
+      const __bf16* vp = static_cast<const __bf16*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
+      unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(kp), nk);
+      unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(kp + 8), nk + 8);
+      unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(vp), nv);
+      unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(vp + 8), nv + 8);
+    }
     float ks, vs;
     const u32x4 kq = fp8_quantize_quad(nk, &ks), vq = fp8_quantize_quad(nv, &vs);     // nk / nv now dequantised
     if (tid < LPK) {
@@ -846,9 +867,9 @@ int launch_kv_quantize_fp8(const void* src_bf16, void* dst_fp8, void* scales, in
 int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
   if ((!a.q && !a.q_f32) || !a.kcache || !a.vcache || !a.out || a.B <= 0 || a.H <= 0 || a.cap <= 0)
     return mt3::fail(MT3_ERR_INVALID, "decode_attention: bad arguments");
-  if (a.q_f32 && (a.new_k || !a.q_ss || a.q_ss_n <= 0 || a.q_ss_n > 64 || (a.q_ss_n & 3)))
-    return mt3::fail(MT3_ERR_INVALID, "decode_attention: the unnormalised f32 query form is the cross-attention's "
-                                      "(no append), with the row's partial sums of squares");
+  if (a.q_f32 && (!a.q_ss || a.q_ss_n <= 0 || a.q_ss_n > 64 || (a.q_ss_n & 3)))
+    return mt3::fail(MT3_ERR_INVALID, "decode_attention: the unnormalised f32 query form needs the row's partial sums "
+                                      "of squares (4 .. 64 of them, a multiple of 4)");
   if (!a.step && (a.n_keys <= 0 || a.n_keys > a.cap)) return mt3::fail(MT3_ERR_INVALID, "decode_attention: n_keys");
   const bool append = a.new_k != nullptr;
   if (append && !a.new_v) return mt3::fail(MT3_ERR_INVALID, "decode_attention: new_k without new_v");
@@ -883,17 +904,21 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
     else if (nw == 3) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 3>), grid, block, 0, s, a);     \
     else hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 4>), grid, block, 0, s, a);                  \
   } while (0)
+#define MT3_LAUNCH_DEC_Q(CT, AP)                                                                        \
+  do {                                                                                                  \
+    if (nw == 2) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 2, true>), grid, block, 0, s, a);          \
+    else if (nw == 3) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 3, true>), grid, block, 0, s, a);     \
+    else hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 4, true>), grid, block, 0, s, a);                  \
+  } while (0)
   if (dtype == MT3_BF16 && a.q_f32) {
-    if (nw == 2) hipLaunchKernelGGL((dec_attn_kernel<__bf16, false, 2, true>), grid, block, 0, s, a);
-    else if (nw == 3) hipLaunchKernelGGL((dec_attn_kernel<__bf16, false, 3, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((dec_attn_kernel<__bf16, false, 4, true>), grid, block, 0, s, a);
+    if (append) MT3_LAUNCH_DEC_Q(__bf16, true);
+    else MT3_LAUNCH_DEC_Q(__bf16, false);
   } else if (dtype == MT3_BF16) {
     if (append) MT3_LAUNCH_DEC(__bf16, true);
     else MT3_LAUNCH_DEC(__bf16, false);
   } else if (dtype == MT3_F32 && a.q_f32) {
-    if (nw == 2) hipLaunchKernelGGL((dec_attn_kernel<float, false, 2, true>), grid, block, 0, s, a);
-    else if (nw == 3) hipLaunchKernelGGL((dec_attn_kernel<float, false, 3, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((dec_attn_kernel<float, false, 4, true>), grid, block, 0, s, a);
+    if (append) MT3_LAUNCH_DEC_Q(float, true);
+    else MT3_LAUNCH_DEC_Q(float, false);
   } else if (dtype == MT3_F32) {
     if (append) MT3_LAUNCH_DEC(float, true);
     else MT3_LAUNCH_DEC(float, false);
@@ -901,6 +926,7 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
     return mt3::fail(MT3_ERR_INVALID, "decode_attention: unknown dtype");
   }
 #undef MT3_LAUNCH_DEC
+#undef MT3_LAUNCH_DEC_Q
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

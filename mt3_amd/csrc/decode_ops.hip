@@ -108,10 +108,21 @@ int launch_residual_split(const float* x, void* x_ct, float* x_ss, int rows, int
   return MT3_OK;
 }
 
+// q_out[b] = ew[tok] + pw[t]: the first decoder layer's unnormalised q | k | v | cross-q of the row (RowProj)
+__device__ __forceinline__ void put_row_projection(const RowProj& rp, int b, int tok, int t, int tid, int nthreads) {
+  const float* e = rp.ew + static_cast<size_t>(tok) * rp.q_n;
+  const float* p = rp.pw + static_cast<size_t>(t) * rp.q_n;
+  float* o = rp.q_out + static_cast<size_t>(b) * rp.q_n;
+  for (int i = tid * 4; i < rp.q_n; i += nthreads * 4) {
+    const float4 a = *reinterpret_cast<const float4*>(e + i), c = *reinterpret_cast<const float4*>(p + i);
+    *reinterpret_cast<float4*>(o + i) = make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w);
+  }
+}
+
 __global__ __launch_bounds__(128) void embed_kernel(const float* __restrict__ table, const float* __restrict__ pos,
                                                      const int* __restrict__ tok, const int* __restrict__ step,
                                                      float* __restrict__ y, void* __restrict__ y_ct,
-                                                     float* __restrict__ y_ss, int dim) {
+                                                     float* __restrict__ y_ss, int dim, RowProj rp) {
   const int b = blockIdx.x;
   const float* e = table + static_cast<size_t>(tok[b]) * dim;
   const float* p = pos + static_cast<size_t>(step[b]) * dim;
@@ -119,12 +130,14 @@ __global__ __launch_bounds__(128) void embed_kernel(const float* __restrict__ ta
     const float4 a = *reinterpret_cast<const float4*>(e + i), c = *reinterpret_cast<const float4*>(p + i);
     put_row_piece(make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w), y, y_ct, y_ss, b, dim, i);
   }
+  if (rp.q_out) put_row_projection(rp, b, tok[b], step[b], threadIdx.x, 128);
 }
 
 int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, void* y_ct,
-                 float* y_ss, int B, int dim, hipStream_t s) {
+                 float* y_ss, int B, int dim, const RowProj& rp, hipStream_t s) {
   if ((y_ct || y_ss) && (!y_ss || dim % 16)) return mt3::fail(MT3_ERR_INVALID, "embed: the split form needs y_ss and dim % 16 == 0");
-  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(128), 0, s, table, pos, tok, step, y, y_ct, y_ss, dim);
+  if (rp.q_out && (!rp.ew || !rp.pw || rp.q_n % 4)) return mt3::fail(MT3_ERR_INVALID, "embed: row projection tables missing");
+  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(128), 0, s, table, pos, tok, step, y, y_ct, y_ss, dim, rp);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }
@@ -168,7 +181,8 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
                                                            float* __restrict__ y_ss, int dim,
                                                            float* __restrict__ beam_f, int* __restrict__ beam_len,
                                                            const float* __restrict__ beam_cfg, int beam_rows,
-                                                           const int* __restrict__ forced, int forced_stride) {
+                                                           const int* __restrict__ forced, int forced_stride,
+                                                           RowProj rp) {
   __shared__ float s_v[8], s_sum[4];
   __shared__ int s_i[8];
   __shared__ int s_tok, s_t;
@@ -278,22 +292,25 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
       const float4 a = *reinterpret_cast<const float4*>(e + i), c = *reinterpret_cast<const float4*>(p + i);
       put_row_piece(make_float4(a.x + c.x, a.y + c.y, a.z + c.z, a.w + c.w), y_next, y_ct, y_ss, b, dim, i);
     }
+    if (rp.q_out) put_row_projection(rp, b, s_tok, tp, tid, 256);
   }
 }
 
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
                        float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam,
-                       const int* forced, int forced_stride, hipStream_t s) {
+                       const int* forced, int forced_stride, const RowProj& rp, hipStream_t s) {
   if (beam && forced) return mt3::fail(MT3_ERR_INVALID, "argmax_step: teacher forcing is a greedy-path feature");
+  if (rp.q_out && (!y_next || !rp.ew || !rp.pw || rp.q_n % 4))
+    return mt3::fail(MT3_ERR_INVALID, "argmax_step: row projection needs the next-row output and its tables");
   if (beam)
     hipLaunchKernelGGL(argmax_step_kernel<true>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
                        done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, beam->f, beam->len,
-                       beam->cfg, beam->rows, nullptr, 0);
+                       beam->cfg, beam->rows, nullptr, 0, rp);
   else
     hipLaunchKernelGGL(argmax_step_kernel<false>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
                        done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, nullptr, nullptr, nullptr, 0,
-                       forced, forced_stride);
+                       forced, forced_stride, rp);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

@@ -67,6 +67,9 @@ struct LayerDev {
   // q-fold (bf16 decode): the cross-attention q-projection rides in the two neighbouring launches
   void* wqkv_ext = nullptr;  // decoder [3HD + HD][emb]: wqkv rows, then the cross query rows (pre_cross norm scale folded)
   void* wo_ext = nullptr;    // decoder [emb + HD][HD]: self out-projection rows, then (Wo . (s2 * Wq_x))^T
+  // qkv-fold (round 3): the NEXT layer's q | k | v | cross-q projections ride in this layer's MLP out-projection launch
+  void* w_fold = nullptr;    // decoder [emb + 4HD][mlp + emb]: rows < emb = [Wo_mlp^T | 0]; rows >= emb =
+                             // [(Wo_mlp . Wext)^T | Wext^T] with Wext = the next layer's scaled [q | k | v | cross-q]
   void* wi = nullptr;        // [2*mlp][emb] interleaved gate/linear
   void* wo_mlp = nullptr;    // [emb][mlp]
   void* self_k = nullptr;    // decoder [Bm][H][L][64]
@@ -130,6 +133,19 @@ struct mt3_engine {
   // RESID epilogue leaves anyway: 8 launches per step fewer
   float* qf = nullptr;           // [max_batch][HD] f32, unnormalised cross-attention query
   bool q_fold = false;
+  // qkv-fold: y_in(l+1) . W = y2(l) . W + h(l) . (Wo_mlp . W) by the same linearity, W = the next layer's
+  // [q | k | v | cross-q]: a two-source K = mlp + emb product that rides as 4HD extra output columns in layer l's MLP
+  // out-projection launch (kEpiResidS); layer 0's row comes from two table rows (embedding . W, position table . W)
+  // written by the kernel that creates the decoder input row.  The self-attention kernel applies 1/rms and rounds
+  // q / k / v itself.  8 more launches per step gone.
+  bool qkv_fold = false;
+  float* qkvf = nullptr;         // [max_batch][4HD] f32 unnormalised q | k | v | cross-q of the current layer's input row
+  float* ew0 = nullptr;          // [vocab][4HD] f32: embedding . Wext(layer 0)
+  float* pw0 = nullptr;          // [kMaxPos][4HD] f32: position table . Wext(layer 0)
+  // the two-source launch reads the compute-type residual rows as an operand while its RESID tiles replace them: the
+  // rows alternate between two buffers from layer to layer (bf16: the bf16 copy; f32: the f32 rows themselves)
+  void* y_ct_alt = nullptr;
+  float* y_alt = nullptr;
   void* qkv_d = nullptr;
   void* attn_d = nullptr;
   void* q_d = nullptr;
@@ -297,6 +313,89 @@ int build_q_fold(mt3_engine* e, const std::string& P, const float* s1, const flo
   return upload_ct(e, u, &L->wo_ext);
 }
 
+mt3k::GemmArgs gemm_args(const void* A, const void* Wt, void* out, int M, int N, int K, int ldo);
+const float* scale_of(mt3_engine* e, const std::string& name);
+
+// qkv-fold matrices and tables (see mt3_engine::qkv_fold).  The matrix products (Wo_mlp . Wext per layer: 0.8 GFLOP;
+// embedding / position table . Wext of layer 0) run on the device with the engine's own f32 GEMM (exact f32 products,
+// f32 accumulation: ~1e-6 of an entry, far below what the operand formats keep) instead of seconds of host loops.
+int build_qkv_fold(mt3_engine* e) {
+  const mt3_engine_config& c = e->cfg;
+  const int emb = c.emb_dim, hd = e->HD(), mlp = c.mlp_dim, n4 = 4 * hd, nl = c.num_decoder_layers;
+  // Wext^T of layer l: output-major [4HD][emb] = scaled q | k | v of the self-attention, scaled cross-attention query
+  auto wext_t = [&](int l, std::vector<float>* t) -> int {
+    const std::string P = "decoder/layers_" + std::to_string(l);
+    const float* s1 = scale_of(e, P + "/pre_self_attention_layer_norm/scale");
+    const float* s2 = scale_of(e, P + "/pre_cross_attention_layer_norm/scale");
+    const HostWeight *q = find(e, P + "/self_attention/query/kernel", emb, hd),
+                     *k = find(e, P + "/self_attention/key/kernel", emb, hd),
+                     *v = find(e, P + "/self_attention/value/kernel", emb, hd),
+                     *qx = find(e, P + "/encoder_decoder_attention/query/kernel", emb, hd);
+    if (!s1 || !s2 || !q || !k || !v || !qx) return MT3_ERR_MISSING;
+    t->assign(static_cast<size_t>(n4) * emb, 0.f);
+    put_transposed(*t, emb, 0, *q, s1);
+    put_transposed(*t, emb, hd, *k, s1);
+    put_transposed(*t, emb, 2 * hd, *v, s1);
+    put_transposed(*t, emb, 3 * hd, *qx, s2);
+    return MT3_OK;
+  };
+  float *d_wext = nullptr, *d_wo = nullptr, *d_prod = nullptr;
+  auto cleanup = [&]() {
+    if (d_wext) (void)hipFree(d_wext);
+    if (d_wo) (void)hipFree(d_wo);
+    if (d_prod) (void)hipFree(d_prod);
+  };
+  int rc = MT3_OK;
+  hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_wext), static_cast<size_t>(n4) * emb * 4);
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_wo), static_cast<size_t>(mlp) * emb * 4);
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_prod), static_cast<size_t>(n4) * mlp * 4);
+  std::vector<float> wt, prod(static_cast<size_t>(n4) * mlp), w;
+  for (int l = 0; l + 1 < nl && he == hipSuccess && rc == MT3_OK; ++l) {
+    const HostWeight* wo = find(e, "decoder/layers_" + std::to_string(l) + "/mlp/wo/kernel", mlp, emb);
+    if (!wo) rc = MT3_ERR_MISSING;
+    if (rc == MT3_OK) rc = wext_t(l + 1, &wt);
+    if (rc != MT3_OK) break;
+    he = hipMemcpy(d_wext, wt.data(), wt.size() * 4, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(d_wo, wo->data.data(), wo->data.size() * 4, hipMemcpyHostToDevice);
+    if (he != hipSuccess) break;
+    // prod[n][k] = sum_e Wext^T[n][e] * Wo_mlp[k][e]: "A" = Wext^T rows, "Wt" = Wo_mlp rows (K = emb for both)
+    mt3k::GemmArgs g = gemm_args(d_wext, d_wo, d_prod, n4, mlp, emb, mlp);
+    rc = mt3k::launch_gemm(MT3_F32, g, false, 0, MT3_EPI_F32, false, nullptr);
+    if (rc != MT3_OK) break;
+    he = hipMemcpy(prod.data(), d_prod, prod.size() * 4, hipMemcpyDeviceToHost);
+    if (he != hipSuccess) break;
+    const size_t K = static_cast<size_t>(mlp) + emb;
+    w.assign((static_cast<size_t>(emb) + n4) * K, 0.f);
+    for (int k = 0; k < mlp; ++k)
+      for (int n = 0; n < emb; ++n) w[static_cast<size_t>(n) * K + k] = wo->data[static_cast<size_t>(k) * emb + n];
+    for (int n = 0; n < n4; ++n) {
+      float* row = w.data() + (static_cast<size_t>(emb) + n) * K;
+      std::memcpy(row, prod.data() + static_cast<size_t>(n) * mlp, static_cast<size_t>(mlp) * 4);
+      std::memcpy(row + mlp, wt.data() + static_cast<size_t>(n) * emb, static_cast<size_t>(emb) * 4);
+    }
+    rc = upload_ct(e, w, &e->dec[l].w_fold);
+  }
+  // layer 0: its input row is Embed(tok) + FixedEmbed[t], so its projection is the sum of two table rows
+  if (he == hipSuccess && rc == MT3_OK) rc = wext_t(0, &wt);
+  if (he == hipSuccess && rc == MT3_OK) {
+    he = hipMemcpy(d_wext, wt.data(), wt.size() * 4, hipMemcpyHostToDevice);
+    if (he == hipSuccess) rc = dmalloc(e, reinterpret_cast<void**>(&e->ew0), static_cast<size_t>(c.vocab_size) * n4 * 4);
+    if (he == hipSuccess && rc == MT3_OK)
+      rc = dmalloc(e, reinterpret_cast<void**>(&e->pw0), static_cast<size_t>(kMaxPos) * n4 * 4);
+    if (he == hipSuccess && rc == MT3_OK)
+      rc = mt3k::launch_gemm(MT3_F32, gemm_args(e->embedding, d_wext, e->ew0, c.vocab_size, n4, emb, n4), false, 0,
+                             MT3_EPI_F32, false, nullptr);
+    if (he == hipSuccess && rc == MT3_OK)
+      rc = mt3k::launch_gemm(MT3_F32, gemm_args(e->pos_table, d_wext, e->pw0, kMaxPos, n4, emb, n4), false, 0,
+                             MT3_EPI_F32, false, nullptr);
+    if (he == hipSuccess && rc == MT3_OK) he = hipDeviceSynchronize();
+  }
+  cleanup();
+  if (rc != MT3_OK) return rc;
+  if (he != hipSuccess) return mt3::fail(MT3_ERR_HIP, std::string("qkv-fold tables: ") + hipGetErrorString(he));
+  return MT3_OK;
+}
+
 int build_mlp(mt3_engine* e, const std::string& prefix, const float* scale, LayerDev* L, bool encoder = false) {
   const int emb = e->cfg.emb_dim, mlp = e->cfg.mlp_dim;
   const HostWeight *w0 = find(e, prefix + "/wi_0/kernel", emb, mlp), *w1 = find(e, prefix + "/wi_1/kernel", emb, mlp),
@@ -368,14 +467,29 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   const int Lmax = c.max_decode_len;
   const size_t es = e->esize, kes = e->kv_esize;
   const bool small = true;
+  const int nl = c.num_decoder_layers;
+  const bool split = e->y_split, fold = e->qkv_fold;
+  // Which of the two residual buffers is current (qkv-fold only: the two-source launch at the end of layer l reads the
+  // rows it replaces, so the rows move to the other buffer there): layer l works on buffer l & 1; the logits and the
+  // arg-max read the last layer's, the arg-max writes the next step's input row into buffer 0.
+  const int layer = op < 8 * nl ? (op >> 3) : nl - 1;
+  const int cur = fold ? (layer & 1) : 0;
+  const bool f32 = dt == MT3_F32;
+  auto y_buf = [&](int which) -> float* {            // f32 residual rows
+    return ((fold && f32 && which) ? e->y_alt : e->y) + static_cast<size_t>(row0) * emb;
+  };
+  auto yct_buf = [&](int which) -> char* {           // compute-type rows the norm-fused GEMMs read (f32: the rows themselves)
+    if (!split) return nullptr;
+    if (f32) return reinterpret_cast<char*>(y_buf(which));
+    return static_cast<char*>((fold && which) ? e->y_ct_alt : e->y_ct) + static_cast<size_t>(row0) * emb * es;
+  };
   // the decoder input row of this step (Embed(tok) + FixedEmbed[t]) is already in `y`: written by the
   // embed launch before the first step and by the previous step's argmax kernel afterwards
-  float* y = e->y + static_cast<size_t>(row0) * emb;
-  // residual rows as the norm-fused GEMMs see them: f32 with in-kernel statistics, or (bf16 path) the
-  // compute-type copy with the producer's partial sums
-  const bool split = e->y_split;
-  char* y_ct = split ? static_cast<char*>(e->y_ct) + static_cast<size_t>(row0) * emb * es : nullptr;   // f32: == y
-  char* y_copy = split && dt == MT3_BF16 ? y_ct : nullptr;       // where producers of a residual row leave its bf16 copy
+  float* y = y_buf(cur);
+  // residual rows as the norm-fused GEMMs see them: f32 with in-kernel statistics, or (split form) the
+  // compute-type rows with the producer's partial sums
+  char* y_ct = yct_buf(cur);
+  char* y_copy = split && !f32 ? y_ct : nullptr;     // where producers of a residual row leave its bf16 copy
   float* y_ss = split ? e->y_ss + static_cast<size_t>(row0) * (emb / 16) : nullptr;
   auto normed = [&](const void* Wt, void* out, int N, int ldo) {
     mt3k::GemmArgs g = gemm_args(split ? static_cast<const void*>(y_ct) : static_cast<const void*>(y), Wt, out, rows, N,
@@ -394,22 +508,25 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   char* attn_d = static_cast<char*>(e->attn_d) + static_cast<size_t>(row0) * hd * es;
   char* q_d = static_cast<char*>(e->q_d) + static_cast<size_t>(row0) * hd * es;
   char* h_d = static_cast<char*>(e->h_d) + static_cast<size_t>(row0) * c.mlp_dim * es;
+  float* qkvf = fold ? e->qkvf + static_cast<size_t>(row0) * 4 * hd : nullptr;
   float* logits = e->logits + static_cast<size_t>(row0) * c.vocab_size;
   int* step = e->step + row0;                    // per-row position counters
-  const int nl = c.num_decoder_layers;
   if (op == 8 * nl)
     return mt3k::launch_gemm(dt, normed(e->logits_w, logits, c.vocab_size, c.vocab_size), !split, nrm, MT3_EPI_F32,
                              small, s);
   if (op == 8 * nl + 1) {
     const mt3k::BeamState beam{e->beam_f + row0, e->beam_len + row0, e->beam_cfg, c.max_batch};
+    const mt3k::RowProj rp{e->ew0, e->pw0, qkvf, 4 * hd};
     return mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
                                     e->cur_tok + row0, e->done + row0, e->n_done, step, e->embedding, e->pos_table,
-                                    kMaxPos, y, y_copy, y_ss, emb, rows, (skip & 4) ? &beam : nullptr,
-                                    (skip & 8) ? e->forced + static_cast<size_t>(row0) * Lmax : nullptr, Lmax, s);
+                                    kMaxPos, y_buf(0), split && !f32 ? yct_buf(0) : nullptr, y_ss, emb, rows,
+                                    (skip & 4) ? &beam : nullptr,
+                                    (skip & 8) ? e->forced + static_cast<size_t>(row0) * Lmax : nullptr, Lmax, rp, s);
   }
   LayerDev& L = e->dec[op >> 3];
   switch (op & 7) {
     case 0:
+      if (fold) return MT3_OK;                // rode in the previous layer's MLP out-projection launch / the row's producer
       if (e->q_fold) {
         mt3k::GemmArgs g = normed(L.wqkv_ext, qkv_d, 4 * hd, 3 * hd);
         g.out2 = e->qf + static_cast<size_t>(row0) * hd;
@@ -429,6 +546,15 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
       a.new_k = qkv_d + static_cast<size_t>(hd) * es;
       a.new_v = qkv_d + static_cast<size_t>(2 * hd) * es;
       a.kv_stride = 3 * hd;
+      if (fold) {                             // unnormalised f32 q | k | v + the input row's partial sums of squares
+        a.q = nullptr;
+        a.q_f32 = qkvf;
+        a.q_stride = a.kv_stride = 4 * hd;
+        a.new_k = qkvf + hd;
+        a.new_v = qkvf + 2 * hd;
+        a.q_ss = y_ss;
+        a.q_ss_n = emb / 16;
+      }
       a.step = step;
       a.out = attn_d;
       a.B = rows;
@@ -439,7 +565,8 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
       if (e->q_fold) {
         mt3k::GemmArgs g = resid(attn_d, L.wo_ext, hd);
         g.N = emb + hd;
-        g.out2 = e->qf + static_cast<size_t>(row0) * hd;
+        g.out2 = fold ? qkvf + 3 * hd : e->qf + static_cast<size_t>(row0) * hd;
+        g.ld2 = fold ? 4 * hd : 0;
         g.n_split = emb;
         return mt3k::launch_gemm(dt, g, false, 0, mt3k::kEpiResidQ, small, s);
       }
@@ -453,7 +580,8 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
       x.q = q_d;
       x.q_stride = hd;
       if (e->q_fold) {
-        x.q_f32 = e->qf + static_cast<size_t>(row0) * hd;
+        x.q_f32 = fold ? qkvf + 3 * hd : e->qf + static_cast<size_t>(row0) * hd;
+        if (fold) x.q_stride = 4 * hd;
         x.q_ss = y_ss;
         x.q_ss_n = emb / 16;
       }
@@ -472,6 +600,22 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     case 6:
       return mt3k::launch_gemm(dt, normed(L.wi, h_d, 2 * c.mlp_dim, c.mlp_dim), !split, nrm, MT3_EPI_GEGLU, small, s);
     default:
+      if (fold && (op >> 3) + 1 < nl) {
+        // MLP out-projection + residual, and -- as 4HD extra output columns with a two-source K = mlp + emb -- the NEXT
+        // layer's unnormalised q | k | v | cross-q.  The residual rows move to the other buffer (see `cur`).
+        mt3k::GemmArgs g = gemm_args(h_d, L.w_fold, y_buf(cur ^ 1), rows, emb + 4 * hd, c.mlp_dim + emb, emb);
+        g.lda = c.mlp_dim;
+        g.resid_src = y;
+        g.out_ct = f32 ? nullptr : yct_buf(cur ^ 1);
+        g.out_ss = y_ss;
+        g.out2 = qkvf;
+        g.ld2 = 4 * hd;
+        g.n_split = emb;
+        g.A2 = y_ct;
+        g.lda2 = emb;
+        g.k_split = c.mlp_dim;
+        return mt3k::launch_gemm(dt, g, false, 0, mt3k::kEpiResidS, small, s);
+      }
       return mt3k::launch_gemm(dt, resid(h_d, L.wo_mlp, c.mlp_dim), false, 0, MT3_EPI_RESID, small, s);
   }
 }
@@ -584,7 +728,8 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: dense_dtype must be 0 (= compute dtype) or MT3_FP8_E4M3");
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
-  if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM))
+  if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM |
+                       MT3_OPT_SEPARATE_QKV_PROJECTION))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -718,6 +863,9 @@ int mt3_engine_finalize(mt3_engine* e) {
       }
     if ((rc = upload_f32(e, pe, &e->pos_table))) return rc;
   }
+  // ---- qkv-fold (needs the embedding and the position table on the device, and the raw weights still on the host)
+  e->qkv_fold = q_fold && !(c.options & MT3_OPT_SEPARATE_QKV_PROJECTION) && emb % 512 == 0 && c.mlp_dim % 512 == 0;
+  if (e->qkv_fold && (rc = build_qkv_fold(e))) return rc;
   // ---- workspaces
   const size_t M = static_cast<size_t>(Bm) * T;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->x), M * emb * 4))) return rc;
@@ -756,7 +904,16 @@ int mt3_engine_finalize(mt3_engine* e) {
     if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y_ss), static_cast<size_t>(Bm) * (emb / 16) * 4))) return rc;
   }
   if (e->q_fold && !e->y_split) e->q_fold = false;
+  if (!e->q_fold) e->qkv_fold = false;
   if (e->q_fold && (rc = dmalloc(e, reinterpret_cast<void**>(&e->qf), static_cast<size_t>(Bm) * hd * 4))) return rc;
+  if (e->qkv_fold) {
+    if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->qkvf), static_cast<size_t>(Bm) * 4 * hd * 4))) return rc;
+    if (c.compute_dtype == MT3_BF16) {
+      if ((rc = dmalloc(e, &e->y_ct_alt, static_cast<size_t>(Bm) * emb * 2))) return rc;
+    } else if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->y_alt), static_cast<size_t>(Bm) * emb * 4))) {
+      return rc;
+    }
+  }
   if ((rc = dmalloc(e, &e->qkv_d, static_cast<size_t>(Bm) * 3 * hd * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->attn_d, static_cast<size_t>(Bm) * hd * e->esize))) return rc;
   if ((rc = dmalloc(e, &e->q_d, static_cast<size_t>(Bm) * hd * e->esize))) return rc;
@@ -921,8 +1078,11 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
   if (d_forced)    // engine-owned copy: the step graph holds ITS address, whatever buffer the caller passes
     MT3_HIP_CHECK(hipMemcpyAsync(e->forced, d_forced, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
   // decoder input of step 0: Embed(BOS) + FixedEmbed[0]; later steps get theirs from the argmax kernel
-  MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y,
-                             c.compute_dtype == MT3_BF16 ? e->y_ct : nullptr, e->y_ss, batch, c.emb_dim, s));
+  {
+    const mt3k::RowProj rp{e->ew0, e->pw0, e->qkv_fold ? e->qkvf : nullptr, 4 * e->HD()};
+    MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y,
+                               c.compute_dtype == MT3_BF16 ? e->y_ct : nullptr, e->y_ss, batch, c.emb_dim, rp, s));
+  }
 
   // step-graph variant: bits 1 / 2 = mt3_debug_engine_decode's skipped kernels (mt3_hip_debug.h; never set by the
   // product entry points), 4 = beam-1 selection, 8 = teacher forcing
@@ -1012,6 +1172,7 @@ int mt3_engine_status(const mt3_engine* e, int32_t what) {
     case MT3_STATUS_KV_FP8: return e->kv_fp8 ? 1 : 0;
     case MT3_STATUS_DENSE_FP8: return e->dense_fp8 ? 1 : 0;
     case MT3_STATUS_Q_FOLD: return e->q_fold ? 1 : 0;
+    case MT3_STATUS_QKV_FOLD: return e->qkv_fold ? 1 : 0;
     default: return mt3::fail(MT3_ERR_INVALID, "mt3_engine_status: unknown item");
   }
 }

@@ -74,15 +74,23 @@ __device__ __forceinline__ void tile_chunk(int tid, int p, int* row, int* chunk)
 template <typename CT, bool A_F32, bool NORM, int A_PASSES, int B_PASSES, int CPR, int NT>
 __device__ __forceinline__ void gemm_load_tiles(u32x4 (&a_reg)[A_PASSES], u32x4 (&b_reg)[B_PASSES],
                                                 float (&ss)[A_PASSES], const void* gA, const void* gW, int m0,
-                                                int n0, int tid, int gM, int gLda, int gK, int k0) {
+                                                int n0, int tid, int gM, int gLda, int gK, int k0,
+                                                const void* gA2 = nullptr, int gLda2 = 0, int k1 = 0) {
   constexpr int KPL = CTraits<CT>::KPL;
+  // two-source rows (kEpiResidS): weight columns [k1, K) multiply the rows of A2 (slice-uniform)
+  int ka = k0;
+  if (gA2 != nullptr && k0 >= k1) {
+    gA = gA2;
+    gLda = gLda2;
+    ka = k0 - k1;
+  }
 #pragma unroll
   for (int p = 0; p < A_PASSES; ++p) {
     int ld_row, ld_chunk;
     tile_chunk<CPR, NT>(tid, p, &ld_row, &ld_chunk);
     int row = m0 + ld_row;
     row = row < gM ? row : gM - 1;                       // clamp: out-of-range rows are never stored
-    const size_t e = static_cast<size_t>(row) * gLda + k0 + ld_chunk * KPL;
+    const size_t e = static_cast<size_t>(row) * gLda + ka + ld_chunk * KPL;
     if constexpr (A_F32) {
       const float4* src = reinterpret_cast<const float4*>(static_cast<const float*>(gA) + e);
       if constexpr (KPL == 8) {
@@ -125,6 +133,7 @@ struct EpiCtx {
   float* out_ss;
   float* out2;              // *Q epilogues: f32 [M][ld2] for tile columns >= n_split
   int n_split, ld2;
+  const float* resid_src;   // RESID: old values of the f32 output region (== out unless the update is out of place)
 };
 
 // acc[i][j]: the wave's (wm, wn) sub-tile as FM x FN 16x16 C fragments of the workgroup tile at (m0, n0);
@@ -136,7 +145,7 @@ template <typename CT, int EPI_, int FM, int FN, bool PRE, typename RowRs>
 __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm, int wn, int lane, int m0, int n0,
                                               const EpiCtx& c, RowRs row_rs, const float (&pre)[FM][FN][4]) {
   const int frag_row = lane & 15, frag_g = lane >> 4;
-  if constexpr (EPI_ == kEpiStoreQ || EPI_ == kEpiResidQ) {
+  if constexpr (EPI_ == kEpiStoreQ || EPI_ == kEpiResidQ || EPI_ == kEpiResidS) {
     if (n0 >= c.n_split) {       // (tile-uniform) the second product: plain f32, no row scale
 #pragma unroll
       for (int i = 0; i < FM; ++i)
@@ -154,7 +163,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm
       return;
     }
   }
-  constexpr int EPI = EPI_ == kEpiStoreQ ? MT3_EPI_STORE : EPI_ == kEpiResidQ ? MT3_EPI_RESID : EPI_;
+  constexpr int EPI = EPI_ == kEpiStoreQ ? MT3_EPI_STORE : (EPI_ == kEpiResidQ || EPI_ == kEpiResidS) ? MT3_EPI_RESID : EPI_;
   // ---- epilogue: C fragment (i, j): rows (lane>>4)*4 + r, col lane & 15
   // 2-byte outputs are never stored one element at a time (a sub-dword store costs a read-modify-write in the
   // cache: the bf16 STORE epilogue of a decode GEMM took 2.5 us against 0.7 us for the f32 RESID one): lanes l
@@ -216,7 +225,7 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm
         for (int r = 0; r < 4; ++r) {
           const int row = m0 + lrow0 + r;
           const size_t at = static_cast<size_t>(row < c.M ? row : c.M - 1) * c.ldo + col;
-          vnew[r] = (PRE ? pre[i][j][r] : static_cast<float*>(c.out)[at]) + acc[i][j][r];
+          vnew[r] = (PRE ? pre[i][j][r] : c.resid_src[at]) + acc[i][j][r];
           if (row < c.M) static_cast<float*>(c.out)[at] = vnew[r];
         }
         if (c.out_ss) {
@@ -364,15 +373,23 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
       pv[u] = (scale_rows && u < (gK >> 6)) ? p4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   // decode-sized RESID tiles (bf16): this lane's elements of the residual rows, requested before anything else
-  constexpr bool kPre = (EPI == MT3_EPI_RESID || EPI == kEpiResidQ) && FM * FN <= 2;
+  constexpr bool kPre = (EPI == MT3_EPI_RESID || EPI == kEpiResidQ || EPI == kEpiResidS) && FM * FN <= 2;
+  constexpr bool kSplitEpi = EPI == kEpiStoreQ || EPI == kEpiResidQ || EPI == kEpiResidS;
+  const int ld2 = kSplitEpi ? (g.ld2 ? g.ld2 : gN - g.n_split) : 0;
+  const bool second = kSplitEpi && n0 >= g.n_split;        // (tile-uniform) this tile belongs to the second product
+  // kEpiResidS: second-product tiles run over the whole two-source K, the RESID tiles over its first k_split columns
+  const int kend = EPI == kEpiResidS ? (second ? gK : g.k_split) : gK;
+  const void* const gA2 = EPI == kEpiResidS && second ? g.A2 : nullptr;
+  const int gLda2 = g.lda2, k1 = g.k_split;
   float xpre[FM][FN][4];
-  if constexpr (kPre) if (wk == 0) {
-    const float* src = static_cast<const float*>(gO);
+  const float* const gResidSrc = g.resid_src ? g.resid_src : static_cast<const float*>(gO);
+  if constexpr (kPre) if (wk == 0 && !(EPI == kEpiResidS && second)) {
+    const float* src = gResidSrc;
     int ld = gLdo, c0 = n0;
     if constexpr (EPI == kEpiResidQ) {
-      if (n0 >= g.n_split) {             // (tile-uniform) the second product's f32 region
+      if (second) {                      // the second product's f32 region
         src = g.out2;
-        ld = gN - g.n_split;
+        ld = ld2;
         c0 = n0 - g.n_split;
       }
     }
@@ -401,11 +418,12 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
   const CT* a_base = &As[(wm * FM * 16 + frag_row) * ROWE + frag_g * KPL];
   const CT* b_base = &Bs[(wn * FN * 16 + frag_row) * ROWE + frag_g * KPL];
 
-  gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg[0], b_reg[0], ss, gA, gW, m0, n0, tid, gM, gLda, gK, 0);
+  gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg[0], b_reg[0], ss, gA, gW, m0, n0, tid, gM, gLda, gK, 0,
+                                                                gA2, gLda2, k1);
   if constexpr (PF == 2)
-    if (BK < gK)
+    if (BK < kend)
       gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg[1], b_reg[1], ss, gA, gW, m0, n0, tid, gM, gLda,
-                                                                    gK, BK);
+                                                                    gK, BK, gA2, gLda2, k1);
   if constexpr (!NORM) {
     if (scale_rows) {
       float t = 0.f;
@@ -433,9 +451,9 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
     }
     __syncthreads();
     MT3_PROF_MARK(2);
-    if (k0 + PF * BK < gK)              // a later slice in flight while the MFMAs below run
+    if (k0 + PF * BK < kend)            // a later slice in flight while the MFMAs below run
       gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg[SLOT], b_reg[SLOT], ss, gA, gW, m0, n0, tid, gM,
-                                                                    gLda, gK, k0 + PF * BK);
+                                                                    gLda, gK, k0 + PF * BK, gA2, gLda2, k1);
     constexpr int KSTEPS = BK / KG / WK;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
@@ -452,11 +470,11 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
     }
   };
   if constexpr (PF == 1) {
-    for (int k0 = 0; k0 < gK; k0 += BK) slice(std::integral_constant<int, 0>{}, k0);
+    for (int k0 = 0; k0 < kend; k0 += BK) slice(std::integral_constant<int, 0>{}, k0);
   } else {
-    for (int k0 = 0; k0 < gK; k0 += 2 * BK) {
+    for (int k0 = 0; k0 < kend; k0 += 2 * BK) {
       slice(std::integral_constant<int, 0>{}, k0);
-      if (k0 + BK < gK) slice(std::integral_constant<int, 1>{}, k0 + BK);
+      if (k0 + BK < kend) slice(std::integral_constant<int, 1>{}, k0 + BK);
     }
   }
   MT3_PROF_MARK(3);
@@ -513,8 +531,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
     return rsqrtf(t / static_cast<float>(gK) + 1e-6f);
   };
   MT3_PROF_MARK(5);
-  constexpr bool SPLIT = EPI == kEpiStoreQ || EPI == kEpiResidQ;
-  const EpiCtx ec{gO, gAux, gM, SPLIT ? g.n_split : gN, gLdo, gSeq, gOutCt, gOutSs, g.out2, g.n_split, gN - g.n_split};
+  const EpiCtx ec{gO, gAux, gM, kSplitEpi ? g.n_split : gN, gLdo, gSeq, gOutCt, gOutSs, g.out2, g.n_split, ld2, gResidSrc};
   gemm_epilogue<CT, EPI, FM, FN, kPre>(acc, wm, wn, lane, m0, n0, ec, row_rs, xpre);
   MT3_PROF_MARK(4);
 }
@@ -900,6 +917,9 @@ static int launch_typed(const GemmArgs& g, bool a_f32, int norm, int epi, bool s
       case kEpiResidQ:
         if (small) return launch_tile<CT, false, false, kEpiResidQ>(g, small, s);
         break;
+      case kEpiResidS:
+        if (small) return launch_tile<CT, false, false, kEpiResidS>(g, small, s);
+        break;
       case MT3_EPI_HEADS: return launch_tile<CT, false, false, MT3_EPI_HEADS>(g, small, s);
       case MT3_EPI_STORE: return launch_tile<CT, false, false, MT3_EPI_STORE>(g, small, s);
       case MT3_EPI_F32: return launch_tile<CT, false, false, MT3_EPI_F32>(g, small, s);
@@ -913,8 +933,11 @@ int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, int norm, int epi, boo
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A || !g.Wt || !g.out)
     return mt3::fail(MT3_ERR_INVALID, "gemm: bad shape or null pointer");
   if (epi == MT3_EPI_POS && (!g.aux || g.seq_len <= 0)) return mt3::fail(MT3_ERR_INVALID, "gemm: POS needs aux/seq_len");
-  if ((epi == kEpiStoreQ || epi == kEpiResidQ) && (!g.out2 || g.n_split <= 0 || g.n_split >= g.N || g.n_split % 64))
+  if ((epi == kEpiStoreQ || epi == kEpiResidQ || epi == kEpiResidS) &&
+      (!g.out2 || g.n_split <= 0 || g.n_split >= g.N || g.n_split % 64))
     return mt3::fail(MT3_ERR_INVALID, "gemm: split epilogue needs out2 and 0 < n_split < N, n_split a multiple of 64");
+  if (epi == kEpiResidS && (!g.A2 || g.k_split <= 0 || g.k_split >= g.K || g.k_split % 512 || (g.K - g.k_split) % 512))
+    return mt3::fail(MT3_ERR_INVALID, "gemm: the two-source epilogue needs A2 and slice-aligned 0 < k_split < K");
   if (epi == MT3_EPI_HEADS && (g.seq_len <= 0 || g.M % g.seq_len != 0 || g.N % 128 != 0))
     return mt3::fail(MT3_ERR_INVALID, "gemm: HEADS needs M = B*T and N = 2*H*64");
   if (dtype == MT3_BF16 && !small && glds_eligible(g, a_f32, norm, epi)) {

@@ -28,12 +28,23 @@ struct GemmArgs {
   // out2 (f32 [M][N - n_split], unscaled; ResidQ accumulates into it), columns [0, n_split) take the STORE / RESID path
   float* out2;
   int n_split;
+  int ld2;            // row stride of out2 in floats (0: N - n_split)
+  // kEpiResidS: the tiles past n_split multiply a TWO-SOURCE row [A (K = k_split columns) | A2 (K - k_split columns)]
+  // with their K-wide weight rows and STORE the product to out2; the tiles before n_split are a plain RESID over
+  // the first k_split columns of their weight rows (the rest of those rows is never read)
+  const void* A2;     // [M, lda2] compute type
+  int lda2;
+  int k_split;
+  // RESID family: where the OLD value of the f32 output region is read from (nullptr: `out` itself, the update in
+  // place).  The two-source launch of the f32 engine reads the rows it updates as an operand of its other tiles, so
+  // there the update goes out of place
+  const float* resid_src;
   // tile -> XCD dealing: 0 = an XCD owns a run of row blocks (all weight columns pass through its L2), 1 = an XCD
   // owns a run of weight-column tiles for ALL row blocks (its L2 sees 1/8 of the weights; set by launch_gemm)
   int n_major;
 };
 // internal epilogues (not part of the C ABI): STORE / RESID with a second f32 output region, see GemmArgs::out2
-constexpr int kEpiStoreQ = 6, kEpiResidQ = 7;
+constexpr int kEpiStoreQ = 6, kEpiResidQ = 7, kEpiResidS = 8;
 
 // norm: 0 none, 1 fused RMSNorm with statistics from the f32 A stream, 2 fused RMSNorm from g.a_ss (A = compute type)
 int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, int norm, int epi, bool small, hipStream_t s);
@@ -75,8 +86,17 @@ int launch_rmsnorm(int dtype, const float* x, const float* scale, void* out_ct, 
 int launch_residual_split(const float* x, void* x_ct, float* x_ss, int rows, int dim, hipStream_t s);
 // y[b] = table[tok[b]] + pos[step[b]]
 // y_ct / y_ss (both or neither): bf16 copy of the rows and their per-16-column sums of squares (see GemmArgs)
+// first-layer projections by table lookup (the decoder's first QKV launch folded away): when q_out != nullptr the
+// kernels that produce a decoder input row Embed(tok) + FixedEmbed[t] also write its UNNORMALISED projection
+// q_out[b][0 .. q_n) = ew[tok] + pw[t]  (ew = embedding . W, pw = position table . W, both f32 [rows][q_n])
+struct RowProj {
+  const float* ew;
+  const float* pw;
+  float* q_out;
+  int q_n;
+};
 int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, void* y_ct,
-                 float* y_ss, int B, int dim, hipStream_t s);
+                 float* y_ss, int B, int dim, const RowProj& rp, hipStream_t s);
 // per-row state of the beam-1 search (t5x beam_search, num_decodes = 1): f = [live_logp | best finished
 // score], the second array `rows` floats after the first; len = prefix length of the best finished
 // hypothesis or -1; cfg[0] = brevity_penalty(max_len + 1), cfg[1 + n] = brevity_penalty(n) (device memory)
@@ -91,7 +111,7 @@ struct BeamState {
 int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
                        float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam,
-                       const int* forced, int forced_stride, hipStream_t s);
+                       const int* forced, int forced_stride, const RowProj& rp, hipStream_t s);
 int launch_set_float(float* dst, float v, hipStream_t s);
 int launch_beam1_finalize(int* ids, int L, const int* beam_len, int B, hipStream_t s);
 int launch_ids_to_tokens(const int* ids, int B, int L, int num_regular, int* out, hipStream_t s);

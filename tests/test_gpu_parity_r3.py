@@ -269,8 +269,9 @@ def test_wide_bf16_engine_encodes_at_batch_one():
 
 def test_f32_engine_variants_agree_at_f32_round_off():
     """Round 3 moved the f32 decode loop onto the split residual form (f32 rows + per-16-column sums of squares), folded
-    the cross-attention q-projection into its neighbours and gave the decode-sized f32 tiles eight waves with the
-    K-groups split two ways.  Every variant is the same function with different summation orders: against the r2 path
+    the cross-attention q-projection AND every layer's q / k / v projection into the neighbouring launches (layer 0:
+    two table rows), and gave the decode-sized f32 tiles eight waves with the K-groups split two ways and two K slices
+    in flight.  Every variant is the same function with different summation orders: against the r2 path
     (options = SINGLE_RESIDUAL_STREAM | SEPARATE_PROJECTIONS, four-wave tiles) teacher-forced logits at 96 positions
     agree to 2e-5 rel-L2 per (step, row), and each variant stays inside 1e-4 of the f32 oracle."""
     cfg = network.T5Config(dtype="float32")
@@ -283,12 +284,16 @@ def test_f32_engine_variants_agree_at_f32_round_off():
     lib = _lib.load()
     outs = {}
     try:
-        for name, opt, no_split_k in (("r3", 0, 0), ("r3 four-wave tiles", 0, 1), ("separate projections", _lib.OPT_SEPARATE_PROJECTIONS, 0),
+        for name, opt, no_split_k in (("r3", 0, 0), ("r3 four-wave tiles", 0, 1),
+                                      ("q-fold only", _lib.OPT_SEPARATE_QKV_PROJECTION, 0),
+                                      ("separate projections", _lib.OPT_SEPARATE_PROJECTIONS, 0),
                                       ("r2 path", _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_SEPARATE_PROJECTIONS, 1)):
             _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_F32_SPLIT_K, no_split_k))
+            _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_PREFETCH2, no_split_k))
             eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=opt)
             eng.load_params(params)
-            assert eng.status(_lib.STATUS_Q_FOLD) == (1 if opt == 0 else 0)
+            assert eng.status(_lib.STATUS_Q_FOLD) == (0 if opt & (_lib.OPT_SEPARATE_PROJECTIONS | _lib.OPT_SINGLE_RESIDUAL_STREAM) else 1)
+            assert eng.status(_lib.STATUS_QKV_FOLD) == (1 if opt == 0 else 0)
             assert eng.status(_lib.STATUS_RESIDUAL_SPLIT) == (0 if opt & _lib.OPT_SINGLE_RESIDUAL_STREAM else 1)
             eng.encode(torch.from_numpy(x).cuda())
             ids, logits = eng.decode_forced(forced, num_steps=S)
@@ -301,8 +306,57 @@ def test_f32_engine_variants_agree_at_f32_round_off():
             del eng
     finally:
         _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_F32_SPLIT_K, 0))
-    for name in ("r3", "r3 four-wave tiles", "separate projections"):
+        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_PREFETCH2, 0))
+    for name in ("r3", "r3 four-wave tiles", "q-fold only", "separate projections"):
         d = _rel_rows(outs[name], outs["r2 path"])
         print(f"f32 engine [{name}] vs the r2 path: max rel-L2 {d.max():.3e}")
         assert d.max() < 2e-5, (name, d.max())
         assert np.array_equal(outs[name + " ids"], outs["r2 path ids"])
+
+
+def test_folded_qkv_projection_bf16_and_fp8_caches_against_the_separate_launches():
+    """bf16 engine (the benched path) and bf16 + e4m3 caches: the q / k / v (+ cross-query) projection of every decoder
+    layer rides in the previous layer's MLP out-projection launch (y_in . W = y2 . W + h . (Wo_mlp . W): a two-source
+    K = mlp + emb product), layer 0's row is the sum of two table rows (embedding . W, position table . W), and the
+    self-attention kernel applies 1/rms and rounds q / k / v itself.  Same function, rounded in different places:
+    teacher-forced logits at 200 positions (incl. a padded row and a short segment) stay inside the bf16 bound against
+    the f32 oracle for every variant, variants agree with each other to bf16 noise, graph replay == direct launches, 1
+    chain == 3 chains, beam-1 and greedy both run."""
+    cfg32 = network.T5Config(dtype="float32")
+    params = network.init_random_params(cfg32, seed=0, norm_scale_jitter=0.2)
+    B, S = 7, 200
+    x = _inputs(B, seed=41)
+    x[6, 90:] = 0.0
+    forced = _forced(B, S, 13)
+    forced[2, 60:] = 0
+    _, ref = _teacher_forced_ref(_oracle(cfg32, params), x, forced)
+    for kv, bound in (("", 3e-2), ("fp8_e4m3", 6e-2)):
+        cfg = dataclasses.replace(network.T5Config(), dtype="bfloat16", kv_dtype=kv)
+        outs = {}
+        for name, opt in (("folded", 0), ("q-fold only", _lib.OPT_SEPARATE_QKV_PROJECTION),
+                          ("separate", _lib.OPT_SEPARATE_PROJECTIONS)):
+            eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=opt)
+            eng.load_params(params)
+            assert eng.status(_lib.STATUS_QKV_FOLD) == (1 if opt == 0 else 0)
+            eng.encode(torch.from_numpy(x).cuda())
+            _, logits = eng.decode_forced(forced, num_steps=S)
+            outs[name] = logits.cpu().numpy()
+            r = _rel_rows(outs[name], ref)
+            print(f"kv {kv or 'bf16'} [{name}]: teacher-forced logits vs f32 oracle max {r.max():.3e} mean {r.mean():.3e}")
+            assert r.max() < bound, (kv, name, r.max())
+            if opt == 0:
+                _, l2 = eng.decode_forced(forced, num_steps=40, use_graph=False)
+                assert torch.equal(l2.cpu(), torch.from_numpy(outs[name][:40]))
+                a = eng.decode(num_steps=48, chains=1).cpu().numpy()
+                b = eng.decode(num_steps=48, chains=3).cpu().numpy()
+                c = eng.decode(num_steps=48, use_graph=False).cpu().numpy()
+                assert np.array_equal(a, b) and np.array_equal(a, c)
+                d1 = eng.decode(num_steps=32, beam1=True, chains=1).cpu().numpy()
+                d2 = eng.decode(num_steps=32, beam1=True, chains=2).cpu().numpy()
+                assert np.array_equal(d1, d2)
+                assert eng.status(_lib.STATUS_GRAPH_FALLBACKS) == 0
+            del eng
+        for name in ("folded", "q-fold only"):
+            d = _rel_rows(outs[name], outs["separate"])
+            print(f"kv {kv or 'bf16'} [{name}] vs separate launches: max {d.max():.3e} median {np.median(d):.3e}")
+            assert d.max() < (2e-2 if not kv else 5e-2) and np.median(d) < 8e-3, (kv, name, d.max(), np.median(d))
