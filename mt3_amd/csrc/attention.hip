@@ -420,25 +420,37 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
 
   // QF32: q (and with APPEND the step's new K/V row) arrive as UNNORMALISED f32 products plus the partial sums of
   // squares of the residual row they were projected from (the projection rode in the neighbouring GEMM launches):
-  // 1/rms is applied here, then the values are rounded to the compute type exactly where the GEMM epilogue would have
+  // 1/rms is applied here, then the values are rounded to the compute type exactly where the GEMM epilogue would have.
+  // ALL raw loads are issued before the reduction that yields 1/rms (that reduction waits on ITS load; anything issued
+  // after it would cost a second dependent memory round trip per launch -- measured: 0.9 us).
+  constexpr int NRAW = QF32 ? (APPEND ? 3 : 1) : 1;
+  float4 raw[NRAW][2];
+  if constexpr (QF32) {
+    const float* src[3] = {a.q_f32 + static_cast<size_t>(b) * a.q_stride + h * D + sub * KPL,
+                           APPEND ? static_cast<const float*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * KPL : nullptr,
+                           APPEND ? static_cast<const float*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * KPL : nullptr};
+#pragma unroll
+    for (int i = 0; i < NRAW; ++i) {
+      raw[i][0] = *reinterpret_cast<const float4*>(src[i]);
+      raw[i][1] = KPL == 8 ? *reinterpret_cast<const float4*>(src[i] + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   float rs = 1.f;
   if constexpr (QF32) rs = row_rs_from_partials(a.q_ss + static_cast<size_t>(b) * a.q_ss_n, a.q_ss_n, lane);
-  auto scaled_chunk = [&](const float* p) -> u32x4 {
-    const float4 v0 = *reinterpret_cast<const float4*>(p);
+  auto scaled_chunk = [&](const float4 (&r)[2]) -> u32x4 {
     if constexpr (KPL == 8) {
-      const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
-      const float f[8] = {v0.x * rs, v0.y * rs, v0.z * rs, v0.w * rs, v1.x * rs, v1.y * rs, v1.z * rs, v1.w * rs};
+      const float f[8] = {r[0].x * rs, r[0].y * rs, r[0].z * rs, r[0].w * rs, r[1].x * rs, r[1].y * rs, r[1].z * rs, r[1].w * rs};
       return pack_bf16x8(f);
     } else {
-      return pack_f32x4(v0.x * rs, v0.y * rs, v0.z * rs, v0.w * rs);
+      return pack_f32x4(r[0].x * rs, r[0].y * rs, r[0].z * rs, r[0].w * rs);
     }
   };
   u32x4 new_k = {0u, 0u, 0u, 0u}, new_v = {0u, 0u, 0u, 0u};
   if constexpr (APPEND) {
     // this step's K/V row: folded in below from registers, persisted for the later steps
     if constexpr (QF32) {
-      new_k = scaled_chunk(static_cast<const float*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * KPL);
-      new_v = scaled_chunk(static_cast<const float*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * KPL);
+      new_k = scaled_chunk(raw[NRAW - 2]);
+      new_v = scaled_chunk(raw[NRAW - 1]);
     } else {
       new_k = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride +
                                               h * D + sub * KPL);
@@ -454,7 +466,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
 
   u32x4 qc;
   if constexpr (QF32) {
-    qc = scaled_chunk(a.q_f32 + static_cast<size_t>(b) * a.q_stride + h * D + sub * KPL);
+    qc = scaled_chunk(raw[0]);
   } else {
     qc = *reinterpret_cast<const u32x4*>(static_cast<const CT*>(a.q) + static_cast<size_t>(b) * a.q_stride + h * D +
                                          sub * KPL);
@@ -673,16 +685,35 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
 
   // q: 16 bf16 of this lane's slice -> f32, pre-multiplied by log2(e) (base-2 softmax)
   float q[EPL];
-  if (a.q_f32) {     // (wave-uniform) folded q-projection: unnormalised f32 query + the row's partial sums of squares
+  float nk[EPL], nv[EPL];
+  if (a.q_f32) {     // (wave-uniform) folded projections: unnormalised f32 query (+ new K/V row) + the row's partial sums
     const float* qp = a.q_f32 + static_cast<size_t>(b) * a.q_stride + h * D + sub * EPL;
 #pragma unroll
     for (int j = 0; j < EPL; j += 4) {
       const float4 v = *reinterpret_cast<const float4*>(qp + j);
       q[j] = v.x, q[j + 1] = v.y, q[j + 2] = v.z, q[j + 3] = v.w;
     }
-    const float rs = row_rs_from_partials(a.q_ss + static_cast<size_t>(b) * a.q_ss_n, a.q_ss_n, lane) * kLog2e;
+    if constexpr (APPEND) {   // raw loads BEFORE the 1/rms reduction (one memory round trip for all of them)
+      const float* kp = static_cast<const float*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
+      const float* vp = static_cast<const float*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
+#pragma unroll
+      for (int j = 0; j < EPL; j += 4) {
+        const float4 kx = *reinterpret_cast<const float4*>(kp + j), vx = *reinterpret_cast<const float4*>(vp + j);
+        nk[j] = kx.x, nk[j + 1] = kx.y, nk[j + 2] = kx.z, nk[j + 3] = kx.w;
+        nv[j] = vx.x, nv[j + 1] = vx.y, nv[j + 2] = vx.z, nv[j + 3] = vx.w;
+      }
+    }
+    const float rs1 = row_rs_from_partials(a.q_ss + static_cast<size_t>(b) * a.q_ss_n, a.q_ss_n, lane);
+    const float rs = rs1 * kLog2e;
 #pragma unroll
     for (int j = 0; j < EPL; ++j) q[j] *= rs;
+    if constexpr (APPEND) {   // scale, round to bf16 as the GEMM epilogue would have
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) {
+        nk[j] = static_cast<float>(static_cast<__bf16>(nk[j] * rs1));
+        nv[j] = static_cast<float>(static_cast<__bf16>(nv[j] * rs1));
+      }
+    }
   } else {
     const __bf16* qp = static_cast<const __bf16*>(a.q) + static_cast<size_t>(b) * a.q_stride + h * D + sub * EPL;
     const u32x4 q0 = *reinterpret_cast<const u32x4*>(qp), q1 = *reinterpret_cast<const u32x4*>(qp + 8);
@@ -690,19 +721,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
     unpack_chunk<__bf16>(q1, q + 8);
 #pragma unroll
     for (int j = 0; j < EPL; ++j) q[j] *= kLog2e;
-  }
-  float nk[EPL], nv[EPL];
-  if constexpr (APPEND) {
-    if (a.q_f32) {   // (wave-uniform) the new row as unnormalised f32 products too: scale, round to bf16 as the GEMM would
-      const float* kp = static_cast<const float*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
-      const float* vp = static_cast<const float*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
-      const float rs1 = row_rs_from_partials(a.q_ss + static_cast<size_t>(b) * a.q_ss_n, a.q_ss_n, lane);
-#pragma unroll
-      for (int j = 0; j < EPL; ++j) {
-        nk[j] = static_cast<float>(static_cast<__bf16>(kp[j] * rs1));
-        nv[j] = static_cast<float>(static_cast<__bf16>(vp[j] * rs1));
-      }
-    } else {
+    if constexpr (APPEND) {
       const __bf16* kp = static_cast<const __bf16*>(a.new_k) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
       const __bf16* vp = static_cast<const __bf16*>(a.new_v) + static_cast<size_t>(b) * a.kv_stride + h * D + sub * EPL;
       unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(kp), nk);
@@ -710,6 +729,8 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
       unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(vp), nv);
       unpack_chunk<__bf16>(*reinterpret_cast<const u32x4*>(vp + 8), nv + 8);
     }
+  }
+  if constexpr (APPEND) {
     float ks, vs;
     const u32x4 kq = fp8_quantize_quad(nk, &ks), vq = fp8_quantize_quad(nv, &vs);     // nk / nv now dequantised
     if (tid < LPK) {

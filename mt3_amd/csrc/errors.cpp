@@ -41,8 +41,8 @@ int mt3_debug_set_knob(int32_t knob, int32_t value) {
       if (value < 0 || value > 2) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_set_knob: XCD_N_MAJOR is 0 (auto), 1 or 2");
       mt3k::g_knobs.xcd_n_major = value;
       return MT3_OK;
-    case MT3_DEBUG_KNOB_NO_PREFETCH2:
-      mt3k::g_knobs.no_prefetch2 = value != 0;
+    case MT3_DEBUG_KNOB_PREFETCH2:
+      mt3k::g_knobs.prefetch2 = value != 0;
       return MT3_OK;
     default:
       return mt3::fail(MT3_ERR_INVALID, "mt3_debug_set_knob: unknown knob");

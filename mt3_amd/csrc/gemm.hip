@@ -823,10 +823,13 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
 //         >= 100 workgroups on the chip, and the K step is as deep as LDS allows (16 K-groups = 512 bf16
 //         elements: K = 512 in ONE slice) so that every global load of the block is in flight at once
 //         instead of 8-16 dependent load->barrier->MFMA rounds.
-// decode-sized tile BMxBN with K slice BK; more than one slice: two slices in flight (PF = 2)
+// decode-sized tile BMxBN with K slice BK.  Two slices in flight (PF = 2) is an opt-in debug knob: measured on MI355X
+// at B = 256 it is SLOWER than one (bf16 decode without attention 191 -> 199.5 us per step, f32 358 -> 415): the second
+// slice's 64-128 KB per workgroup queue up in the same CU's 64 B/clk L1 path in front of the first slice's
+// last lines, so the first multiply starts later and the second gains less than that
 template <typename CT, int BM, int BN, int BK, bool A_F32, bool NORM, int EPI, int NPV = 8, int WK = 1>
 static int launch_small(const GemmArgs& g, hipStream_t s) {
-  if (g.K > BK && !g_knobs.no_prefetch2) return launch_cfg<CT, BM, BN, BK, 2, 2, A_F32, NORM, EPI, NPV, WK, 2>(g, s);
+  if (g.K > BK && g_knobs.prefetch2) return launch_cfg<CT, BM, BN, BK, 2, 2, A_F32, NORM, EPI, NPV, WK, 2>(g, s);
   return launch_cfg<CT, BM, BN, BK, 2, 2, A_F32, NORM, EPI, NPV, WK, 1>(g, s);
 }
 

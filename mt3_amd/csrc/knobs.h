@@ -12,7 +12,7 @@ struct Knobs {
   int no_f32_split_k;       // decode-sized f32 GEMM tiles with four waves (no split-K inside the workgroup)
   int xcd_n_major;          // decode-sized GEMM tiles dealt to the XCDs by weight-column slice: 0 = when the weight
                             // matrix exceeds 3 MB (more than an XCD's L2 keeps next to everything else), 1 = always, 2 = never
-  int no_prefetch2;         // decode-sized multi-slice tiles with one K slice in flight instead of two
+  int prefetch2;            // decode-sized multi-slice tiles with TWO K slices in flight (measured slower: off)
 };
 extern Knobs g_knobs;
 

@@ -239,9 +239,10 @@ def test_folded_cross_query_projection_matches_the_separate_launch(setup):
     step-0 logits within bf16 noise on every row; against the f32 oracle both stay inside the bf16 bound."""
     x = torch.from_numpy(np.repeat(setup["x"], 12, axis=0)[:34]).cuda()
     out = {}
-    for name, opt in (("fold", 0), ("separate", _lib.OPT_SEPARATE_PROJECTIONS)):
+    # (the q / k / v fold of round 3 has its own test, tests/test_gpu_parity_r3.py: here the cross-query fold alone)
+    for name, opt in (("fold", _lib.OPT_SEPARATE_QKV_PROJECTION), ("separate", _lib.OPT_SEPARATE_PROJECTIONS)):
         eng = _engine("bfloat16", setup["params"], 34, options=opt)
-        assert eng.status(_lib.STATUS_Q_FOLD) == (1 if opt == 0 else 0)
+        assert eng.status(_lib.STATUS_Q_FOLD) == (1 if name == "fold" else 0) and eng.status(_lib.STATUS_QKV_FOLD) == 0
         eng.encode(x)
         ids, logits0 = eng.decode(num_steps=24, return_first_logits=True)
         out[name] = (ids.cpu().numpy(), logits0.cpu().numpy())

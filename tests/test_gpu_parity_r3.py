@@ -289,7 +289,7 @@ def test_f32_engine_variants_agree_at_f32_round_off():
                                       ("separate projections", _lib.OPT_SEPARATE_PROJECTIONS, 0),
                                       ("r2 path", _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_SEPARATE_PROJECTIONS, 1)):
             _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_F32_SPLIT_K, no_split_k))
-            _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_PREFETCH2, no_split_k))
+            _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_PREFETCH2, 1 if name == 'r3 four-wave tiles' else 0))
             eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=opt)
             eng.load_params(params)
             assert eng.status(_lib.STATUS_Q_FOLD) == (0 if opt & (_lib.OPT_SEPARATE_PROJECTIONS | _lib.OPT_SINGLE_RESIDUAL_STREAM) else 1)
@@ -306,7 +306,7 @@ def test_f32_engine_variants_agree_at_f32_round_off():
             del eng
     finally:
         _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_F32_SPLIT_K, 0))
-        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_PREFETCH2, 0))
+        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_PREFETCH2, 0))
     for name in ("r3", "r3 four-wave tiles", "q-fold only", "separate projections"):
         d = _rel_rows(outs[name], outs["r2 path"])
         print(f"f32 engine [{name}] vs the r2 path: max rel-L2 {d.max():.3e}")

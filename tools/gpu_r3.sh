@@ -16,8 +16,8 @@ export TMPDIR=/tmp
 for st in $STAGES; do
   case $st in
     test)
-      timeout ${TEST_TIMEOUT:-900} python -m pytest tests -m gpu -x -q $TESTS > gpurun_out/pytest_r3.log 2>&1
-      echo "exit $? : pytest -m gpu $TESTS"; tail -5 gpurun_out/pytest_r3.log; grep -h "rel-L2\|token-exact\|agreement\|benched" gpurun_out/pytest_r3.log | cut -c1-300 | tail -20
+      timeout ${TEST_TIMEOUT:-900} python -m pytest ${TESTS:-tests} -m gpu -x -q -s > gpurun_out/pytest_r3.log 2>&1
+      echo "exit $? : pytest -m gpu $TESTS"; tail -5 gpurun_out/pytest_r3.log; grep -h "rel-L2\|token-exact\|agreement\|benched\|vs separate\|vs f32 oracle\|vs the r2" gpurun_out/pytest_r3.log | cut -c1-260 | tail -40
       ;;
     pmc)
       rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
