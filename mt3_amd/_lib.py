@@ -21,8 +21,8 @@ DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1 = 1, 2, 4
  OPT_SEPARATE_QKV_PROJECTION) = 1, 2, 4, 8                                      # mt3_engine_config.options
 # include/mt3_hip_debug.h (measurement / fault injection; not the product ABI)
 DEBUG_SKIP_SELF_ATTN, DEBUG_SKIP_CROSS_ATTN = 1, 2
-(DEBUG_KNOB_DEC_ATTN_WAVES, DEBUG_KNOB_DEC_ATTN_FP8_WAVES, DEBUG_KNOB_NO_LDS_DMA_GEMM, DEBUG_KNOB_NO_F32_SPLIT_K,
- DEBUG_KNOB_XCD_N_MAJOR, DEBUG_KNOB_PREFETCH2) = range(6)
+(DEBUG_KNOB_DEC_ATTN_WAVES, DEBUG_KNOB_DEC_ATTN_FP8_WAVES, DEBUG_KNOB_NO_LDS_DMA_GEMM, DEBUG_KNOB_F32_SPLIT_K,
+ DEBUG_KNOB_XCD_N_MAJOR, DEBUG_KNOB_PREFETCH2, DEBUG_KNOB_NO_K768_SPLIT) = range(7)
 (STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8, STATUS_Q_FOLD,
  STATUS_DENSE_FP8, STATUS_QKV_FOLD) = range(7)
 EV_SHIFT, EV_PITCH, EV_VELOCITY, EV_TIE, EV_PROGRAM, EV_DRUM = range(6)
@@ -83,6 +83,8 @@ SIGNATURES = {
     "mt3_engine_status": (C.c_int, [_P, C.c_int32]),
     "mt3_debug_engine_decode": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mt3_debug_engine_poison_caches": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
+    "mt3_debug_engine_decode_split": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
+                                                C.POINTER(C.c_float), _P]),
     "mt3_debug_set_knob": (C.c_int, [C.c_int32, C.c_int32]),
     "mt3_ids_to_tokens": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mt3_op_gemm": (C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32,

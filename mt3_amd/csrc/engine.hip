@@ -26,12 +26,14 @@
 //     (B=256: ~3.3 GB KV cache + ~0.9 GB cross K/V + ~0.5 GB activations in bf16).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -1143,6 +1145,74 @@ int mt3_debug_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int
   if (skip & ~(MT3_DEBUG_SKIP_SELF_ATTN | MT3_DEBUG_SKIP_CROSS_ATTN))
     return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode: unknown skip bit");
   return decode_impl(e, batch, num_steps, flags, skip, nullptr, nullptr, d_ids, nullptr, nullptr, stream);
+}
+
+int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t n_groups, int32_t mask_mode,
+                                  int32_t* d_ids, float* h_ms, void* stream) {
+  if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: engine not finalized");
+  const mt3_engine_config& c = e->cfg;
+  if (batch <= 0 || batch != e->cur_batch || num_steps <= 0 || num_steps > c.max_decode_len || !d_ids)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: bad batch / steps / ids");
+  if (n_groups < 2 || n_groups > 4 || batch / n_groups < 16 || mask_mode < 0 || mask_mode > 2)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: 2 .. 4 groups of >= 16 rows, mask_mode 0 .. 2");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int L = c.max_decode_len;
+  MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, static_cast<size_t>(batch) * 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->n_done, 0, 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->done, 0, static_cast<size_t>(batch) * 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->cur_tok, 0, static_cast<size_t>(batch) * 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->ids, 0, static_cast<size_t>(batch) * L * 4, s));
+  {
+    const mt3k::RowProj rp{e->ew0, e->pw0, e->qkv_fold ? e->qkvf : nullptr, 4 * e->HD()};
+    MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y,
+                               c.compute_dtype == MT3_BF16 ? e->y_ct : nullptr, e->y_ss, batch, c.emb_dim, rp, s));
+  }
+  MT3_HIP_CHECK(hipStreamSynchronize(s));
+  int n_cu = 0, dev = 0;
+  MT3_HIP_CHECK(hipGetDevice(&dev));
+  MT3_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+  const int words = (n_cu + 31) / 32;
+  std::vector<hipStream_t> gs(n_groups, nullptr);
+  for (int g = 0; g < n_groups; ++g) {
+    if (mask_mode == 0) {
+      MT3_HIP_CHECK(hipStreamCreateWithFlags(&gs[g], hipStreamNonBlocking));
+    } else {
+      std::vector<uint32_t> mask(words, 0u);
+      for (int i = 0; i < n_cu; ++i) {
+        const bool mine = mask_mode == 1 ? (i * n_groups / n_cu == g) : (i % n_groups == g);
+        if (mine) mask[i >> 5] |= 1u << (i & 31);
+      }
+      MT3_HIP_CHECK(hipExtStreamCreateWithCUMask(&gs[g], static_cast<uint32_t>(words), mask.data()));
+    }
+  }
+  std::vector<int> rcs(n_groups, MT3_OK);
+  std::vector<std::string> errs(n_groups);
+  const auto t0 = std::chrono::steady_clock::now();
+  {
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_groups; ++g)
+      th.emplace_back([&, g]() {
+        (void)hipSetDevice(dev);
+        int row0, rows;
+        chain_rows(batch, n_groups, g, &row0, &rows);
+        for (int t = 0; t < num_steps && rcs[g] == MT3_OK; ++t) rcs[g] = enqueue_chain_step(e, row0, rows, g, batch, 0, gs[g]);
+        if (rcs[g] != MT3_OK) errs[g] = mt3_last_error();
+        const hipError_t he = hipStreamSynchronize(gs[g]);
+        if (rcs[g] == MT3_OK && he != hipSuccess) {
+          rcs[g] = MT3_ERR_HIP;
+          errs[g] = hipGetErrorString(he);
+        }
+      });
+    for (std::thread& t : th) t.join();
+  }
+  const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  for (hipStream_t g : gs) (void)hipStreamDestroy(g);
+  for (int g = 0; g < n_groups; ++g)
+    if (rcs[g] != MT3_OK) return mt3::fail(rcs[g], "mt3_debug_engine_decode_split: group " + std::to_string(g) + ": " + errs[g]);
+  if (h_ms) *h_ms = ms;
+  MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
+  MT3_HIP_CHECK(hipStreamSynchronize(s));
+  return MT3_OK;
 }
 
 int mt3_debug_engine_poison_caches(mt3_engine* e, int32_t pattern, int32_t cross, void* stream) {

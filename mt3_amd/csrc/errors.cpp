@@ -17,7 +17,7 @@ int fail(int code, const std::string& msg) {
 }  // namespace mt3
 
 namespace mt3k {
-Knobs g_knobs = {0, 0, 0, 0, 0, 0};
+Knobs g_knobs = {0, 0, 0, 0, 0, 0, 0};
 }
 
 extern "C" {
@@ -34,12 +34,15 @@ int mt3_debug_set_knob(int32_t knob, int32_t value) {
     case MT3_DEBUG_KNOB_NO_LDS_DMA_GEMM:
       mt3k::g_knobs.no_lds_dma_gemm = value != 0;
       return MT3_OK;
-    case MT3_DEBUG_KNOB_NO_F32_SPLIT_K:
-      mt3k::g_knobs.no_f32_split_k = value != 0;
+    case MT3_DEBUG_KNOB_F32_SPLIT_K:
+      mt3k::g_knobs.f32_split_k = value != 0;
       return MT3_OK;
     case MT3_DEBUG_KNOB_XCD_N_MAJOR:
       if (value < 0 || value > 2) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_set_knob: XCD_N_MAJOR is 0 (auto), 1 or 2");
       mt3k::g_knobs.xcd_n_major = value;
+      return MT3_OK;
+    case MT3_DEBUG_KNOB_NO_K768_SPLIT:
+      mt3k::g_knobs.no_k768_split = value != 0;
       return MT3_OK;
     case MT3_DEBUG_KNOB_PREFETCH2:
       mt3k::g_knobs.prefetch2 = value != 0;

@@ -841,7 +841,7 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
     if constexpr (!NORM && !A_F32 && KG == 16 && EPI != MT3_EPI_HEADS && EPI != MT3_EPI_POS) {
       // f32 operands arriving in the compute type (the split residual form / plain activations): eight waves per
       // tile, K-groups split two ways (see gemm_kernel; halves the staging registers per thread as well)
-      if (!g_knobs.no_f32_split_k) {
+      if (g_knobs.f32_split_k) {          // opt-in: measured 1 % SLOWER than four waves (1163 vs 1151 ms per decode)
         if constexpr (EPI == MT3_EPI_GEGLU) {
           if (deep) return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI, 8, 2>(g, s);
         } else {
@@ -854,8 +854,18 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
       // ismir2022/base.gin shape (emb = heads * 64 = 768): K = 768 as ONE slice too, with room for its 48 partial
       // sums of squares when the rows arrive as the bf16 residual copy (norm 2)
       if (g.K == 24 * KG) {
-        if constexpr (EPI == MT3_EPI_GEGLU) return launch_cfg<CT, 32, 64, 24 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
-        else return launch_cfg<CT, 32, 32, 24 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
+        // (the one-slice tiles hold 100 / 150 KB of LDS = ONE workgroup per CU: a launch with more workgroups than CUs
+        // -- QKV N = 3072: 768, GEGLU N = 4096: 512 -- would run in rounds; those take K in two slices of 384 instead,
+        // 51 / 75 KB, three / two workgroups per CU, one round)
+        if constexpr (EPI == MT3_EPI_GEGLU) {
+          if (((g.M + 31) / 32) * (g.N / 64) > 256 && !g_knobs.no_k768_split)
+            return launch_cfg<CT, 32, 64, 12 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
+          return launch_cfg<CT, 32, 64, 24 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
+        } else {
+          if (((g.M + 31) / 32) * (g.N / 32) > 256 && !g_knobs.no_k768_split)
+            return launch_cfg<CT, 32, 32, 12 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
+          return launch_cfg<CT, 32, 32, 24 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
+        }
       }
     }
     if constexpr (EPI == MT3_EPI_GEGLU) {
@@ -868,8 +878,13 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
         if (g.K == 12 * KG) return launch_cfg<CT, 32, 32, 12 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
       }
       if constexpr (!NORM && !A_F32 && KG == 16) {
-        // f32 operands: the attention out-projections (K = 384) in two slices of 192 instead of six of 64
-        if (g.K == 24 * KG) return launch_small<CT, 32, 32, 12 * KG, A_F32, NORM, EPI>(g, s);
+        // f32 operands: the attention out-projections (K = 384) as ONE slice (100 KB of LDS: one workgroup per CU,
+        // these launches have at most 224) -- every slice of an f32 tile is a dependent 64 KB trip through the CU's L1
+        if (g.K == 24 * KG) {
+          const int wgs = ((g.M + 31) / 32) * (g.N / 32);
+          if (wgs <= 256) return launch_cfg<CT, 32, 32, 24 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
+          return launch_small<CT, 32, 32, 12 * KG, A_F32, NORM, EPI>(g, s);
+        }
       }
       if (deep) return launch_small<CT, 32, 32, 16 * KG, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 32, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);

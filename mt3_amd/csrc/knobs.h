@@ -9,9 +9,10 @@ struct Knobs {
   int dec_attn_waves;       // waves per decode-attention workgroup (2 / 3 / 4)
   int dec_attn_fp8_waves;
   int no_lds_dma_gemm;      // encoder GEMMs on the register-staged tile
-  int no_f32_split_k;       // decode-sized f32 GEMM tiles with four waves (no split-K inside the workgroup)
+  int f32_split_k;          // decode-sized f32 GEMM tiles with EIGHT waves, K-groups split two ways (measured slower: off)
   int xcd_n_major;          // decode-sized GEMM tiles dealt to the XCDs by weight-column slice: 0 = when the weight
                             // matrix exceeds 3 MB (more than an XCD's L2 keeps next to everything else), 1 = always, 2 = never
+  int no_k768_split;        // K = 768 decode tiles always as one slice (one workgroup per CU), however many workgroups
   int prefetch2;            // decode-sized multi-slice tiles with TWO K slices in flight (measured slower: off)
 };
 extern Knobs g_knobs;

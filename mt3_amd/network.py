@@ -233,6 +233,17 @@ class Transformer:
                                                      torch.cuda.current_stream().cuda_stream))
         return ids
 
+    def debug_decode_split(self, num_steps: Optional[int] = None, groups: int = 2, mask_mode: int = 1):
+        """mt3_debug_engine_decode_split: the CU-partitioned two-stream overlap experiment (one host thread and one
+        CU-masked stream per row group, direct launches).  Returns (ids, wall ms of the decode loop)."""
+        import torch
+        B, L = self._batch, self.max_decode_length
+        ids = torch.empty((B, L), device="cuda", dtype=torch.int32)
+        ms = C.c_float()
+        _lib.check(self._lib.mt3_debug_engine_decode_split(self._h, B, num_steps or L, groups, mask_mode, ids.data_ptr(),
+                                                           C.byref(ms), torch.cuda.current_stream().cuda_stream))
+        return ids, ms.value
+
     def debug_poison_caches(self, pattern: int = 0xFF, cross: bool = False):
         """mt3_debug_engine_poison_caches: fill the K/V caches with a byte pattern (0xFF = NaN in every cache format)."""
         import torch

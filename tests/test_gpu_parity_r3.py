@@ -284,12 +284,12 @@ def test_f32_engine_variants_agree_at_f32_round_off():
     lib = _lib.load()
     outs = {}
     try:
-        for name, opt, no_split_k in (("r3", 0, 0), ("r3 four-wave tiles", 0, 1),
+        for name, opt, split_k in (("r3", 0, 0), ("r3 eight-wave tiles", 0, 1),
                                       ("q-fold only", _lib.OPT_SEPARATE_QKV_PROJECTION, 0),
                                       ("separate projections", _lib.OPT_SEPARATE_PROJECTIONS, 0),
-                                      ("r2 path", _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_SEPARATE_PROJECTIONS, 1)):
-            _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_F32_SPLIT_K, no_split_k))
-            _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_PREFETCH2, 1 if name == 'r3 four-wave tiles' else 0))
+                                      ("r2 path", _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_SEPARATE_PROJECTIONS, 0)):
+            _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_F32_SPLIT_K, split_k))
+            _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_PREFETCH2, split_k))
             eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=opt)
             eng.load_params(params)
             assert eng.status(_lib.STATUS_Q_FOLD) == (0 if opt & (_lib.OPT_SEPARATE_PROJECTIONS | _lib.OPT_SINGLE_RESIDUAL_STREAM) else 1)
@@ -305,9 +305,9 @@ def test_f32_engine_variants_agree_at_f32_round_off():
             outs[name + " ids"] = g
             del eng
     finally:
-        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_F32_SPLIT_K, 0))
+        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_F32_SPLIT_K, 0))
         _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_PREFETCH2, 0))
-    for name in ("r3", "r3 four-wave tiles", "q-fold only", "separate projections"):
+    for name in ("r3", "r3 eight-wave tiles", "q-fold only", "separate projections"):
         d = _rel_rows(outs[name], outs["r2 path"])
         print(f"f32 engine [{name}] vs the r2 path: max rel-L2 {d.max():.3e}")
         assert d.max() < 2e-5, (name, d.max())

@@ -23,26 +23,26 @@ VARIANTS = [
     ("bf16 q-fold only (r2)", "bfloat16", "", "mt3", K.OPT_SEPARATE_QKV_PROJECTION, {}),
     ("bf16 q-fold only, two slices in flight", "bfloat16", "", "mt3", K.OPT_SEPARATE_QKV_PROJECTION, {K.DEBUG_KNOB_PREFETCH2: 1}),
     ("bf16 separate projections", "bfloat16", "", "mt3", K.OPT_SEPARATE_PROJECTIONS, {}),
-    ("f32 default (split + folds + split-K + 2 slices)", "float32", "", "mt3", 0, {}),
+    ("f32 default (split form + folds)", "float32", "", "mt3", 0, {}),
     ("f32 two slices in flight", "float32", "", "mt3", 0, {K.DEBUG_KNOB_PREFETCH2: 1}),
-    ("f32 four-wave tiles", "float32", "", "mt3", 0, {K.DEBUG_KNOB_NO_F32_SPLIT_K: 1}),
+    ("f32 eight-wave split-K tiles", "float32", "", "mt3", 0, {K.DEBUG_KNOB_F32_SPLIT_K: 1}),
     ("f32 q-fold only", "float32", "", "mt3", K.OPT_SEPARATE_QKV_PROJECTION, {}),
     ("f32 xcd never n-major", "float32", "", "mt3", 0, {K.DEBUG_KNOB_XCD_N_MAJOR: 2}),
     ("f32 separate projections", "float32", "", "mt3", K.OPT_SEPARATE_PROJECTIONS, {}),
     ("f32 r2 path", "float32", "", "mt3", K.OPT_SEPARATE_PROJECTIONS | K.OPT_SINGLE_RESIDUAL_STREAM,
-     {K.DEBUG_KNOB_NO_F32_SPLIT_K: 1}),
+     {}),
     ("fp8kv default", "bfloat16", "fp8_e4m3", "mt3", 0, {}),
     ("fp8kv q-fold only (r2)", "bfloat16", "fp8_e4m3", "mt3", K.OPT_SEPARATE_QKV_PROJECTION, {}),
     ("base fp8kv default", "bfloat16", "fp8_e4m3", "base", 0, {}),
     ("base fp8kv xcd never n-major", "bfloat16", "fp8_e4m3", "base", 0, {K.DEBUG_KNOB_XCD_N_MAJOR: 2}),
-    ("base fp8kv two slices in flight", "bfloat16", "fp8_e4m3", "base", 0, {K.DEBUG_KNOB_PREFETCH2: 1}),
+    ("base fp8kv K=768 always one slice", "bfloat16", "fp8_e4m3", "base", 0, {K.DEBUG_KNOB_NO_K768_SPLIT: 1}),
 ]
 want = sys.argv[1:]
 stream = torch.cuda.Stream()
 audio = synthetic.synth_audio(B, seed=1000)
 lm = spectrograms.compute_spectrogram_batch(audio, None)
 ALL_KNOBS = (K.DEBUG_KNOB_DEC_ATTN_WAVES, K.DEBUG_KNOB_DEC_ATTN_FP8_WAVES, K.DEBUG_KNOB_NO_LDS_DMA_GEMM,
-             K.DEBUG_KNOB_NO_F32_SPLIT_K, K.DEBUG_KNOB_XCD_N_MAJOR, K.DEBUG_KNOB_PREFETCH2)
+             K.DEBUG_KNOB_F32_SPLIT_K, K.DEBUG_KNOB_XCD_N_MAJOR, K.DEBUG_KNOB_PREFETCH2, K.DEBUG_KNOB_NO_K768_SPLIT)
 for name, dtype, kv, model, opt, knobs in VARIANTS:
     if want and not any(w in name for w in want):
         continue

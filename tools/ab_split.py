@@ -1,0 +1,44 @@
+"""The CU-partitioned overlap experiment (VERDICT r2, next #2 iii): the bf16 decode of 256 segments as one graph-replayed
+chain (the product) against 2 / 3 / 4 row groups, one host thread + one stream each with direct launches, the streams
+unmasked / masked to contiguous blocks of the CU-mask bits / masked to interleaved bits (mt3_debug_engine_decode_split).
+Prints wall ms of the 1024-step decode loop and whether the ids are identical."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mt3_amd import network, spectrograms, synthetic  # noqa: E402
+
+B = int(os.environ.get("AB_B", "256"))
+cfg = network.T5Config(dtype=os.environ.get("AB_DTYPE", "bfloat16"))
+eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=B)
+eng.load_params(network.init_random_params(cfg, seed=0))
+stream = torch.cuda.Stream()
+lm = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(B, seed=1000), None)
+with torch.cuda.stream(stream):
+    eng.encode(lm)
+    eng.decode(num_steps=2)
+    best = 1e30
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ref = eng.decode(num_steps=1024)
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) * 1e3)
+    print("one chain, hipGraph replay (product)          : %8.1f ms" % best, flush=True)
+    t0 = time.perf_counter()
+    d = eng.decode(num_steps=1024, use_graph=False)
+    torch.cuda.synchronize()
+    print("one chain, direct launches, one host thread   : %8.1f ms  ids equal %s" % ((time.perf_counter() - t0) * 1e3,
+                                                                                  bool(torch.equal(d, ref))), flush=True)
+    for groups in (2, 3, 4):
+        for mode, label in ((0, "no CU mask"), (1, "contiguous CU-mask blocks"), (2, "interleaved CU-mask bits")):
+            try:
+                eng.debug_decode_split(num_steps=8, groups=groups, mask_mode=mode)
+                ids, ms = eng.debug_decode_split(num_steps=1024, groups=groups, mask_mode=mode)
+                print("%d groups, %-26s            : %8.1f ms  ids equal %s" % (groups, label, ms, bool(torch.equal(ids, ref))),
+                      flush=True)
+            except Exception as ex:
+                print("%d groups, %s: FAILED %r" % (groups, label, ex), flush=True)

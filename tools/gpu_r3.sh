@@ -67,6 +67,10 @@ PY
       timeout ${AB_TIMEOUT:-600} python tools/ab_decode.py $AB_ARGS > gpurun_out/ab_decode.log 2>&1
       echo "exit $? : ab_decode $AB_ARGS"; grep -v "^/opt\|Warning" gpurun_out/ab_decode.log | tail -20
       ;;
+    split)
+      timeout ${SPLIT_TIMEOUT:-240} python tools/ab_split.py > gpurun_out/ab_split.log 2>&1
+      echo "exit $? : ab_split"; grep -v "^/opt\|Warning" gpurun_out/ab_split.log | tail -14
+      ;;
     *) echo "unknown stage $st";;
   esac
 done
