@@ -330,6 +330,8 @@ def main():
         gather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / max(1, len(gather_events))
     graph_fallbacks = eng.status(_lib.STATUS_GRAPH_FALLBACKS)
     used_graph = eng.status(_lib.STATUS_LAST_DECODE_USED_GRAPH)
+    decode_groups = eng.status(_lib.STATUS_LAST_DECODE_GROUPS)
+    partition_fallbacks = eng.status(_lib.STATUS_PARTITION_FALLBACKS)
 
     # ---- roofline of the dominant kernel (decode self-attention: HBM streaming of the K/V cache).
     # In-situ and live: HIP events (recorded on the stream the graphs are launched on) around the whole
@@ -382,6 +384,10 @@ def main():
                 return min(timed(lambda: engine.debug_decode(num_steps=args.decode_steps, chains=1, **kw))
                            for _ in range(reps))
             t_full = decode_ms()
+            with torch.cuda.stream(stream):
+                engine.decode(num_steps=2)
+            t_prod = min(timed(lambda: engine.decode(num_steps=args.decode_steps)) for _ in range(reps))
+            prod_groups = engine.status(_lib.STATUS_LAST_DECODE_GROUPS)
             t_noself = decode_ms(skip_self_attn=True)
             t_nocross = decode_ms(skip_cross_attn=True)
             esz = 2 if ecfg.dtype == "bfloat16" else 4
@@ -411,12 +417,16 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_us": self_us, "algorithmic_bytes_per_launch": self_bytes / launches,
                     "launches": launches,
-                    "method": "HIP events on the launch stream around the whole graph-replayed decode, with and "
+                    "method": "HIP events on the launch stream around the whole graph-replayed single-stream decode "
+                              "(the kernel at full-GPU width, one launch at a time, as rocprofv3 times it), with and "
                               "without this kernel in the step graph; (difference)/launches",
                     "decode_ms_single_chain": t_full, "decode_ms_without_self_attn": t_noself,
                     "decode_ms_without_cross_attn": t_nocross,
                     "small_kernel_us_per_step": (t_noself + t_nocross - t_full) * 1e3 / S,
                     "whole_step_hbm_frac": (self_bytes + cross_bytes) / (t_full * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    # the schedule the headline runs (CU-partitioned row groups at this batch): same bytes, its own clock
+                    "decode_ms_product_schedule": t_prod, "product_schedule_row_groups": prod_groups,
+                    "whole_step_hbm_frac_product_schedule": (self_bytes + cross_bytes) / (t_prod * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "cross_attn": {"achieved": cross_bytes / launches / (cross_us * 1e-6) / 1e9,
                                    "frac": cross_bytes / launches / (cross_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                    "avg_launch_us": cross_us, "algorithmic_bytes_per_launch": cross_bytes / launches}}
@@ -562,7 +572,7 @@ def main():
             head = ("BASELINE configs[2]: MT3 (model.gin) random-init" if args.model == "mt3" else
                     "BASELINE configs[4] shape: ismir2022/base.gin random-init")
             workload = ("%s, full encoder-decoder %s decode, batch=%d synthetic 2.048 s segments per GPU, %d decode "
-                        "steps (no early exit), hipGraph step replay, ids->tokens + host note decoding included%s"
+                        "steps (no early exit), ids->tokens + host note decoding included%s"
                         % (head, "greedy" if args.decoding == "greedy" else "beam-1 (t5x beam_search, one beam)",
                            B, args.decode_steps, ", e4m3 K/V caches" if args.kv_dtype else ""))
         out = {
@@ -579,8 +589,11 @@ def main():
                        "file_segments": args.file_segments,
                        "parallelism": "dp%d (segments sharded, weights replicated, ONE RCCL gather of the token rows to rank 0)"
                                       % world if world > 1 else "single GPU",
-                       "step_graph": "hipGraph replay" if used_graph else "DIRECT LAUNCHES (graph capture failed)",
-                       "graph_fallbacks": graph_fallbacks,
+                       "decode_schedule": ("CU-partitioned: %d row groups on CU-masked streams, one host thread each, "
+                                           "direct launches" % decode_groups) if decode_groups > 1 else
+                       ("one stream, hipGraph replay per step" if used_graph else
+                        "one stream, DIRECT LAUNCHES (graph capture failed)"),
+                       "graph_fallbacks": graph_fallbacks, "partition_fallbacks": partition_fallbacks,
                        "notes_decoded_last_step": n_notes},
             "segments_per_s": segs / dt,
             "rccl_world": dist.get_world_size() if world > 1 else 1,

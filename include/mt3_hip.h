@@ -132,7 +132,9 @@ enum {
   /* decoder: only the q / k / v (+ cross-query) projection of a layer's INPUT row keeps its own launch (otherwise it
    * rides in the previous layer's MLP out-projection launch, and layer 0's comes from two table rows); the
    * cross-attention query stays folded */
-  MT3_OPT_SEPARATE_QKV_PROJECTION = 8
+  MT3_OPT_SEPARATE_QKV_PROJECTION = 8,
+  /* never use the CU-partitioned decode schedule (see mt3_engine_decode): every decode stays on the caller's stream */
+  MT3_OPT_NO_CU_PARTITION = 16
 };
 
 typedef struct mt3_engine mt3_engine;
@@ -167,11 +169,19 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch,
  * flags & MT3_DECODE_NO_GRAPH.  d_ids [batch, L] int32 (columns >= num_steps
  * are zero-filled).  d_first_logits: [batch, vocab] f32 logits of step 0, or NULL.
  * With MT3_DECODE_EARLY_EXIT the host polls a device flag every 32 steps and
- * stops once every row has emitted EOS / finished its search (this synchronises the stream). */
+ * stops once every row has emitted EOS / finished its search (this synchronises the stream).
+ * Schedule: a batch of >= 128 rows is decoded as TWO row groups, each on an engine-owned stream restricted to half of
+ * the compute units (hipExtStreamCreateWithCUMask) and driven by its own host thread with direct launches, so that one
+ * group's HBM-bound attention runs beside the other group's latency-bound GEMMs (+6 % at batch 256); the caller's
+ * stream is ordered before and after the groups by events, the ids are bit-identical to the single-stream schedule
+ * (rows are independent), the call returns when both groups are ENQUEUED.  MT3_DECODE_SINGLE_STREAM / _NO_GRAPH /
+ * _CHAINS(n), decode_chains > 1 or MT3_OPT_NO_CU_PARTITION keep everything on `stream`. */
 enum {
   MT3_DECODE_NO_GRAPH = 1,
   MT3_DECODE_EARLY_EXIT = 2,
-  MT3_DECODE_BEAM1 = 4
+  MT3_DECODE_BEAM1 = 4,
+  /* keep the whole decode on the caller's stream (no helper streams / threads): see "schedule" below */
+  MT3_DECODE_SINGLE_STREAM = 8
   /* bits 8..11: number of decode chains for this call (1..8); 0 = the engine's configured default.
    * Any other bit is rejected with MT3_ERR_INVALID (profiling variants live in mt3_hip_debug.h). */
 };
@@ -197,7 +207,9 @@ int mt3_engine_decode_forced(mt3_engine* e, int32_t batch, int32_t num_steps, in
 enum { MT3_STATUS_GRAPH_FALLBACKS = 0, MT3_STATUS_LAST_DECODE_USED_GRAPH = 1, MT3_STATUS_RESIDUAL_SPLIT = 2,
        MT3_STATUS_KV_FP8 = 3, MT3_STATUS_Q_FOLD = 4 /* cross q-projection folded into the neighbouring launches */,
        MT3_STATUS_DENSE_FP8 = 5 /* encoder dense layers on the MXFP8 path */,
-       MT3_STATUS_QKV_FOLD = 6 /* the decoder layers' q/k/v projections folded into the preceding launches */ };
+       MT3_STATUS_QKV_FOLD = 6 /* the decoder layers' q/k/v projections folded into the preceding launches */,
+       MT3_STATUS_LAST_DECODE_GROUPS = 7 /* 2: the most recent decode ran CU-partitioned; 1: on the caller's stream */,
+       MT3_STATUS_PARTITION_FALLBACKS = 8 /* decodes that wanted the partitioned schedule but could not set it up */ };
 int mt3_engine_status(const mt3_engine* e, int32_t what);
 
 /* GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271): -1 from the

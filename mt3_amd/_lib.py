@@ -16,15 +16,15 @@ LIB_PATH = os.path.join(HERE, "libmt3hip.so")
 MT3_OK, MT3_ERR_INVALID, MT3_ERR_HIP, MT3_ERR_CAPACITY, MT3_ERR_MISSING = 0, -1, -2, -3, -4
 MT3_BF16, MT3_F32, MT3_FP8_E4M3 = 0, 1, 2
 EPI_STORE, EPI_RESID, EPI_GEGLU, EPI_POS, EPI_F32, EPI_HEADS = range(6)
-DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1 = 1, 2, 4
+DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SINGLE_STREAM = 1, 2, 4, 8
 (OPT_SINGLE_RESIDUAL_STREAM, OPT_SEPARATE_PROJECTIONS, OPT_ENCODER_SINGLE_RESIDUAL_STREAM,
- OPT_SEPARATE_QKV_PROJECTION) = 1, 2, 4, 8                                      # mt3_engine_config.options
+ OPT_SEPARATE_QKV_PROJECTION, OPT_NO_CU_PARTITION) = 1, 2, 4, 8, 16              # mt3_engine_config.options
 # include/mt3_hip_debug.h (measurement / fault injection; not the product ABI)
 DEBUG_SKIP_SELF_ATTN, DEBUG_SKIP_CROSS_ATTN = 1, 2
 (DEBUG_KNOB_DEC_ATTN_WAVES, DEBUG_KNOB_DEC_ATTN_FP8_WAVES, DEBUG_KNOB_NO_LDS_DMA_GEMM, DEBUG_KNOB_F32_SPLIT_K,
  DEBUG_KNOB_XCD_N_MAJOR, DEBUG_KNOB_PREFETCH2, DEBUG_KNOB_NO_K768_SPLIT) = range(7)
 (STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8, STATUS_Q_FOLD,
- STATUS_DENSE_FP8, STATUS_QKV_FOLD) = range(7)
+ STATUS_DENSE_FP8, STATUS_QKV_FOLD, STATUS_LAST_DECODE_GROUPS, STATUS_PARTITION_FALLBACKS) = range(9)
 EV_SHIFT, EV_PITCH, EV_VELOCITY, EV_TIE, EV_PROGRAM, EV_DRUM = range(6)
 EVENT_TYPE_NAMES = ("shift", "pitch", "velocity", "tie", "program", "drum")
 SPEC_ONSETS, SPEC_NOTES, SPEC_TIES = range(3)

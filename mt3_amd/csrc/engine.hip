@@ -166,6 +166,17 @@ struct mt3_engine {
   int* beam_len = nullptr;       // [max_batch]
   float* beam_cfg = nullptr;     // [0] brevity penalty of the loop bound, [1 + n] brevity_penalty(n)
 
+  // CU-partitioned decode schedule (round 3): the batch as two row groups, each on its own stream restricted to half of
+  // the compute units (hipExtStreamCreateWithCUMask, interleaved mask bits), each driven by its own host thread with
+  // direct launches -- one group's HBM-bound attention kernels run beside the other group's latency-bound GEMMs.
+  // Measured on MI355X at B = 256: 591 ms per 1024-step decode against 629 ms for one graph-replayed chain (without
+  // the masks the same two streams take 818 ms: every kernel then spreads over the whole chip and the groups serialise).
+  hipStream_t part_stream[4] = {};
+  hipEvent_t part_done[4] = {};
+  hipEvent_t part_begin = nullptr;
+  int part_failed = 0;           // partitioned decodes that fell back to the single-stream schedule (stream creation failed)
+  int last_groups = 1;           // row groups of the most recent decode
+
   int cur_batch = 0;             // batch of the last encode
   hipStream_t cap_stream[8] = {};     // one capture stream per chain (kMaxChains)
   hipEvent_t cap_event[8] = {};
@@ -463,7 +474,7 @@ inline bool chain_op_is_heavy(const mt3_engine* e, int op) {
   return op < 8 * e->cfg.num_decoder_layers && ((op & 7) == 1 || (op & 7) == 4);
 }
 
-int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, int op, hipStream_t s) {
+int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, int op, hipStream_t s, int done_slot = 0) {
   const mt3_engine_config& c = e->cfg;
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), H = c.num_heads, T = c.input_length;
   const int Lmax = c.max_decode_len;
@@ -520,7 +531,7 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     const mt3k::BeamState beam{e->beam_f + row0, e->beam_len + row0, e->beam_cfg, c.max_batch};
     const mt3k::RowProj rp{e->ew0, e->pw0, qkvf, 4 * hd};
     return mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
-                                    e->cur_tok + row0, e->done + row0, e->n_done, step, e->embedding, e->pos_table,
+                                    e->cur_tok + row0, e->done + row0, e->n_done + done_slot, step, e->embedding, e->pos_table,
                                     kMaxPos, y_buf(0), split && !f32 ? yct_buf(0) : nullptr, y_ss, emb, rows,
                                     (skip & 4) ? &beam : nullptr,
                                     (skip & 8) ? e->forced + static_cast<size_t>(row0) * Lmax : nullptr, Lmax, rp, s);
@@ -622,9 +633,11 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   }
 }
 
-int enqueue_chain_step(mt3_engine* e, int row0, int rows, int chain, int B_total, int skip, hipStream_t s) {
+int enqueue_chain_step(mt3_engine* e, int row0, int rows, int chain, int B_total, int skip, hipStream_t s,
+                       int done_slot = 0) {
   (void)chain;
-  for (int op = 0, n = chain_num_ops(e); op < n; ++op) MT3_TRY(enqueue_chain_op(e, row0, rows, B_total, skip, op, s));
+  for (int op = 0, n = chain_num_ops(e); op < n; ++op)
+    MT3_TRY(enqueue_chain_op(e, row0, rows, B_total, skip, op, s, done_slot));
   return MT3_OK;
 }
 
@@ -731,7 +744,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
   if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM |
-                       MT3_OPT_SEPARATE_QKV_PROJECTION))
+                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_CU_PARTITION))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -751,6 +764,11 @@ void mt3_engine_destroy(mt3_engine* e) {
     if (e->cap_stream[k]) (void)hipStreamDestroy(e->cap_stream[k]);
     if (e->cap_event[k]) (void)hipEventDestroy(e->cap_event[k]);
   }
+  for (int g = 0; g < 4; ++g) {
+    if (e->part_stream[g]) (void)hipStreamDestroy(e->part_stream[g]);
+    if (e->part_done[g]) (void)hipEventDestroy(e->part_done[g]);
+  }
+  if (e->part_begin) (void)hipEventDestroy(e->part_begin);
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
@@ -925,7 +943,7 @@ int mt3_engine_finalize(mt3_engine* e) {
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->cur_tok), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->done), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->step), static_cast<size_t>(Bm) * 4))) return rc;
-  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->n_done), 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->n_done), 4 * kMaxChains))) return rc;   // one counter per row group
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->forced), static_cast<size_t>(Bm) * L * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->beam_f), static_cast<size_t>(2) * Bm * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->beam_len), static_cast<size_t>(Bm) * 4))) return rc;
@@ -1055,6 +1073,72 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
   return MT3_OK;
 }
 
+// The decode loop as `groups` row groups on CU-masked streams, one host thread each (mt3_engine::part_stream).  The
+// caller's stream is never synchronised unless EARLY_EXIT polls: the groups start after an event recorded on it and it
+// waits for an event per group at the end.  MT3_ERR_CAPACITY = the streams could not be set up (caller falls back).
+static int decode_partitioned(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int skip, int groups,
+                              int* steps_run, hipStream_t s) {
+  int n_cu = 0, dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 2 * groups)
+    return MT3_ERR_CAPACITY;
+  for (int g = 0; g < groups; ++g) {
+    if (!e->part_stream[g]) {
+      std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+      for (int i = g; i < n_cu; i += groups) mask[i >> 5] |= 1u << (i & 31);       // interleaved CU-mask bits
+      if (hipExtStreamCreateWithCUMask(&e->part_stream[g], static_cast<uint32_t>(mask.size()), mask.data()) != hipSuccess) {
+        e->part_stream[g] = nullptr;
+        (void)hipGetLastError();
+        return MT3_ERR_CAPACITY;
+      }
+    }
+    if (!e->part_done[g] && hipEventCreateWithFlags(&e->part_done[g], hipEventDisableTiming) != hipSuccess)
+      return MT3_ERR_CAPACITY;
+  }
+  if (!e->part_begin && hipEventCreateWithFlags(&e->part_begin, hipEventDisableTiming) != hipSuccess)
+    return MT3_ERR_CAPACITY;
+  MT3_HIP_CHECK(hipEventRecord(e->part_begin, s));
+  std::vector<int> rcs(groups, MT3_OK), ran(groups, 0);
+  std::vector<std::string> errs(groups);
+  const bool early = (flags & MT3_DECODE_EARLY_EXIT) != 0;
+  auto body = [&](int g) {
+    (void)hipSetDevice(dev);
+    hipStream_t gs = e->part_stream[g];
+    int row0, rows;
+    chain_rows(batch, groups, g, &row0, &rows);
+    hipError_t he = hipStreamWaitEvent(gs, e->part_begin, 0);
+    for (int t = 0; t < num_steps && rcs[g] == MT3_OK && he == hipSuccess; ++t) {
+      rcs[g] = enqueue_chain_step(e, row0, rows, g, batch, skip, gs, g);
+      ++ran[g];
+      if (early && t % 32 == 31 && rcs[g] == MT3_OK) {      // every group stops as soon as ITS rows are finished
+        he = hipMemcpyAsync(e->h_pinned + g, e->n_done + g, 4, hipMemcpyDeviceToHost, gs);
+        if (he == hipSuccess) he = hipStreamSynchronize(gs);
+        if (he == hipSuccess && e->h_pinned[g] >= rows) break;
+      }
+    }
+    if (rcs[g] != MT3_OK) errs[g] = mt3_last_error();
+    if (he == hipSuccess) he = hipEventRecord(e->part_done[g], gs);
+    if (rcs[g] == MT3_OK && he != hipSuccess) {
+      rcs[g] = MT3_ERR_HIP;
+      errs[g] = hipGetErrorString(he);
+    }
+  };
+  {
+    std::vector<std::thread> th;
+    for (int g = 1; g < groups; ++g) th.emplace_back(body, g);
+    body(0);                                        // the calling thread drives group 0
+    for (std::thread& t : th) t.join();
+  }
+  int most = 0;
+  for (int g = 0; g < groups; ++g) {
+    if (rcs[g] != MT3_OK) return mt3::fail(rcs[g], "mt3_engine_decode (row group " + std::to_string(g) + "): " + errs[g]);
+    MT3_HIP_CHECK(hipStreamWaitEvent(s, e->part_done[g], 0));
+    most = ran[g] > most ? ran[g] : most;
+  }
+  *steps_run = most;
+  return MT3_OK;
+}
+
 // shared body of mt3_engine_decode / mt3_engine_decode_forced
 static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t debug_skip,
                        const int32_t* d_forced, float* d_step_logits, int32_t* d_ids, float* d_first_logits,
@@ -1065,7 +1149,8 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
   const mt3_engine_config& c = e->cfg;
   if (num_steps <= 0 || num_steps > c.max_decode_len || !d_ids)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: num_steps out of range or null ids");
-  if (flags & ~(MT3_DECODE_NO_GRAPH | MT3_DECODE_EARLY_EXIT | MT3_DECODE_BEAM1 | MT3_DECODE_CHAINS(0xF)))
+  if (flags & ~(MT3_DECODE_NO_GRAPH | MT3_DECODE_EARLY_EXIT | MT3_DECODE_BEAM1 | MT3_DECODE_SINGLE_STREAM |
+                MT3_DECODE_CHAINS(0xF)))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: unknown flag bit");
   const bool beam1 = (flags & MT3_DECODE_BEAM1) != 0;
   if (d_forced && (beam1 || (flags & MT3_DECODE_EARLY_EXIT)))
@@ -1073,7 +1158,7 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = c.max_decode_len;
   MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, static_cast<size_t>(batch) * 4, s));
-  MT3_HIP_CHECK(hipMemsetAsync(e->n_done, 0, 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->n_done, 0, 4 * kMaxChains, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->done, 0, static_cast<size_t>(batch) * 4, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->cur_tok, 0, static_cast<size_t>(batch) * 4, s));     // BOS = 0
   MT3_HIP_CHECK(hipMemsetAsync(e->ids, 0, static_cast<size_t>(batch) * L * 4, s));
@@ -1096,6 +1181,25 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
     MT3_TRY(mt3k::launch_set_float(e->beam_cfg, brevity_penalty(num_steps + 1), s));
     MT3_HIP_CHECK(hipMemsetAsync(e->beam_f, 0, static_cast<size_t>(2) * c.max_batch * 4, s));
     MT3_HIP_CHECK(hipMemsetAsync(e->beam_len, 0xFF, static_cast<size_t>(c.max_batch) * 4, s));   // -1
+  }
+  // ---- the CU-partitioned schedule (see mt3_engine::part_stream): batches of >= 128 rows, unless the caller asked for
+  // one stream / direct launches / graph chains, or wants per-step logits (those live on the caller's stream)
+  e->last_groups = 1;
+  if (batch >= 128 && !(flags & (MT3_DECODE_NO_GRAPH | MT3_DECODE_SINGLE_STREAM)) && ((flags >> 8) & 0xF) == 0 &&
+      e->cfg.decode_chains <= 1 && !(c.options & MT3_OPT_NO_CU_PARTITION) && debug_skip == 0 && !d_forced &&
+      !d_step_logits && !d_first_logits) {
+    int ran = 0;
+    const int prc = decode_partitioned(e, batch, num_steps, flags, skip, 2, &ran, s);
+    if (prc == MT3_OK) {
+      e->last_groups = 2;
+      e->last_used_graph = 0;
+      if (beam1) MT3_TRY(mt3k::launch_beam1_finalize(e->ids, L, e->beam_len, batch, s));
+      MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
+      if (h_steps_run) *h_steps_run = ran;
+      return MT3_OK;
+    }
+    if (prc != MT3_ERR_CAPACITY) return prc;      // a launch failed: report it
+    ++e->part_failed;                             // the masked streams could not be created: single stream, recorded
   }
   bool use_graph = !(flags & MT3_DECODE_NO_GRAPH);
   const int chains = chains_for(e, batch, (flags >> 8) & 0xF);
@@ -1243,6 +1347,8 @@ int mt3_engine_status(const mt3_engine* e, int32_t what) {
     case MT3_STATUS_DENSE_FP8: return e->dense_fp8 ? 1 : 0;
     case MT3_STATUS_Q_FOLD: return e->q_fold ? 1 : 0;
     case MT3_STATUS_QKV_FOLD: return e->qkv_fold ? 1 : 0;
+    case MT3_STATUS_LAST_DECODE_GROUPS: return e->last_groups;
+    case MT3_STATUS_PARTITION_FALLBACKS: return e->part_failed;
     default: return mt3::fail(MT3_ERR_INVALID, "mt3_engine_status: unknown item");
   }
 }

@@ -202,17 +202,19 @@ class Transformer:
         return enc
 
     def decode(self, num_steps: Optional[int] = None, use_graph: bool = True, early_exit: bool = False,
-               return_first_logits: bool = False, chains: int = 0, beam1: bool = False):
+               return_first_logits: bool = False, chains: int = 0, beam1: bool = False, single_stream: bool = False):
         """Decode for the batch of the last `encode`: greedy until EOS, or with `beam1` the selection
         rule of t5x beam_search(num_decodes=1, alpha=0.6) that the reference's predict_tokens runs.
-        Returns int32 CUDA [B, L] ids (and the step-0 logits [B, V] if asked)."""
+        Returns int32 CUDA [B, L] ids (and the step-0 logits [B, V] if asked).  Batches of >= 128 rows run
+        CU-partitioned (two row groups on CU-masked streams, include/mt3_hip.h) unless `single_stream`."""
         import torch
         B, L = self._batch, self.max_decode_length
         ids = torch.empty((B, L), device="cuda", dtype=torch.int32)
         logits = torch.empty((B, self.config.vocab_size), device="cuda", dtype=torch.float32) \
             if return_first_logits else None
         flags = (0 if use_graph else _lib.DECODE_NO_GRAPH) | (_lib.DECODE_EARLY_EXIT if early_exit else 0) | \
-            ((chains & 0xF) << 8) | (_lib.DECODE_BEAM1 if beam1 else 0)
+            ((chains & 0xF) << 8) | (_lib.DECODE_BEAM1 if beam1 else 0) | \
+            (_lib.DECODE_SINGLE_STREAM if single_stream else 0)
         ran = C.c_int32()
         _lib.check(self._lib.mt3_engine_decode(self._h, B, num_steps or L, flags, ids.data_ptr(),
                                                logits.data_ptr() if logits is not None else None, C.byref(ran),

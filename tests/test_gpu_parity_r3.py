@@ -360,3 +360,43 @@ def test_folded_qkv_projection_bf16_and_fp8_caches_against_the_separate_launches
             d = _rel_rows(outs[name], outs["separate"])
             print(f"kv {kv or 'bf16'} [{name}] vs separate launches: max {d.max():.3e} median {np.median(d):.3e}")
             assert d.max() < (2e-2 if not kv else 5e-2) and np.median(d) < 8e-3, (kv, name, d.max(), np.median(d))
+
+
+def test_cu_partitioned_decode_schedule_is_bit_identical():
+    """Batches of >= 128 rows decode as two row groups on CU-masked streams, one host thread each (include/mt3_hip.h,
+    "Schedule").  Rows are independent, so the ids must equal the single-stream graph-replayed schedule bit for bit:
+    greedy, beam-1, with early exit (every group stops on its own rows), odd batch sizes; the experiment entry
+    (mt3_debug_engine_decode_split) as well."""
+    cfg = network.T5Config(dtype="bfloat16", num_encoder_layers=2, num_decoder_layers=3)
+    params = network.init_random_params(cfg, seed=5, norm_scale_jitter=0.1)
+    k = params["decoder/logits_dense/kernel"].copy()
+    k[:, 1] *= 3.0                                           # rows emit EOS at different steps
+    params["decoder/logits_dense/kernel"] = k
+    B = 131
+    from mt3_amd import spectrograms, synthetic
+    lm = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(B, seed=8), None)
+    eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B)
+    eng.load_params(params)
+    eng.encode(lm)
+    for kw in (dict(), dict(beam1=True)):
+        a = eng.decode(num_steps=96, single_stream=True, **kw)
+        assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 1 and eng.status(_lib.STATUS_LAST_DECODE_USED_GRAPH) == 1
+        b = eng.decode(num_steps=96, **kw)
+        assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 2, "a batch of 131 rows should run CU-partitioned"
+        assert eng.status(_lib.STATUS_PARTITION_FALLBACKS) == 0
+        assert torch.equal(a, b), kw
+    full = eng.decode(num_steps=L, single_stream=True)
+    ee = eng.decode(num_steps=L, early_exit=True)
+    assert eng.steps_run <= L and torch.equal(ee, full)
+    assert bool((full == 1).any()), "the case should contain rows that emit EOS"
+    ids, ms = eng.debug_decode_split(num_steps=96, groups=2, mask_mode=1)
+    assert torch.equal(ids[:, :96], eng.decode(num_steps=96, single_stream=True)[:, :96])
+    # a small batch stays on the caller's stream, and the option switches the schedule off for good
+    eng.encode(lm[:64])
+    eng.decode(num_steps=8)
+    assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 1
+    e2 = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=_lib.OPT_NO_CU_PARTITION)
+    e2.load_params(params)
+    e2.encode(lm)
+    c = e2.decode(num_steps=96)
+    assert e2.status(_lib.STATUS_LAST_DECODE_GROUPS) == 1 and torch.equal(c[:, :96], full[:, :96])

@@ -10,10 +10,12 @@ except Exception as e:
     sys.exit(0)
 r = d.get("roofline") or {}
 print("HEADLINE %s %.1f %s  ms/step %.1f  n_gpus %d steps %d | attn %.2f us frac %.3f traffic %s | cross %.2f us | small %.1f us/step "
-      "| whole-step hbm %.3f" % (d["dtype"], d["value"], d["unit"], d["ms_per_step"], d["n_gpus"], d["steps"],
-                               r.get("avg_launch_us", 0), r.get("frac", 0), r.get("traffic"),
-                               (r.get("cross_attn") or {}).get("avg_launch_us", 0), r.get("small_kernel_us_per_step", 0),
-                               r.get("whole_step_hbm_frac", 0)))
+      "| whole-step hbm %.3f (product schedule: %.1f ms, %.3f)" % (
+          d["dtype"], d["value"], d["unit"], d["ms_per_step"], d["n_gpus"], d["steps"],
+          r.get("avg_launch_us", 0), r.get("frac", 0), r.get("traffic"),
+          (r.get("cross_attn") or {}).get("avg_launch_us", 0), r.get("small_kernel_us_per_step", 0),
+          r.get("whole_step_hbm_frac", 0), r.get("decode_ms_product_schedule", 0),
+          r.get("whole_step_hbm_frac_product_schedule", 0)))
 for k, v in (d.get("extra") or {}).items():
     if not isinstance(v, dict):
         continue
@@ -27,9 +29,9 @@ for k, v in (d.get("extra") or {}).items():
                                  if a in ("value", "ms_per_step", "steps", "ms", "achieved", "frac", "encoder_ms",
                                           "segments_per_s", "traffic", "error"))
     if rr:
-        s += " | attn %.2f us frac %.3f traffic %s small %.1f us/step whole-step %.3f" % (
+        s += " | attn %.2f us frac %.3f traffic %s small %.1f us/step whole-step %.3f (product %.3f)" % (
             rr["avg_launch_us"], rr["frac"], rr.get("traffic"), rr.get("small_kernel_us_per_step", 0),
-            rr["whole_step_hbm_frac"])
+            rr["whole_step_hbm_frac"], rr.get("whole_step_hbm_frac_product_schedule", 0))
     print(s[:600])
 c = d.get("cpu_baseline")
 if c:
