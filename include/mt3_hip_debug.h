@@ -49,10 +49,11 @@ int mt3_debug_engine_poison_caches(mt3_engine* e, int32_t pattern, int32_t cross
  *   XCD_N_MAJOR: decode-sized GEMM tiles dealt to the XCDs by weight-column slice instead of by row block:
  *                0 = automatically for weight matrices above 3 MB, 1 = always, 2 = never
  *   NO_K768_SPLIT: the K = 768 decode tiles (base.gin shape) always take K in one slice
+ *   NO_GLDS_256: encoder GEMMs never take the 256 x 128 LDS-DMA tile
  *   PREFETCH2: decode-sized multi-slice GEMM tiles keep TWO K slices in flight instead of one (measured slower) */
 enum { MT3_DEBUG_KNOB_DEC_ATTN_WAVES = 0, MT3_DEBUG_KNOB_DEC_ATTN_FP8_WAVES = 1, MT3_DEBUG_KNOB_NO_LDS_DMA_GEMM = 2,
        MT3_DEBUG_KNOB_F32_SPLIT_K = 3, MT3_DEBUG_KNOB_XCD_N_MAJOR = 4, MT3_DEBUG_KNOB_PREFETCH2 = 5,
-       MT3_DEBUG_KNOB_NO_K768_SPLIT = 6 };
+       MT3_DEBUG_KNOB_NO_K768_SPLIT = 6, MT3_DEBUG_KNOB_NO_GLDS_256 = 7 };
 int mt3_debug_set_knob(int32_t knob, int32_t value);
 
 #ifdef __cplusplus

@@ -1185,7 +1185,10 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
   // ---- the CU-partitioned schedule (see mt3_engine::part_stream): batches of >= 128 rows, unless the caller asked for
   // one stream / direct launches / graph chains, or wants per-step logits (those live on the caller's stream)
   e->last_groups = 1;
-  if (batch >= 128 && !(flags & (MT3_DECODE_NO_GRAPH | MT3_DECODE_SINGLE_STREAM)) && ((flags >> 8) & 0xF) == 0 &&
+  // (bf16 operands only: the f32 engine's decode GEMMs are bound by each CU's L1 bandwidth, not by latency -- halving
+  // the CUs per group stretches them by more than the overlap returns: measured 1238 against 1213 ms per step)
+  if (batch >= 128 && c.compute_dtype == MT3_BF16 && !(flags & (MT3_DECODE_NO_GRAPH | MT3_DECODE_SINGLE_STREAM)) &&
+      ((flags >> 8) & 0xF) == 0 &&
       e->cfg.decode_chains <= 1 && !(c.options & MT3_OPT_NO_CU_PARTITION) && debug_skip == 0 && !d_forced &&
       !d_step_logits && !d_first_logits) {
     int ran = 0;

@@ -550,17 +550,21 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
 // read of logical chunk q of row r looks at slot q ^ ((r >> 2) & 3) -- the 16 rows of a ds_read_b128 lane group
 // then cover all 16 sixteen-byte bank slots.  The fused RMSNorm comes from the producer's partial sums of squares
 // (norm 2), folded after the K loop.
-template <int EPI, int NPV>
+// BM_ = 256 (round 3; STORE / GEGLU / HEADS epilogues): a wave owns 128 x 64 outputs (8 x 4 fragments), so a K slice costs
+// 12 fragment reads for 32 MFMAs instead of 8 for 16 and the A panel is shared by twice the rows: the 128 x 128 tile's
+// K loop alone ran at 55 % of the matrix peak with LDS reads and MFMAs both at ~100 % of their own pipes.
+template <int EPI, int NPV, int BM_ = 128>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   using CT = __bf16;
-  constexpr int BM = 128, BN = 128, BK = MT3_GLDS_BK, FM = 4, FN = 4;
+  constexpr int BM = BM_, BN = 128, BK = MT3_GLDS_BK, FM = BM / 32, FN = 4;
+  static_assert(BM == 128 || (BM == 256 && EPI != MT3_EPI_RESID && MT3_GLDS_BK == 32), "tile height");
   constexpr int ROWB = BK * 2;                       // bytes per tile row: 64 (4 chunks) or 128 (8 chunks)
   constexpr int CPROW = ROWB / 16;                   // 16-byte chunks per row
   constexpr int RPP = 64 / CPROW;                    // rows per 1 KB DMA piece: 16 or 8
   constexpr int KSH = BK == 32 ? 2 : 1;              // swizzle key of row r: (r >> KSH) & (CPROW - 1)
   constexpr int STAGE_B = (BM + BN) * ROWB;          // 16 / 32 KB per stage: A rows, then W rows
   constexpr int NS = MT3_GLDS_NS, DEPTH = NS - 1;    // ring stages / K slices in flight
-  constexpr int PPW = 64 / RPP;                      // 1 KB pieces per wave per stage: 4 or 8
+  constexpr int PPW = (BM + BN) / RPP / 4;           // 1 KB pieces per wave per stage: 4 (8 with 128-byte rows), 6 at BM = 256
   static_assert(BK == 32 || BK == 64, "K slice");
   // ONE shared object (a second one makes hipcc drain the DMA queue before every k-step's first ds_read)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE_B + BM * 4];
@@ -593,14 +597,14 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     for (int u = 0; u < NPV; ++u) pv[u] = p4[u < npv ? u : npv - 1];
   }
 
-  // ---- DMA plan: a stage is 16 (32) one-KB pieces, half of A, half of W.  Waves 0,1 bring A rows 0-63 / 64-127,
-  // waves 2,3 W rows 0-63 / 64-127, PPW pieces each; lane i of a piece: row = RPP * piece + i / CPROW, slot = i % CPROW.
-  const bool is_a = wave < 2;
-  const int half = wave & 1;
+  // ---- DMA plan: a stage is (BM + BN) / RPP one-KB pieces: the A rows, then the W rows; wave w brings pieces
+  // w * PPW .. w * PPW + PPW - 1; lane i of a piece: row = RPP * piece + i / CPROW (of the A | W row stack), slot = i % CPROW.
   const unsigned char* src[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
-    const int r = half * 64 + j * RPP + lane / CPROW;                    // row inside the operand tile
+    const int rr = (wave * PPW + j) * RPP + lane / CPROW;                // row inside the A | W stack
+    const bool is_a = rr < BM;                                           // (piece-uniform: BM is a multiple of RPP)
+    const int r = is_a ? rr : rr - BM;                                   // row inside the operand tile
     const int chunk = (lane % CPROW) ^ ((r >> KSH) & (CPROW - 1));
     if (is_a) {
       int row = m0 + r;
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
       src[j] = static_cast<const unsigned char*>(gW) + (static_cast<size_t>(n0 + r) * gK + chunk * 8) * 2;
     }
   }
-  const int piece0 = (is_a ? 0 : 2 * PPW) + half * PPW;
+  const int piece0 = wave * PPW;
   auto issue = [&](int kt, int stage) {
     const int dst0 = __builtin_amdgcn_readfirstlane(stage * STAGE_B + piece0 * 1024);
 #pragma unroll
@@ -629,7 +633,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   const int frag_row = lane & 15, frag_g = lane >> 4;
   // byte offsets of this lane's fragment pieces inside a stage: logical chunk 4 kk + frag_g of row frag_row (+ 16 i)
   const int key = (frag_row >> KSH) & (CPROW - 1);
-  const int a_off = (wm * 64 + frag_row) * ROWB, b_off = BM * ROWB + (wn * 64 + frag_row) * ROWB;
+  const int a_off = (wm * (BM / 2) + frag_row) * ROWB, b_off = BM * ROWB + (wn * 64 + frag_row) * ROWB;
 
   const int KT = gK / BK;
 #pragma unroll
@@ -640,9 +644,11 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
     const int ahead = KT - 1 - t < DEPTH - 1 ? KT - 1 - t : DEPTH - 1;
     if (DEPTH > 2 && ahead >= 2) {
       if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     } else if (DEPTH > 1 && ahead == 1) {
       if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if constexpr (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -704,23 +710,29 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
                                                      static_cast<size_t>(grow < gM ? grow : gM - 1) * g.ldo + n0 + (tid & 31) * 4);
       }
   }
+  // passes of 64 rows: pass hm = rows [64 hm, 64 hm + 64) of the tile = fragments (hm % PW) * 4 .. + 3 of the waves with
+  // wm == hm / PW (PW = passes per wave row: 1 at BM = 128, 2 at BM = 256); the fragment index must be static
+  constexpr int PW = FM / 4;
 #pragma unroll 1
-  for (int hm = 0; hm < 2; ++hm) {
-    __syncthreads();                     // the ring / the previous half's image is no longer read (rs_x is visible)
-    if (wm == hm) {
+  for (int hw = 0; hw < 2; ++hw)
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+  for (int hp = 0; hp < PW; ++hp) {
+    const int hm = hw * PW + hp;
+    __syncthreads();                     // the ring / the previous pass's image is no longer read (rs_x is visible)
+    if (wm == hw) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = i * 16 + frag_g * 4 + r;                // (row >> 2) & 3 == frag_g
             const int col = (wn * 64 + j * 16 + frag_row) ^ (frag_g << 4);
-            tile[row * BN + col] = acc[i][j][r];
+            tile[row * BN + col] = acc[hp * 4 + i][j][r];
           }
     }
     __syncthreads();
-    const int mh = m0 + hm * 64;                                     // first global row of this half
+    const int mh = m0 + hm * 64;                                     // first global row of this pass
     if constexpr (EPI == MT3_EPI_GEGLU) {
       // tile columns [32q, 32q + 16) = gate, [32q + 16, 32q + 32) = linear of hidden units (n0 >> 1) + 16q + 0..15
       CT* const out = static_cast<CT*>(g.out);
@@ -750,7 +762,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
         const int col = n0 + c4;
         if constexpr (EPI == MT3_EPI_RESID) {
           f32x4* xp = reinterpret_cast<f32x4*>(static_cast<float*>(g.out) + static_cast<size_t>(grow) * g.ldo + col);
-          const f32x4 x = hm ? xpre[1][p] : xpre[0][p];   // (plain accesses: non-temporal ones made the read-modify-write 10-20 % slower)
+          const f32x4 x = hw ? xpre[1][p] : xpre[0][p];   // (plain accesses: non-temporal ones made the read-modify-write 10-20 % slower)
           v.x += x.x, v.y += x.y, v.z += x.z, v.w += x.w;
           *xp = f32x4{v.x, v.y, v.z, v.w};
           if (g.out_ct) {
@@ -787,6 +799,18 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
 
 template <int EPI>
 static int launch_glds(const GemmArgs& g, hipStream_t s) {
+  if constexpr (EPI != MT3_EPI_RESID && MT3_GLDS_BK == 32) {
+    // 256-row tiles when the launch still fills the chip twice over with them (the encoder at B >= 16)
+    const int grid256 = ((g.M + 255) / 256) * (g.N / 128);
+    if (!g_knobs.no_glds_256 && grid256 >= 512) {
+      if (g.a_ss && g.K > 512)
+        hipLaunchKernelGGL((gemm_glds_kernel<EPI, 16, 256>), dim3(grid256), dim3(256), 0, s, g);
+      else
+        hipLaunchKernelGGL((gemm_glds_kernel<EPI, 8, 256>), dim3(grid256), dim3(256), 0, s, g);
+      MT3_HIP_CHECK(hipGetLastError());
+      return MT3_OK;
+    }
+  }
   const int grid = ((g.M + 127) / 128) * (g.N / 128);
   if (g.a_ss && g.K > 512)
     hipLaunchKernelGGL((gemm_glds_kernel<EPI, 16>), dim3(grid), dim3(256), 0, s, g);

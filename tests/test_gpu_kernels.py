@@ -222,6 +222,56 @@ def test_gemm_glds_geglu_and_heads():
     assert rel_err(o2, r2) < 6e-3
 
 
+@pytest.mark.parametrize("tall", [True, False])
+def test_gemm_glds_256_row_tile_store_geglu_heads(tall):
+    """The 256 x 128 LDS-DMA tile (round 3; taken when a launch has >= 512 of them) against float64 on the same bf16
+    operands, ragged M (the last tile holds 37 rows), every epilogue it serves, K = 512 and K = 1024 (norm-2 partial
+    sums in 16 registers); `tall=False` forces the 128 x 128 tile through the debug knob: both must agree with the
+    reference, and with each other bit for bit (same per-element summation order)."""
+    _lib.check(lib().mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_GLDS_256, 0 if tall else 1))
+    try:
+        g = torch.Generator(device="cuda").manual_seed(77)
+        outs = []
+        for (M, N, K) in ((256 * 57 + 37, 1152, 512), (256 * 40 + 5, 2048, 1024)):
+            x = torch.randn(M, K, device="cuda", generator=g) * torch.rand(M, 1, device="cuda", generator=g) * 4
+            Wt = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+            ct, ss = _split(x)
+            rs = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-6)
+            out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+            run_gemm_ex(ct, 2, Wt, out, M, N, K, _lib.EPI_STORE, a_ss=ss)
+            ref = (ct.double() @ Wt.double().T) * rs
+            assert rel_err(out, ref) < 6e-3, (M, N, K, rel_err(out, ref))
+            worst = ((out.double() - ref).abs().amax(1) / ref.abs().amax(1)).max()
+            assert float(worst) < 2e-2, float(worst)                     # no row is garbage (ragged tail, tile seams)
+            outs.append(out)
+            # GEGLU on the same operands: N columns = interleaved gate / linear groups of 16
+            F = N // 2
+            og = torch.zeros(M, F, device="cuda", dtype=torch.bfloat16)
+            run_gemm_ex(ct, 2, Wt, og, M, N, K, _lib.EPI_GEGLU, a_ss=ss)
+            full = (ct.double() @ Wt.double().T) * rs
+            gate = full.view(M, F // 16, 2, 16)[:, :, 0].reshape(M, F)
+            lin = full.view(M, F // 16, 2, 16)[:, :, 1].reshape(M, F)
+            assert rel_err(og, gelu_tanh(gate) * lin) < 8e-3
+            outs.append(og)
+        B, T, H, K = 86, 256, 6, 512                                     # 86 * 256 rows = 86 tall tiles x 6 columns = 516
+        A = torch.randn(B * T, K, device="cuda", generator=g).to(torch.bfloat16)
+        W2 = (torch.randn(2 * H * 64, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+        o2 = torch.zeros(2, B, H, T, 64, device="cuda", dtype=torch.bfloat16)
+        run_gemm_ex(A, 0, W2, o2, B * T, 2 * H * 64, K, _lib.EPI_HEADS, seq_len=T)
+        r2 = (A.double() @ W2.double().T).view(B, T, 2, H, 64).permute(2, 0, 3, 1, 4)
+        assert rel_err(o2, r2) < 6e-3
+        outs.append(o2)
+        test_gemm_glds_256_row_tile_store_geglu_heads.results = getattr(
+            test_gemm_glds_256_row_tile_store_geglu_heads, "results", {})
+        test_gemm_glds_256_row_tile_store_geglu_heads.results[tall] = [o.clone() for o in outs]
+        both = test_gemm_glds_256_row_tile_store_geglu_heads.results
+        if True in both and False in both:
+            for a, b in zip(both[True], both[False]):
+                assert torch.equal(a, b), "the 256-row and the 128-row tile must produce identical outputs"
+    finally:
+        _lib.check(lib().mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_GLDS_256, 0))
+
+
 # ------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("dtype,T", [(BF16, 256), (BF16, 512), (F32, 256), (F32, 512)])
 def test_encoder_attention(dtype, T):

@@ -67,6 +67,18 @@ PY
       timeout ${AB_TIMEOUT:-600} python tools/ab_decode.py $AB_ARGS > gpurun_out/ab_decode.log 2>&1
       echo "exit $? : ab_decode $AB_ARGS"; grep -v "^/opt\|Warning" gpurun_out/ab_decode.log | tail -20
       ;;
+    enc)
+      timeout 300 python tools/ab_encoder.py > gpurun_out/ab_encoder.log 2>&1
+      echo "exit $? : ab_encoder"; grep -v "^/opt\|Warning" gpurun_out/ab_encoder.log | tail -8
+      rm -rf gpurun_out/prof_enc; mkdir -p gpurun_out/prof_enc
+      cd /tmp
+      timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_enc" -o enc -- python "$R/tools/ab_encoder.py" > "$R/gpurun_out/ab_encoder_prof.log" 2>&1
+      echo "exit $? : rocprof ab_encoder"
+      cd "$R"
+      f=$(find gpurun_out/prof_enc -name "enc_kernel_stats.csv" | head -1)
+      [ -n "$f" ] && cp "$f" gpurun_out/r3_encoder_kernel_stats.csv && head -24 "$f" | cut -c1-170
+      find gpurun_out/prof_enc -name "*kernel_trace.csv" -delete; find gpurun_out/prof_enc -name "*.db" -delete
+      ;;
     split)
       timeout ${SPLIT_TIMEOUT:-240} python tools/ab_split.py > gpurun_out/ab_split.log 2>&1
       echo "exit $? : ab_split"; grep -v "^/opt\|Warning" gpurun_out/ab_split.log | tail -14
