@@ -253,7 +253,7 @@ def test_gemm_glds_256_row_tile_store_geglu_heads(tall):
             lin = full.view(M, F // 16, 2, 16)[:, :, 1].reshape(M, F)
             assert rel_err(og, gelu_tanh(gate) * lin) < 8e-3
             outs.append(og)
-        B, T, H, K = 86, 256, 6, 512                                     # 86 * 256 rows = 86 tall tiles x 6 columns = 516
+        B, T, H, K = 171, 256, 6, 512                                    # 171 tall tiles x 6 columns = 1026 >= 1024
         A = torch.randn(B * T, K, device="cuda", generator=g).to(torch.bfloat16)
         W2 = (torch.randn(2 * H * 64, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
         o2 = torch.zeros(2, B, H, T, 64, device="cuda", dtype=torch.bfloat16)
