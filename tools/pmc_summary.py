@@ -70,7 +70,10 @@ def entry(f_kib, w_kib, n_keys, append, kind):
 
 
 # launch order of pmc_attn.py per cache format: (1024, 513, 129) x 2 rounds x 4 layers of self/append, then 8 cross
-KIND = {"bf16": lambda n, g: "dec_attn_kernel<__bf16" in n, "f32": lambda n, g: "dec_attn_kernel<float" in n,
+# (rocprofv3 prints the __bf16 instantiations either mangled -- ...dec_attn_kernelIDF16b... -- or mis-demangled as
+# "dec_attn_kernel<bool _Accum, ...>")
+KIND = {"bf16": lambda n, g: "dec_attn_kernel" in n and "dec_attn_kernel<float" not in n,
+        "f32": lambda n, g: "dec_attn_kernel<float" in n,
         "fp8": lambda n, g: "dec_attn_fp8_kernel" in n}
 for kind, pred in KIND.items():
     af, aw = pick(fetch, pred), pick(write, pred)

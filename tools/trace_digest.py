@@ -30,8 +30,9 @@ for n, (c, us) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:24]:
 # (B*H workgroups = the largest grid); the roofline's avg_launch_us must agree with the latter.
 groups = defaultdict(list)
 for s, e, n, grid, wg in rows:
-    if "dec_attn_kernel" in n:
-        kind = "cross(no append)" if "Lb0E" in n else "self(append)"
+    if "dec_attn_kernel" in n or "dec_attn_fp8_kernel" in n:
+        # APPEND is the second template argument: mangled ...IDF16bLb0E... / demangled "<float, false, ..."
+        kind = "cross(no append)" if ("Lb0ELi" in n or "<float, false" in n or "<__bf16, false" in n) else "self(append)"
         groups[(kind, grid // max(wg, 1))].append((e - s) / 1e3)
 for (kind, wgs), d in sorted(groups.items()):
     line = "dec_attn %s, %d workgroups: %d launches, avg %.3f us" % (kind, wgs, len(d), sum(d) / len(d))
