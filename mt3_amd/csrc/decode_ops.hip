@@ -315,6 +315,18 @@ int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride,
   return MT3_OK;
 }
 
+// busy-wait on the device for ~us microseconds (one lane; wall_clock64 ticks at 100 MHz): the stagger of the
+// CU-partition experiment (mt3_debug_engine_decode_split)
+__global__ void delay_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+int launch_delay_us(int us, hipStream_t s) {
+  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, s, static_cast<long long>(us) * 100);
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+
 // one float into device memory from a kernel ARGUMENT (no host buffer has to outlive the call)
 __global__ void set_float_kernel(float* dst, float v) { *dst = v; }
 int launch_set_float(float* dst, float v, hipStream_t s) {

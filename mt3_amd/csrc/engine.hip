@@ -1260,8 +1260,12 @@ int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_step
   const mt3_engine_config& c = e->cfg;
   if (batch <= 0 || batch != e->cur_batch || num_steps <= 0 || num_steps > c.max_decode_len || !d_ids)
     return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: bad batch / steps / ids");
-  if (n_groups < 2 || n_groups > 4 || batch / n_groups < 16 || mask_mode < 0 || mask_mode > 2)
-    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: 2 .. 4 groups of >= 16 rows, mask_mode 0 .. 2");
+  // mask_mode 3 .. 6: interleaved masks + group g starts after a device-side delay of g x {8, 15, 25, 40} us
+  if (n_groups < 2 || n_groups > 4 || batch / n_groups < 16 || mask_mode < 0 || mask_mode > 6)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: 2 .. 4 groups of >= 16 rows, mask_mode 0 .. 6");
+  static const int kStagger[7] = {0, 0, 0, 8, 15, 25, 40};
+  const int stagger_us = kStagger[mask_mode];
+  if (mask_mode > 2) mask_mode = 2;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = c.max_decode_len;
   MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, static_cast<size_t>(batch) * 4, s));
@@ -1302,6 +1306,7 @@ int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_step
         (void)hipSetDevice(dev);
         int row0, rows;
         chain_rows(batch, n_groups, g, &row0, &rows);
+        if (stagger_us && g) rcs[g] = mt3k::launch_delay_us(g * stagger_us, gs[g]);
         for (int t = 0; t < num_steps && rcs[g] == MT3_OK; ++t) rcs[g] = enqueue_chain_step(e, row0, rows, g, batch, 0, gs[g]);
         if (rcs[g] != MT3_OK) errs[g] = mt3_last_error();
         const hipError_t he = hipStreamSynchronize(gs[g]);

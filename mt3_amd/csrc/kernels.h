@@ -113,6 +113,7 @@ int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride,
                        float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam,
                        const int* forced, int forced_stride, const RowProj& rp, hipStream_t s);
 int launch_set_float(float* dst, float v, hipStream_t s);
+int launch_delay_us(int us, hipStream_t s);
 int launch_beam1_finalize(int* ids, int L, const int* beam_len, int B, hipStream_t s);
 int launch_ids_to_tokens(const int* ids, int B, int L, int num_regular, int* out, hipStream_t s);
 

@@ -33,12 +33,18 @@ with torch.cuda.stream(stream):
     torch.cuda.synchronize()
     print("one chain, direct launches, one host thread   : %8.1f ms  ids equal %s" % ((time.perf_counter() - t0) * 1e3,
                                                                                   bool(torch.equal(d, ref))), flush=True)
-    for groups in (2, 3, 4):
-        for mode, label in ((0, "no CU mask"), (1, "contiguous CU-mask blocks"), (2, "interleaved CU-mask bits")):
+    cases = [(g, m, l) for g in (2, 3, 4) for m, l in ((0, "no CU mask"), (1, "contiguous CU-mask blocks"),
+                                                        (2, "interleaved CU-mask bits"))]
+    cases += [(2, m, "interleaved, stagger %d us" % us) for m, us in ((3, 8), (4, 15), (5, 25), (6, 40))]
+    cases += [(2, 2, "interleaved CU-mask bits (again)")]
+    if os.environ.get("AB_SPLIT_ONLY"):
+        cases = [c for c in cases if c[0] == 2 and c[1] >= 2]
+    for groups, mode, label in cases:
+        if True:
             try:
                 eng.debug_decode_split(num_steps=8, groups=groups, mask_mode=mode)
                 ids, ms = eng.debug_decode_split(num_steps=1024, groups=groups, mask_mode=mode)
-                print("%d groups, %-26s            : %8.1f ms  ids equal %s" % (groups, label, ms, bool(torch.equal(ids, ref))),
+                print("%d groups, %-34s    : %8.1f ms  ids equal %s" % (groups, label, ms, bool(torch.equal(ids, ref))),
                       flush=True)
             except Exception as ex:
                 print("%d groups, %s: FAILED %r" % (groups, label, ex), flush=True)

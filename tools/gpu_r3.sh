@@ -6,6 +6,7 @@
 #   prof   rocprofv3 --kernel-trace --stats of `bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras` for the bf16
 #          headline and for --dtype float32 -> gpurun_out/prof/{r3,r3_f32}_kernel_stats.csv + trace digests
 #   bench  python bench.py $BENCH_ARGS -> gpurun_out/bench_r3.log
+#   pmcenc tools/gpu_pmc_enc.sh: SQ / MFMA counter passes over the encoder -> gpurun_out/pmc_enc/summary.json
 #   ab     python tools/ab_decode.py $AB_ARGS (decode-loop variants, one process) -> gpurun_out/ab_decode.log
 # Everything lands under gpurun_out/; copy what should be judged into profiles/.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -78,6 +79,10 @@ PY
       f=$(find gpurun_out/prof_enc -name "enc_kernel_stats.csv" | head -1)
       [ -n "$f" ] && cp "$f" gpurun_out/r3_encoder_kernel_stats.csv && head -24 "$f" | cut -c1-170
       find gpurun_out/prof_enc -name "*kernel_trace.csv" -delete; find gpurun_out/prof_enc -name "*.db" -delete
+      ;;
+    pmcenc)
+      bash tools/gpu_pmc_enc.sh > gpurun_out/pmc_enc.log 2>&1
+      echo "exit $? : pmc_enc"; grep "mfma_util" gpurun_out/pmc_enc.log | cut -c1-230 | tail -16
       ;;
     split)
       timeout ${SPLIT_TIMEOUT:-240} python tools/ab_split.py > gpurun_out/ab_split.log 2>&1

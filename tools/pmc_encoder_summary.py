@@ -18,10 +18,12 @@ def short(name):
         epi = ["STORE", "RESID", "GEGLU", "POS", "F32", "HEADS"][int(m.group(6))]
         return "gemm %sx%sx%s %s%s%s" % (m.group(1), m.group(2), m.group(3), "f32A " if m.group(4) == "1" else "",
                                          "norm " if m.group(5) == "1" else "", epi)
-    m = re.search(r"gemm_(glds|mx8)_kernel<(\d+), (\d+)>", name) or re.search(r"gemm_(glds|mx8)_kernelILi(\d+)ELi(\d+)", name)
+    m = re.search(r"gemm_(glds|mx8)_kernel<(\d+), (\d+)(?:, (\d+))?>", name) or \
+        re.search(r"gemm_(glds|mx8)_kernelILi(\d+)ELi(\d+)(?:ELi(\d+))?", name)
     if m:
         epi = ["STORE", "RESID", "GEGLU", "POS", "F32", "HEADS"][int(m.group(2))]
-        return ("gemm LDS-DMA bf16 128x128x32 " if m.group(1) == "glds" else "gemm MXFP8 128x128x128 ") + epi
+        bm = m.group(4) or "128"
+        return ("gemm LDS-DMA bf16 %sx128x32 " % bm if m.group(1) == "glds" else "gemm MXFP8 128x128x128 ") + epi
     if "mx8_quantize" in name:
         return "mx8_quantize"
     if "enc_attn" in name:
