@@ -24,10 +24,15 @@ with torch.cuda.stream(stream):
     for _ in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ref = eng.decode(num_steps=1024)
+        ref = eng.decode(num_steps=1024, single_stream=True)
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) * 1e3)
-    print("one chain, hipGraph replay (product)          : %8.1f ms" % best, flush=True)
+    print("one chain, hipGraph replay, one stream        : %8.1f ms" % best, flush=True)
+    t0 = time.perf_counter()
+    d = eng.decode(num_steps=1024)
+    torch.cuda.synchronize()
+    print("mt3_engine_decode as shipped (CU-partitioned) : %8.1f ms  ids equal %s" % ((time.perf_counter() - t0) * 1e3,
+                                                                                  bool(torch.equal(d, ref))), flush=True)
     t0 = time.perf_counter()
     d = eng.decode(num_steps=1024, use_graph=False)
     torch.cuda.synchronize()
