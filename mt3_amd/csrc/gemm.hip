@@ -864,6 +864,12 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
   constexpr int KG = CTraits<CT>::KGROUP;
   if (small) {
     const bool deep = g.K % (16 * KG) == 0;
+    if constexpr (EPI == kEpiResidS) {
+      // the two-source fold launch (N = emb + 4 HD = 2048 columns, K up to 1536): 32 x 64 tiles move 25 % fewer operand
+      // bytes through each CU's L1 than 32 x 32 ones (96 against 2 x 64 rows per 2048 outputs), one workgroup per CU
+      if (deep && g.N % 64 == 0 && g.n_split % 64 == 0 && !g_knobs.no_fold_wide_tile)
+        return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI>(g, s);
+    }
     if constexpr (!NORM && !A_F32 && KG == 16 && EPI != MT3_EPI_HEADS && EPI != MT3_EPI_POS) {
       // f32 operands arriving in the compute type (the split residual form / plain activations): eight waves per
       // tile, K-groups split two ways (see gemm_kernel; halves the staging registers per thread as well)
