@@ -51,12 +51,12 @@ int mt3_debug_engine_poison_caches(mt3_engine* e, int32_t pattern, int32_t cross
  *                0 = automatically for weight matrices above 3 MB, 1 = always, 2 = never
  *   NO_K768_SPLIT: the K = 768 decode tiles (base.gin shape) always take K in one slice
  *   NO_GLDS_256: encoder GEMMs never take the 256 x 128 LDS-DMA tile
- *   NO_FOLD_WIDE_TILE: the decoder's two-source fold launch on 32 x 32 tiles instead of 32 x 64
+ *   FOLD_WIDE_TILE: the decoder's two-source fold launch on 32 x 64 tiles instead of 32 x 32 (measured slower)
  *   PREFETCH2: decode-sized multi-slice GEMM tiles keep TWO K slices in flight instead of one (measured slower) */
 enum { MT3_DEBUG_KNOB_DEC_ATTN_WAVES = 0, MT3_DEBUG_KNOB_DEC_ATTN_FP8_WAVES = 1, MT3_DEBUG_KNOB_NO_LDS_DMA_GEMM = 2,
        MT3_DEBUG_KNOB_F32_SPLIT_K = 3, MT3_DEBUG_KNOB_XCD_N_MAJOR = 4, MT3_DEBUG_KNOB_PREFETCH2 = 5,
        MT3_DEBUG_KNOB_NO_K768_SPLIT = 6, MT3_DEBUG_KNOB_NO_GLDS_256 = 7,
-       MT3_DEBUG_KNOB_NO_FOLD_WIDE_TILE = 8 };
+       MT3_DEBUG_KNOB_FOLD_WIDE_TILE = 8 };
 int mt3_debug_set_knob(int32_t knob, int32_t value);
 
 #ifdef __cplusplus

@@ -47,8 +47,8 @@ int mt3_debug_set_knob(int32_t knob, int32_t value) {
     case MT3_DEBUG_KNOB_NO_GLDS_256:
       mt3k::g_knobs.no_glds_256 = value != 0;
       return MT3_OK;
-    case MT3_DEBUG_KNOB_NO_FOLD_WIDE_TILE:
-      mt3k::g_knobs.no_fold_wide_tile = value != 0;
+    case MT3_DEBUG_KNOB_FOLD_WIDE_TILE:
+      mt3k::g_knobs.fold_wide_tile = value != 0;
       return MT3_OK;
     case MT3_DEBUG_KNOB_PREFETCH2:
       mt3k::g_knobs.prefetch2 = value != 0;

@@ -865,9 +865,10 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
   if (small) {
     const bool deep = g.K % (16 * KG) == 0;
     if constexpr (EPI == kEpiResidS) {
-      // the two-source fold launch (N = emb + 4 HD = 2048 columns, K up to 1536): 32 x 64 tiles move 25 % fewer operand
-      // bytes through each CU's L1 than 32 x 32 ones (96 against 2 x 64 rows per 2048 outputs), one workgroup per CU
-      if (deep && g.N % 64 == 0 && g.n_split % 64 == 0 && !g_knobs.no_fold_wide_tile)
+      // the two-source fold launch (N = emb + 4 HD = 2048 columns, K up to 1536) on 32 x 64 tiles (25 % fewer operand
+      // bytes through each CU's L1, but 101 KB of LDS = one workgroup per CU): opt-in debug knob, measured SLOWER than the
+      // 32 x 32 tiles at two per CU (bf16 632.5 against 629.4 ms per decode, f32 1181.7 against 1164.0)
+      if (deep && g.N % 64 == 0 && g.n_split % 64 == 0 && g_knobs.fold_wide_tile)
         return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI>(g, s);
     }
     if constexpr (!NORM && !A_F32 && KG == 16 && EPI != MT3_EPI_HEADS && EPI != MT3_EPI_POS) {

@@ -18,14 +18,14 @@ K = _lib
 VARIANTS = [
     # name, dtype, kv, model, options, {knob: value}
     ("bf16 default", "bfloat16", "", "mt3", 0, {}),
-    ("bf16 fold launch on 32x32 tiles", "bfloat16", "", "mt3", 0, {K.DEBUG_KNOB_NO_FOLD_WIDE_TILE: 1}),
+    ("bf16 fold launch on 32x64 tiles", "bfloat16", "", "mt3", 0, {K.DEBUG_KNOB_FOLD_WIDE_TILE: 1}),
     ("bf16 two slices in flight", "bfloat16", "", "mt3", 0, {K.DEBUG_KNOB_PREFETCH2: 1}),
     ("bf16 xcd never n-major", "bfloat16", "", "mt3", 0, {K.DEBUG_KNOB_XCD_N_MAJOR: 2}),
     ("bf16 q-fold only (r2)", "bfloat16", "", "mt3", K.OPT_SEPARATE_QKV_PROJECTION, {}),
     ("bf16 q-fold only, two slices in flight", "bfloat16", "", "mt3", K.OPT_SEPARATE_QKV_PROJECTION, {K.DEBUG_KNOB_PREFETCH2: 1}),
     ("bf16 separate projections", "bfloat16", "", "mt3", K.OPT_SEPARATE_PROJECTIONS, {}),
     ("f32 default (split form + folds)", "float32", "", "mt3", 0, {}),
-    ("f32 fold launch on 32x32 tiles", "float32", "", "mt3", 0, {K.DEBUG_KNOB_NO_FOLD_WIDE_TILE: 1}),
+    ("f32 fold launch on 32x64 tiles", "float32", "", "mt3", 0, {K.DEBUG_KNOB_FOLD_WIDE_TILE: 1}),
     ("f32 two slices in flight", "float32", "", "mt3", 0, {K.DEBUG_KNOB_PREFETCH2: 1}),
     ("f32 eight-wave split-K tiles", "float32", "", "mt3", 0, {K.DEBUG_KNOB_F32_SPLIT_K: 1}),
     ("f32 q-fold only", "float32", "", "mt3", K.OPT_SEPARATE_QKV_PROJECTION, {}),
@@ -45,7 +45,7 @@ audio = synthetic.synth_audio(B, seed=1000)
 lm = spectrograms.compute_spectrogram_batch(audio, None)
 ALL_KNOBS = (K.DEBUG_KNOB_DEC_ATTN_WAVES, K.DEBUG_KNOB_DEC_ATTN_FP8_WAVES, K.DEBUG_KNOB_NO_LDS_DMA_GEMM,
              K.DEBUG_KNOB_F32_SPLIT_K, K.DEBUG_KNOB_XCD_N_MAJOR, K.DEBUG_KNOB_PREFETCH2, K.DEBUG_KNOB_NO_K768_SPLIT,
-             K.DEBUG_KNOB_NO_FOLD_WIDE_TILE)
+             K.DEBUG_KNOB_FOLD_WIDE_TILE)
 for name, dtype, kv, model, opt, knobs in VARIANTS:
     if want and not any(w in name for w in want):
         continue
