@@ -28,16 +28,16 @@
 #include "common.h"
 #include "frontend_core.h"
 #include "frontend_tables.h"
+#include "knobs.h"
 #include "mt3_hip.h"
 
 namespace {
 
 using mt3fe::cpx;
 
-constexpr int kFramesPerBlock = 16;                          // G
+constexpr int kFramesPerBlock = 16;                          // frames_per_segment must be a multiple of this
+constexpr int kFramesPerWave = 4;                            // a wave walks 4 frames of its workgroup's tile
 constexpr int kHop = 128;
-constexpr int kTileSamples = kFramesPerBlock * kHop + (mt3fe::kFft - kHop);   // 3968
-constexpr int kWaves = 4;
 constexpr int kMelBins = 512;
 constexpr int kMagStride = 1028;
 constexpr int kMaxBandWeights = 2048;       // >= sum of band lengths (1934 for the reference's mel matrix)
@@ -80,39 +80,47 @@ struct FrontendDev {
   int n_w;
 };
 
-__global__ __launch_bounds__(256) void logmel_kernel(FrontendDev t, const float* __restrict__ audio,
-                                                      const int* __restrict__ n_frames, int frames_per_segment,
-                                                      float* __restrict__ out) {
+// kWaves = 4: 16-frame tiles (3,968 staged samples: the 1,920-sample halo is re-read by every tile, 1.94x on the input
+// side); kWaves = 8 (round 3, when frames_per_segment is a multiple of 32): 32-frame tiles -- the halo and the constant
+// tables (band offsets + padded weights, 22 KB per workgroup) are staged half as often, the same 8 waves per CU
+// (145 KB of LDS: one 512-thread workgroup instead of two of 256).
+template <int kWaves>
+__global__ __launch_bounds__(kWaves * 64) void logmel_kernel(FrontendDev t, const float* __restrict__ audio,
+                                                             const int* __restrict__ n_frames, int frames_per_segment,
+                                                             float* __restrict__ out) {
+  constexpr int kTileFrames = kWaves * kFramesPerWave;                        // G
+  constexpr int kTileSamples = kTileFrames * kHop + (mt3fe::kFft - kHop);     // 3968 / 6016
+  constexpr int kThreads = kWaves * 64;
   __shared__ __attribute__((aligned(16))) float s_samples[kTileSamples];
   __shared__ __attribute__((aligned(16))) cpx s_xchg[kWaves][mt3fe::kXchg];   // also holds Z in natural order
   __shared__ __attribute__((aligned(16))) float s_mag[kWaves][kMagStride];
   __shared__ int s_k0[kMelBins];                                        // first spectrum bin of every mel band
   __shared__ float s_w[mt3fe::kPaddedWeights];                                 // group-padded, transposed band weights
 
-  const int tiles = frames_per_segment / kFramesPerBlock;
+  const int tiles = frames_per_segment / kTileFrames;
   const int seg = blockIdx.x / tiles;
-  const int f0 = (blockIdx.x % tiles) * kFramesPerBlock;
+  const int f0 = (blockIdx.x % tiles) * kTileFrames;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n = n_frames ? n_frames[seg] : frames_per_segment;
   const int valid = n * kHop;                                    // samples of this segment that exist
   const float* seg_audio = audio + static_cast<size_t>(seg) * frames_per_segment * kHop;
 
   // stage the tile's samples once (16x reuse); zeros past the end of the segment (pad_end=True)
-  for (int i = tid; i < kTileSamples / 4; i += 256) {
+  for (int i = tid; i < kTileSamples / 4; i += kThreads) {
     const int idx = f0 * kHop + 4 * i;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx < valid) v = *reinterpret_cast<const float4*>(seg_audio + idx);
     *reinterpret_cast<float4*>(&s_samples[4 * i]) = v;
   }
-  for (int i = tid; i < kMelBins; i += 256) s_k0[i] = t.k0[i];
-  for (int i = tid; i < mt3fe::kPaddedWeights; i += 256) s_w[i] = t.w[i];
+  for (int i = tid; i < kMelBins; i += kThreads) s_k0[i] = t.k0[i];
+  for (int i = tid; i < mt3fe::kPaddedWeights; i += kThreads) s_w[i] = t.w[i];
   mt3fe::LaneConst lc;
   mt3fe::load_lane_const(lc, lane, t.hann, t.tw1024, t.tw2048);
   __syncthreads();
 
   cpx* xchg = s_xchg[wave];
   float* mag = s_mag[wave];
-  for (int r = 0; r < kFramesPerBlock / kWaves; ++r) {
+  for (int r = 0; r < kFramesPerWave; ++r) {
     const int fl = wave + kWaves * r;                            // frame inside the tile
     mt3fe::stage_a(lc, lane, s_samples + fl * kHop, mt3fe::kFft, xchg);
     wave_lds_sync();
@@ -260,9 +268,12 @@ static int launch_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segme
                 static_cast<const cpx*>(fe->d_tw2048), static_cast<const int*>(fe->d_k0),
                 static_cast<const int*>(fe->d_cnt),    static_cast<const int*>(fe->d_off),
                 static_cast<const float*>(fe->d_w), static_cast<int>(fe->host.w.size())};
-  const int tiles = frames_per_segment / kFramesPerBlock;
-  hipLaunchKernelGGL(logmel_kernel, dim3(n_segments * tiles), dim3(256), 0, s, t, d_audio, d_n, frames_per_segment,
-                     d_logmel);
+  if (frames_per_segment % 32 == 0 && !mt3k::g_knobs.frontend_16_frame_tiles)
+    hipLaunchKernelGGL(logmel_kernel<8>, dim3(n_segments * (frames_per_segment / 32)), dim3(512), 0, s, t, d_audio, d_n,
+                       frames_per_segment, d_logmel);
+  else
+    hipLaunchKernelGGL(logmel_kernel<4>, dim3(n_segments * (frames_per_segment / 16)), dim3(256), 0, s, t, d_audio, d_n,
+                       frames_per_segment, d_logmel);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

@@ -84,6 +84,10 @@ PY
       bash tools/gpu_pmc_enc.sh > gpurun_out/pmc_enc.log 2>&1
       echo "exit $? : pmc_enc"; grep "mfma_util" gpurun_out/pmc_enc.log | cut -c1-230 | tail -16
       ;;
+    fe)
+      timeout 200 python tools/ab_frontend.py > gpurun_out/ab_frontend.log 2>&1
+      echo "exit $? : ab_frontend"; grep -v "^/opt\|Warning" gpurun_out/ab_frontend.log | tail -8
+      ;;
     split)
       timeout ${SPLIT_TIMEOUT:-240} python tools/ab_split.py > gpurun_out/ab_split.log 2>&1
       echo "exit $? : ab_split"; grep -v "^/opt\|Warning" gpurun_out/ab_split.log | tail -14
