@@ -50,8 +50,8 @@ int mt3_debug_set_knob(int32_t knob, int32_t value) {
     case MT3_DEBUG_KNOB_FOLD_WIDE_TILE:
       mt3k::g_knobs.fold_wide_tile = value != 0;
       return MT3_OK;
-    case MT3_DEBUG_KNOB_FRONTEND_16_FRAME_TILES:
-      mt3k::g_knobs.frontend_16_frame_tiles = value != 0;
+    case MT3_DEBUG_KNOB_FRONTEND_32_FRAME_TILES:
+      mt3k::g_knobs.frontend_32_frame_tiles = value != 0;
       return MT3_OK;
     case MT3_DEBUG_KNOB_PREFETCH2:
       mt3k::g_knobs.prefetch2 = value != 0;

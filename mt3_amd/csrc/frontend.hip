@@ -80,10 +80,12 @@ struct FrontendDev {
   int n_w;
 };
 
-// kWaves = 4: 16-frame tiles (3,968 staged samples: the 1,920-sample halo is re-read by every tile, 1.94x on the input
-// side); kWaves = 8 (round 3, when frames_per_segment is a multiple of 32): 32-frame tiles -- the halo and the constant
-// tables (band offsets + padded weights, 22 KB per workgroup) are staged half as often, the same 8 waves per CU
-// (145 KB of LDS: one 512-thread workgroup instead of two of 256).
+// kWaves = 4 (product): 16-frame tiles (3,968 staged samples: the 1,920-sample halo is re-read by every tile, 1.94x on
+// the input side, PMC traffic 1.178x algorithmic).  kWaves = 8 (round 3, opt-in debug knob): 32-frame tiles -- halo and
+// constant tables staged half as often, PMC traffic 1.091x, the same 8 waves per CU (135 KB of LDS: ONE 512-thread
+// workgroup per CU instead of two of 256) -- measured 17-19 % SLOWER (186.9 against 156.0 us per 256 segments): the
+// kernel is latency-bound, not HBM-bound, and a single workgroup per CU has nobody to overlap its staging barrier and
+// its prologue with.  Outputs are bit-identical.
 template <int kWaves>
 __global__ __launch_bounds__(kWaves * 64) void logmel_kernel(FrontendDev t, const float* __restrict__ audio,
                                                              const int* __restrict__ n_frames, int frames_per_segment,
@@ -268,7 +270,7 @@ static int launch_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segme
                 static_cast<const cpx*>(fe->d_tw2048), static_cast<const int*>(fe->d_k0),
                 static_cast<const int*>(fe->d_cnt),    static_cast<const int*>(fe->d_off),
                 static_cast<const float*>(fe->d_w), static_cast<int>(fe->host.w.size())};
-  if (frames_per_segment % 32 == 0 && !mt3k::g_knobs.frontend_16_frame_tiles)
+  if (frames_per_segment % 32 == 0 && mt3k::g_knobs.frontend_32_frame_tiles)
     hipLaunchKernelGGL(logmel_kernel<8>, dim3(n_segments * (frames_per_segment / 32)), dim3(512), 0, s, t, d_audio, d_n,
                        frames_per_segment, d_logmel);
   else

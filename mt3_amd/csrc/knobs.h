@@ -15,7 +15,7 @@ struct Knobs {
   int no_k768_split;        // K = 768 decode tiles always as one slice (one workgroup per CU), however many workgroups
   int no_glds_256;          // encoder GEMMs always on the 128 x 128 LDS-DMA tile (never the 256 x 128 one)
   int fold_wide_tile;       // the two-source fold launch on 32 x 64 tiles instead of 32 x 32 (measured slower: off)
-  int frontend_16_frame_tiles;   // log-mel kernel always on 16-frame tiles (256 threads) instead of 32-frame ones
+  int frontend_32_frame_tiles;   // log-mel kernel on 32-frame tiles (512 threads; less halo traffic, measured slower: off)
   int prefetch2;            // decode-sized multi-slice tiles with TWO K slices in flight (measured slower: off)
 };
 extern Knobs g_knobs;

@@ -14,7 +14,7 @@ for n in (256, 2048):
     audio = torch.cat([synthetic.synth_audio(min(1024, n - s), seed=50 + s) for s in range(0, n, 1024)])
     nf = [256 if i % 5 else 77 for i in range(n)]
     for small in (0, 1):
-        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_FRONTEND_16_FRAME_TILES, small))
+        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_FRONTEND_32_FRAME_TILES, 1 - small))
         spectrograms.compute_spectrogram_batch(audio, None)
         best = 1e30
         for _ in range(3):
@@ -32,4 +32,4 @@ for n in (256, 2048):
             655360 * n / (best * 1e-3) / 8e12 * 100), flush=True)
     print("   bit-identical across tile sizes:", bool(torch.equal(outs[(n, 0)][0], outs[(n, 1)][0])),
           bool(torch.equal(outs[(n, 0)][1], outs[(n, 1)][1])), flush=True)
-lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_FRONTEND_16_FRAME_TILES, 0)
+lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_FRONTEND_32_FRAME_TILES, 0)
