@@ -88,6 +88,14 @@ PY
       timeout 200 python tools/ab_frontend.py > gpurun_out/ab_frontend.log 2>&1
       echo "exit $? : ab_frontend"; grep -v "^/opt\|Warning" gpurun_out/ab_frontend.log | tail -8
       ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_r3.log 2>&1
+      echo "exit $? : smoke"; tail -1 gpurun_out/smoke_r3.log | cut -c1-200
+      ;;
+    corpus)
+      timeout 600 python bench.py --corpus 10000 --steps 1 --warmup 0 --no-cpu-baseline --no-extras > gpurun_out/bench_corpus_r3.log 2>&1
+      echo "exit $? : bench --corpus 10000"; grep -h '^{"metric"' gpurun_out/bench_corpus_r3.log | tail -1 | python tools/bench_digest.py
+      ;;
     split)
       timeout ${SPLIT_TIMEOUT:-240} python tools/ab_split.py > gpurun_out/ab_split.log 2>&1
       echo "exit $? : ab_split"; grep -v "^/opt\|Warning" gpurun_out/ab_split.log | tail -14
