@@ -35,19 +35,19 @@ namespace mt3k {
 
 // ------------------------------------------------------------------------ encoder attention
 // stage keys [key0, key0 + TK) of one head into LDS: K row-major [TK][ROWK], V transposed [64][ROWV]
-template <typename CT, int TK, int ROWK, int ROWV>
+template <typename CT, int TK, int ROWK, int ROWV, int NT = 256>
 __device__ __forceinline__ void enc_stage_kv(const CT* base, int RS, int HD, int key0, CT* Ks, CT* Vt, int tid) {
   constexpr int KPL = CTraits<CT>::KPL;
   constexpr int D = 64;
   constexpr int CH = D / KPL;                   // chunks per K/V row
   // ---- K (row-major) : chunk c -> row c / CH, piece c % CH
-  for (int c = tid; c < TK * CH; c += 256) {
+  for (int c = tid; c < TK * CH; c += NT) {
     const int row = c / CH, ch = c % CH;
     const u32x4 v = *reinterpret_cast<const u32x4*>(base + static_cast<size_t>(key0 + row) * RS + HD + ch * KPL);
     *reinterpret_cast<u32x4*>(&Ks[row * ROWK + ch * KPL]) = v;
   }
   // ---- V transposed: work item = (key pair, piece); a wave takes 64 consecutive key pairs
-  for (int w = tid; w < (TK / 2) * CH; w += 256) {
+  for (int w = tid; w < (TK / 2) * CH; w += NT) {
     const int rp = w % (TK / 2), ch = w / (TK / 2);
     const CT* src = base + static_cast<size_t>(key0 + 2 * rp) * RS + 2 * HD + ch * KPL;
     const u32x4 v0 = *reinterpret_cast<const u32x4*>(src);
@@ -202,8 +202,11 @@ __device__ __forceinline__ void enc_attn_store(CT* out, size_t row0, int HD, int
   }
 }
 
-template <typename CT, int T>
-__global__ __launch_bounds__(256) void enc_attn_kernel(const CT* __restrict__ qkv, CT* __restrict__ out, int H) {
+// NW waves per (batch, head) workgroup: 4, or (round 3, bf16 T = 256) 8 -- 114 VGPRs and 74.7 KB of LDS allow two such
+// workgroups per CU = 16 waves instead of 8: twice the loads in flight while K / V^T are staged and twice the waves to
+// hide the softmax's VALU chains behind (the kernel is latency-, not MFMA-bound: matrix pipes 13 % busy)
+template <typename CT, int T, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void enc_attn_kernel(const CT* __restrict__ qkv, CT* __restrict__ out, int H) {
   constexpr int KPL = CTraits<CT>::KPL;
   constexpr int KG = CTraits<CT>::KGROUP;       // head-dim / key elements per chunk-MFMA
   constexpr int D = 64;
@@ -219,11 +222,11 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const CT* __restrict__ qk
   const int RS = 3 * H * D;                     // qkv row stride (elements)
   const CT* base = qkv + static_cast<size_t>(b) * T * RS + h * D;
 
-  enc_stage_kv<CT, T, ROWK, ROWV>(base, RS, H * D, 0, Ks, Vt, tid);
+  enc_stage_kv<CT, T, ROWK, ROWV, NW * 64>(base, RS, H * D, 0, Ks, Vt, tid);
   __syncthreads();
 
   const int fr = lane & 15, fg = lane >> 4;
-  for (int qt = wave; qt < T / 16; qt += 4) {
+  for (int qt = wave; qt < T / 16; qt += NW) {
     const int q0 = qt * 16;
     // Q^T as the B operand: col n = query q0 + fr, K-group chunk c
     u32x4 qf[NC];
@@ -305,7 +308,10 @@ __global__ __launch_bounds__(256) void enc_attn_split_kernel(const CT* __restric
 int launch_encoder_attention(int dtype, const void* qkv, void* out, int B, int T, int H, hipStream_t s) {
   if (!qkv || !out || B <= 0 || H <= 0) return mt3::fail(MT3_ERR_INVALID, "encoder_attention: bad arguments");
   const dim3 grid(B * H), block(256);
-  if (dtype == MT3_BF16 && T == 256) {
+  if (dtype == MT3_BF16 && T == 256 && !g_knobs.enc_attn_4_waves) {
+    hipLaunchKernelGGL((enc_attn_kernel<__bf16, 256, 8>), grid, dim3(512), 0, s, static_cast<const __bf16*>(qkv),
+                       static_cast<__bf16*>(out), H);
+  } else if (dtype == MT3_BF16 && T == 256) {
     hipLaunchKernelGGL((enc_attn_kernel<__bf16, 256>), grid, block, 0, s, static_cast<const __bf16*>(qkv),
                        static_cast<__bf16*>(out), H);
   } else if (dtype == MT3_BF16 && T == 512) {

@@ -14,8 +14,9 @@ from mt3_amd import _lib, network, spectrograms, synthetic  # noqa: E402
 lib = _lib.load()
 x256 = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(256, seed=3), None)
 for dense in ("", "fp8_e4m3"):
-    for no256 in ((0, 1) if not dense else (0,)):
+    for no256, attn4 in (((0, 0), (1, 0), (0, 1)) if not dense else ((0, 0),)):
         _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_GLDS_256, no256))
+        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_ENC_ATTN_4_WAVES, attn4))
         cfg = dataclasses.replace(network.T5Config(dtype="bfloat16"), dense_dtype=dense)
         eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=256)
         eng.load_params(network.init_random_params(cfg, seed=0))
@@ -31,8 +32,9 @@ for dense in ("", "fp8_e4m3"):
                 e1.record()
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / 5)
-            print("%-8s %-22s B=%3d: %.3f ms  %.0f TF/s" % ("mxfp8" if dense else "bf16",
-                                                             "128x128 tiles" if no256 else "256x128 tiles (default)", B,
-                                                             best, 12.214 * B / best), flush=True)
+            print("%-8s %-24s %-28s B=%3d: %.3f ms  %.0f TF/s" % (
+                "mxfp8" if dense else "bf16", "128x128 tiles" if no256 else "256x128 tiles (default)",
+                "attention 4 waves" if attn4 else "attention 8 waves (default)", B, best, 12.214 * B / best), flush=True)
         del eng
 lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_GLDS_256, 0)
+lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_ENC_ATTN_4_WAVES, 0)
