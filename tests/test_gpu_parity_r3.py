@@ -442,3 +442,42 @@ def test_bench_batch_256_bf16_against_the_f32_engine_at_all_1024_positions():
     assert float(r[-64:].mean()) < 1.5 * float(r[:64].mean()) + 1e-3
     assert bool(agree[safe].all()) and float(safe.double().mean()) > 0.5
     assert float(agree.double().mean()) > 0.97
+
+
+def test_launch_shape_knobs_do_not_change_results():
+    """`mt3_debug_set_knob` knobs choose launch shapes, not arithmetic: with the summation order of every output element
+    untouched (tile dealing to XCDs, K = 768 in one or two slices, 128- or 256-row encoder tiles, four or eight waves per
+    encoder-attention workgroup, waves per decode-attention workgroup) the encoder output, the teacher-forced logits and
+    the greedy ids of a base-shape engine with e4m3 caches are BIT-identical to the default build."""
+    cfg = dataclasses.replace(network.MT3_BASE, dtype="bfloat16", kv_dtype="fp8_e4m3", num_encoder_layers=2,
+                              num_decoder_layers=2)
+    params = network.init_random_params(cfg, seed=9, norm_scale_jitter=0.1)
+    from mt3_amd import spectrograms, synthetic
+    B = 40                                                      # 40 x 256 rows: 128-row tiles by default, ragged decode tiles
+    lm = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(B, seed=4), None)
+    forced = _forced(B, 20, 2)
+    lib = _lib.load()
+
+    def run():
+        eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B)
+        eng.load_params(params)
+        enc = eng.encode(lm, return_encoded=True).clone()
+        _, logits = eng.decode_forced(forced, num_steps=20)
+        ids = eng.decode(num_steps=24).clone()
+        return enc, logits.clone(), ids
+
+    base = run()
+    knobs = ((_lib.DEBUG_KNOB_XCD_N_MAJOR, 2), (_lib.DEBUG_KNOB_XCD_N_MAJOR, 1), (_lib.DEBUG_KNOB_NO_K768_SPLIT, 1),
+             (_lib.DEBUG_KNOB_NO_GLDS_256, 1), (_lib.DEBUG_KNOB_ENC_ATTN_4_WAVES, 1),
+             (_lib.DEBUG_KNOB_DEC_ATTN_FP8_WAVES, 2), (_lib.DEBUG_KNOB_NO_LDS_DMA_GEMM, 1))
+    for knob, value in knobs:
+        _lib.check(lib.mt3_debug_set_knob(knob, value))
+        try:
+            got = run()
+        finally:
+            _lib.check(lib.mt3_debug_set_knob(knob, 0))
+        if knob in (_lib.DEBUG_KNOB_NO_LDS_DMA_GEMM, _lib.DEBUG_KNOB_DEC_ATTN_FP8_WAVES):
+            # a different tile / merge tree: same function, different f32 summation order -> bf16-noise distance
+            assert float((got[0] - base[0]).norm() / base[0].norm()) < 6e-3, knob
+            continue
+        assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]) and torch.equal(got[2], base[2]), (knob, value)
