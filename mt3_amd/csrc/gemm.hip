@@ -553,7 +553,10 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
 // BM_ = 256 (round 3; STORE / GEGLU / HEADS epilogues): a wave owns 128 x 64 outputs (8 x 4 fragments), so a K slice costs
 // 12 fragment reads for 32 MFMAs instead of 8 for 16 and the A panel is shared by twice the rows: the 128 x 128 tile's
 // K loop alone ran at 55 % of the matrix peak with LDS reads and MFMAs both at ~100 % of their own pipes.
-template <int EPI, int NPV, int BM_ = 128>
+// DB (round 3 experiment, 128-row tile): FOUR ring stages and two sets of fragment registers -- the fragment reads of slice
+// t + 1 are issued before the MFMAs of slice t (slice t + 1 must have landed at iteration t's barrier, so three slices
+// are in flight instead of two and the ring grows to 64 KB: two workgroups per CU instead of three).
+template <int EPI, int NPV, int BM_ = 128, bool DB = false>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   using CT = __bf16;
   constexpr int BM = BM_, BN = 128, BK = MT3_GLDS_BK, FM = BM / 32, FN = 4;
@@ -563,7 +566,8 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   constexpr int RPP = 64 / CPROW;                    // rows per 1 KB DMA piece: 16 or 8
   constexpr int KSH = BK == 32 ? 2 : 1;              // swizzle key of row r: (r >> KSH) & (CPROW - 1)
   constexpr int STAGE_B = (BM + BN) * ROWB;          // 16 / 32 KB per stage: A rows, then W rows
-  constexpr int NS = MT3_GLDS_NS, DEPTH = NS - 1;    // ring stages / K slices in flight
+  constexpr int NS = DB ? 4 : MT3_GLDS_NS, DEPTH = NS - 1;    // ring stages / K slices in flight
+  static_assert(!DB || (BM_ == 128 && MT3_GLDS_BK == 32 && !MT3_GLDS_PROBE), "fragment double-buffering: 128-row tile");
   constexpr int PPW = (BM + BN) / RPP / 4;           // 1 KB pieces per wave per stage: 4 (8 with 128-byte rows), 6 at BM = 256
   static_assert(BK == 32 || BK == 64, "K slice");
   // ONE shared object (a second one makes hipcc drain the DMA queue before every k-step's first ds_read)
@@ -639,6 +643,46 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
     if (d < KT) issue(d, d);
+  if constexpr (DB) {
+    static_assert(!DB || PPW == 4, "vmcnt immediates below");
+    u32x4 af[2][FM], bf[2][FN];
+    const int so = (frag_g ^ key) * 16;
+    auto read_frags = [&](auto set_c, int t) {
+      constexpr int SET = decltype(set_c)::value;
+      const unsigned char* st = smem + (t % NS) * STAGE_B;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[SET][i] = *reinterpret_cast<const u32x4*>(st + a_off + i * 16 * ROWB + so);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[SET][j] = *reinterpret_cast<const u32x4*>(st + b_off + j * 16 * ROWB + so);
+    };
+    // slice 0 landed (at most the two younger slices outstanding), then its fragments
+    if (KT >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (KT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_frags(std::integral_constant<int, 0>{}, 0);
+    auto step = [&](auto set_c, int t) {
+      constexpr int SET = decltype(set_c)::value;
+      // slice t + 1 landed: only slice t + 2 (if it exists) may still be in flight
+      if (t + 2 <= KT - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // after this barrier: every wave's pieces of slice t + 1 are in LDS, and every wave has issued the MFMAs of
+      // slice t - 1, i.e. its reads of stage (t - 1) % NS have returned -- the stage slice t + DEPTH goes to
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (t + DEPTH < KT) issue(t + DEPTH, (t + DEPTH) % NS);
+      if (t + 1 < KT) read_frags(std::integral_constant<int, 1 - SET>{}, t + 1);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) mfma_chunk<CT>(af[SET][i], bf[SET][j], acc[i][j]);
+    };
+    for (int t = 0; t < KT; t += 2) {
+      step(std::integral_constant<int, 0>{}, t);
+      if (t + 1 < KT) step(std::integral_constant<int, 1>{}, t + 1);
+    }
+  } else
   for (int t = 0; t < KT; ++t) {
     // slice t has landed once at most the (<= DEPTH - 1) younger slices' DMAs of this wave are still outstanding
     const int ahead = KT - 1 - t < DEPTH - 1 ? KT - 1 - t : DEPTH - 1;
@@ -804,7 +848,7 @@ static int launch_glds(const GemmArgs& g, hipStream_t s) {
     // B = 256 the tall tile is 5-9 % faster per launch (GEGLU 243 against 260 us, QKV 139 against 153), at B = 64
     // (1.1 rounds of tall tiles) 1 % slower
     const int grid256 = ((g.M + 255) / 256) * (g.N / 128);
-    if (!g_knobs.no_glds_256 && grid256 >= 1024) {
+    if (!g_knobs.no_glds_256 && !g_knobs.glds_frag_db && grid256 >= 1024) {
       if (g.a_ss && g.K > 512)
         hipLaunchKernelGGL((gemm_glds_kernel<EPI, 16, 256>), dim3(grid256), dim3(256), 0, s, g);
       else
@@ -814,6 +858,16 @@ static int launch_glds(const GemmArgs& g, hipStream_t s) {
     }
   }
   const int grid = ((g.M + 127) / 128) * (g.N / 128);
+  if constexpr (MT3_GLDS_BK == 32 && !MT3_GLDS_PROBE) {
+    if (g_knobs.glds_frag_db) {      // experiment: fragment double-buffering on a four-stage ring
+      if (g.a_ss && g.K > 512)
+        hipLaunchKernelGGL((gemm_glds_kernel<EPI, 16, 128, true>), dim3(grid), dim3(256), 0, s, g);
+      else
+        hipLaunchKernelGGL((gemm_glds_kernel<EPI, 8, 128, true>), dim3(grid), dim3(256), 0, s, g);
+      MT3_HIP_CHECK(hipGetLastError());
+      return MT3_OK;
+    }
+  }
   if (g.a_ss && g.K > 512)
     hipLaunchKernelGGL((gemm_glds_kernel<EPI, 16>), dim3(grid), dim3(256), 0, s, g);
   else

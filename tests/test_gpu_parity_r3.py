@@ -468,7 +468,7 @@ def test_launch_shape_knobs_do_not_change_results():
 
     base = run()
     knobs = ((_lib.DEBUG_KNOB_XCD_N_MAJOR, 2), (_lib.DEBUG_KNOB_XCD_N_MAJOR, 1), (_lib.DEBUG_KNOB_NO_K768_SPLIT, 1),
-             (_lib.DEBUG_KNOB_NO_GLDS_256, 1), (_lib.DEBUG_KNOB_ENC_ATTN_4_WAVES, 1),
+             (_lib.DEBUG_KNOB_NO_GLDS_256, 1), (_lib.DEBUG_KNOB_ENC_ATTN_4_WAVES, 1), (_lib.DEBUG_KNOB_GLDS_FRAG_DB, 1),
              (_lib.DEBUG_KNOB_DEC_ATTN_FP8_WAVES, 2), (_lib.DEBUG_KNOB_NO_LDS_DMA_GEMM, 1))
     for knob, value in knobs:
         _lib.check(lib.mt3_debug_set_knob(knob, value))

@@ -14,8 +14,9 @@ from mt3_amd import _lib, network, spectrograms, synthetic  # noqa: E402
 lib = _lib.load()
 x256 = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(256, seed=3), None)
 for dense in ("", "fp8_e4m3"):
-    for no256, attn4 in (((0, 0), (1, 0), (0, 1)) if not dense else ((0, 0),)):
-        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_GLDS_256, no256))
+    for no256, attn4 in (((0, 0), (1, 0), (0, 1), (2, 0)) if not dense else ((0, 0),)):
+        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_GLDS_256, 1 if no256 == 1 else 0))
+        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_GLDS_FRAG_DB, 1 if no256 == 2 else 0))
         _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_ENC_ATTN_4_WAVES, attn4))
         cfg = dataclasses.replace(network.T5Config(dtype="bfloat16"), dense_dtype=dense)
         eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=256)
@@ -33,8 +34,9 @@ for dense in ("", "fp8_e4m3"):
                 torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / 5)
             print("%-8s %-24s %-28s B=%3d: %.3f ms  %.0f TF/s" % (
-                "mxfp8" if dense else "bf16", "128x128 tiles" if no256 else "256x128 tiles (default)",
+                "mxfp8" if dense else "bf16", ("256x128 tiles (default)", "128x128 tiles", "128x128, fragment DB")[no256],
                 "attention 4 waves" if attn4 else "attention 8 waves (default)", B, best, 12.214 * B / best), flush=True)
         del eng
 lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_GLDS_256, 0)
 lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_ENC_ATTN_4_WAVES, 0)
+lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_GLDS_FRAG_DB, 0)
