@@ -56,12 +56,14 @@ int mt3_debug_engine_poison_caches(mt3_engine* e, int32_t pattern, int32_t cross
  *                algorithmic; measured 17 % slower)
  *   ENC_ATTN_4_WAVES: encoder attention (bf16, T = 256) with four waves per (batch, head) workgroup instead of eight
  *   GLDS_FRAG_DB: encoder GEMMs on the 128-row LDS-DMA tile with a four-stage ring and double-buffered fragments
+ *   GEGLU_NARROW_TILE: the decode step's GEGLU launch on 32 x 32 two-wave tiles (two workgroups per CU)
  *   PREFETCH2: decode-sized multi-slice GEMM tiles keep TWO K slices in flight instead of one (measured slower) */
 enum { MT3_DEBUG_KNOB_DEC_ATTN_WAVES = 0, MT3_DEBUG_KNOB_DEC_ATTN_FP8_WAVES = 1, MT3_DEBUG_KNOB_NO_LDS_DMA_GEMM = 2,
        MT3_DEBUG_KNOB_F32_SPLIT_K = 3, MT3_DEBUG_KNOB_XCD_N_MAJOR = 4, MT3_DEBUG_KNOB_PREFETCH2 = 5,
        MT3_DEBUG_KNOB_NO_K768_SPLIT = 6, MT3_DEBUG_KNOB_NO_GLDS_256 = 7,
        MT3_DEBUG_KNOB_FOLD_WIDE_TILE = 8, MT3_DEBUG_KNOB_FRONTEND_32_FRAME_TILES = 9,
-       MT3_DEBUG_KNOB_ENC_ATTN_4_WAVES = 10, MT3_DEBUG_KNOB_GLDS_FRAG_DB = 11 };
+       MT3_DEBUG_KNOB_ENC_ATTN_4_WAVES = 10, MT3_DEBUG_KNOB_GLDS_FRAG_DB = 11,
+       MT3_DEBUG_KNOB_GEGLU_NARROW_TILE = 12 };
 int mt3_debug_set_knob(int32_t knob, int32_t value);
 
 #ifdef __cplusplus

@@ -24,7 +24,7 @@ DEBUG_SKIP_SELF_ATTN, DEBUG_SKIP_CROSS_ATTN = 1, 2
 (DEBUG_KNOB_DEC_ATTN_WAVES, DEBUG_KNOB_DEC_ATTN_FP8_WAVES, DEBUG_KNOB_NO_LDS_DMA_GEMM, DEBUG_KNOB_F32_SPLIT_K,
  DEBUG_KNOB_XCD_N_MAJOR, DEBUG_KNOB_PREFETCH2, DEBUG_KNOB_NO_K768_SPLIT, DEBUG_KNOB_NO_GLDS_256,
  DEBUG_KNOB_FOLD_WIDE_TILE, DEBUG_KNOB_FRONTEND_32_FRAME_TILES, DEBUG_KNOB_ENC_ATTN_4_WAVES,
- DEBUG_KNOB_GLDS_FRAG_DB) = range(12)
+ DEBUG_KNOB_GLDS_FRAG_DB, DEBUG_KNOB_GEGLU_NARROW_TILE) = range(13)
 (STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8, STATUS_Q_FOLD,
  STATUS_DENSE_FP8, STATUS_QKV_FOLD, STATUS_LAST_DECODE_GROUPS, STATUS_PARTITION_FALLBACKS) = range(9)
 EV_SHIFT, EV_PITCH, EV_VELOCITY, EV_TIE, EV_PROGRAM, EV_DRUM = range(6)

@@ -17,7 +17,7 @@ int fail(int code, const std::string& msg) {
 }  // namespace mt3
 
 namespace mt3k {
-Knobs g_knobs = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+Knobs g_knobs = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 }
 
 extern "C" {
@@ -58,6 +58,9 @@ int mt3_debug_set_knob(int32_t knob, int32_t value) {
       return MT3_OK;
     case MT3_DEBUG_KNOB_GLDS_FRAG_DB:
       mt3k::g_knobs.glds_frag_db = value != 0;
+      return MT3_OK;
+    case MT3_DEBUG_KNOB_GEGLU_NARROW_TILE:
+      mt3k::g_knobs.geglu_narrow_tile = value != 0;
       return MT3_OK;
     case MT3_DEBUG_KNOB_PREFETCH2:
       mt3k::g_knobs.prefetch2 = value != 0;

@@ -956,6 +956,12 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
       }
     }
     if constexpr (EPI == MT3_EPI_GEGLU) {
+      if constexpr (!NORM && !A_F32 && KG == 32) {
+        // experiment (debug knob): 32 x 32 GEGLU tiles of two waves (gate | linear fragment pair per wave), 67.6 KB of
+        // LDS = two workgroups per CU instead of one 32 x 64 tile of 101 KB
+        if (deep && g.K == 16 * KG && g_knobs.geglu_narrow_tile)
+          return launch_cfg<CT, 32, 32, 16 * KG, 2, 1, A_F32, NORM, EPI>(g, s);
+      }
       if (deep) return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 64, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
     } else {

@@ -18,6 +18,7 @@ struct Knobs {
   int frontend_32_frame_tiles;   // log-mel kernel on 32-frame tiles (512 threads; less halo traffic, measured slower: off)
   int enc_attn_4_waves;     // encoder attention (bf16, T = 256) with four waves per workgroup instead of eight
   int glds_frag_db;         // encoder GEMMs on the 128-row LDS-DMA tile with fragment double-buffering (4-stage ring)
+  int geglu_narrow_tile;    // decode GEGLU launch on 32 x 32 two-wave tiles (two per CU) instead of 32 x 64
   int prefetch2;            // decode-sized multi-slice tiles with TWO K slices in flight (measured slower: off)
 };
 extern Knobs g_knobs;
