@@ -171,7 +171,7 @@ struct Top2 {
 //   beam_cfg[0] = brevity_penalty(max_len + 1) of this call, beam_cfg[1 + n] = brevity_penalty(n) =
 //   ((5 + n) / 6) ^ alpha, tabulated on the host.
 template <bool BEAM1>
-__global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restrict__ logits, int vocab,
+__global__ __launch_bounds__(256) void argmax_step_kernel(float* __restrict__ logits, int vocab,
                                                            int* __restrict__ ids, int ids_stride,
                                                            int* __restrict__ cur_tok, int* __restrict__ done,
                                                            int* __restrict__ n_done, int* __restrict__ step,
@@ -182,12 +182,28 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
                                                            float* __restrict__ beam_f, int* __restrict__ beam_len,
                                                            const float* __restrict__ beam_cfg, int beam_rows,
                                                            const int* __restrict__ forced, int forced_stride,
-                                                           RowProj rp) {
+                                                           RowProj rp, LogitScale ls) {
   __shared__ float s_v[8], s_sum[4];
   __shared__ int s_i[8];
   __shared__ int s_tok, s_t;
+  __shared__ float s_rs;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* row = logits + static_cast<size_t>(b) * vocab;
+  float* row = logits + static_cast<size_t>(b) * vocab;
+  if (ls.ss) {
+    // folded logits projection: the row arrives unnormalised; 1/rms of the final residual row from its partial sums
+    // (<= 64 of them: one wave), then the scaled logits replace the raw ones (callers read them: first-step /
+    // per-step logits) -- arg-max would not need the scale, the beam's log-softmax and the parity outputs do
+    if (wave == 0) {
+      float p = lane < ls.n_ss ? ls.ss[static_cast<size_t>(b) * ls.n_ss + lane] : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+      if (lane == 0) s_rs = rsqrtf(p / static_cast<float>(ls.dim) + 1e-6f);
+    }
+    __syncthreads();
+    const float rs = s_rs;
+    for (int i = tid; i < vocab; i += 256) row[i] *= rs;
+    // (each thread re-reads below exactly the elements it just wrote: no barrier needed)
+  }
   // thread 0 issues its state loads up front so that their latency hides behind the reductions
   int was_done = 0, t = 0, blen = -1;
   float live = 0.f, best = 0.f, bp_max = 1.f, bp_t = 1.f;
@@ -296,21 +312,23 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(const float* __restric
   }
 }
 
-int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
+int launch_argmax_step(float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
                        float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam,
-                       const int* forced, int forced_stride, const RowProj& rp, hipStream_t s) {
+                       const int* forced, int forced_stride, const RowProj& rp, const LogitScale& ls, hipStream_t s) {
   if (beam && forced) return mt3::fail(MT3_ERR_INVALID, "argmax_step: teacher forcing is a greedy-path feature");
+  if (ls.ss && (ls.n_ss <= 0 || ls.n_ss > 64 || ls.dim <= 0))
+    return mt3::fail(MT3_ERR_INVALID, "argmax_step: the row scale needs 1 .. 64 partial sums");
   if (rp.q_out && (!y_next || !rp.ew || !rp.pw || rp.q_n % 4))
     return mt3::fail(MT3_ERR_INVALID, "argmax_step: row projection needs the next-row output and its tables");
   if (beam)
     hipLaunchKernelGGL(argmax_step_kernel<true>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
                        done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, beam->f, beam->len,
-                       beam->cfg, beam->rows, nullptr, 0, rp);
+                       beam->cfg, beam->rows, nullptr, 0, rp, ls);
   else
     hipLaunchKernelGGL(argmax_step_kernel<false>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
                        done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, nullptr, nullptr, nullptr, 0,
-                       forced, forced_stride, rp);
+                       forced, forced_stride, rp, ls);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

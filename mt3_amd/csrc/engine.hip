@@ -359,29 +359,44 @@ int build_qkv_fold(mt3_engine* e) {
     if (d_prod) (void)hipFree(d_prod);
   };
   int rc = MT3_OK;
-  hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_wext), static_cast<size_t>(n4) * emb * 4);
+  const int n_max = n4 > c.vocab_size ? n4 : c.vocab_size;
+  hipError_t he = hipMalloc(reinterpret_cast<void**>(&d_wext), static_cast<size_t>(n_max) * emb * 4);
   if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_wo), static_cast<size_t>(mlp) * emb * 4);
-  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_prod), static_cast<size_t>(n4) * mlp * 4);
-  std::vector<float> wt, prod(static_cast<size_t>(n4) * mlp), w;
-  for (int l = 0; l + 1 < nl && he == hipSuccess && rc == MT3_OK; ++l) {
+  if (he == hipSuccess) he = hipMalloc(reinterpret_cast<void**>(&d_prod), static_cast<size_t>(n_max) * mlp * 4);
+  std::vector<float> wt, prod, w;
+  // layer l's MLP out-projection launch carries the NEXT consumer of its output row: layer l + 1's q | k | v | cross-q
+  // (4HD columns), or -- last layer -- the logits projection (vocab columns, decoder_norm scale folded)
+  for (int l = 0; l < nl && he == hipSuccess && rc == MT3_OK; ++l) {
+    const bool last = l + 1 == nl;
+    const int nx = last ? c.vocab_size : n4;
     const HostWeight* wo = find(e, "decoder/layers_" + std::to_string(l) + "/mlp/wo/kernel", mlp, emb);
     if (!wo) rc = MT3_ERR_MISSING;
-    if (rc == MT3_OK) rc = wext_t(l + 1, &wt);
+    if (rc == MT3_OK && !last) rc = wext_t(l + 1, &wt);
+    if (rc == MT3_OK && last) {
+      const float* sn = scale_of(e, "decoder/decoder_norm/scale");
+      const HostWeight* wl = find(e, "decoder/logits_dense/kernel", emb, c.vocab_size);
+      if (!sn || !wl) rc = MT3_ERR_MISSING;
+      else {
+        wt.assign(static_cast<size_t>(nx) * emb, 0.f);
+        put_transposed(wt, emb, 0, *wl, sn);
+      }
+    }
     if (rc != MT3_OK) break;
     he = hipMemcpy(d_wext, wt.data(), wt.size() * 4, hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemcpy(d_wo, wo->data.data(), wo->data.size() * 4, hipMemcpyHostToDevice);
     if (he != hipSuccess) break;
     // prod[n][k] = sum_e Wext^T[n][e] * Wo_mlp[k][e]: "A" = Wext^T rows, "Wt" = Wo_mlp rows (K = emb for both)
-    mt3k::GemmArgs g = gemm_args(d_wext, d_wo, d_prod, n4, mlp, emb, mlp);
+    mt3k::GemmArgs g = gemm_args(d_wext, d_wo, d_prod, nx, mlp, emb, mlp);
     rc = mt3k::launch_gemm(MT3_F32, g, false, 0, MT3_EPI_F32, false, nullptr);
     if (rc != MT3_OK) break;
+    prod.resize(static_cast<size_t>(nx) * mlp);
     he = hipMemcpy(prod.data(), d_prod, prod.size() * 4, hipMemcpyDeviceToHost);
     if (he != hipSuccess) break;
     const size_t K = static_cast<size_t>(mlp) + emb;
-    w.assign((static_cast<size_t>(emb) + n4) * K, 0.f);
+    w.assign((static_cast<size_t>(emb) + nx) * K, 0.f);
     for (int k = 0; k < mlp; ++k)
       for (int n = 0; n < emb; ++n) w[static_cast<size_t>(n) * K + k] = wo->data[static_cast<size_t>(k) * emb + n];
-    for (int n = 0; n < n4; ++n) {
+    for (int n = 0; n < nx; ++n) {
       float* row = w.data() + (static_cast<size_t>(emb) + n) * K;
       std::memcpy(row, prod.data() + static_cast<size_t>(n) * mlp, static_cast<size_t>(mlp) * 4);
       std::memcpy(row + mlp, wt.data() + static_cast<size_t>(n) * emb, static_cast<size_t>(emb) * 4);
@@ -524,17 +539,21 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   float* qkvf = fold ? e->qkvf + static_cast<size_t>(row0) * 4 * hd : nullptr;
   float* logits = e->logits + static_cast<size_t>(row0) * c.vocab_size;
   int* step = e->step + row0;                    // per-row position counters
-  if (op == 8 * nl)
+  if (op == 8 * nl) {
+    if (fold) return MT3_OK;                  // the logits projection rode in the last layer's MLP out-projection launch
     return mt3k::launch_gemm(dt, normed(e->logits_w, logits, c.vocab_size, c.vocab_size), !split, nrm, MT3_EPI_F32,
                              small, s);
+  }
   if (op == 8 * nl + 1) {
     const mt3k::BeamState beam{e->beam_f + row0, e->beam_len + row0, e->beam_cfg, c.max_batch};
     const mt3k::RowProj rp{e->ew0, e->pw0, qkvf, 4 * hd};
+    // folded logits arrive unnormalised: the row scale comes from the final residual row's partial sums
+    const mt3k::LogitScale ls{fold ? y_ss : nullptr, emb / 16, emb};
     return mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
                                     e->cur_tok + row0, e->done + row0, e->n_done + done_slot, step, e->embedding, e->pos_table,
                                     kMaxPos, y_buf(0), split && !f32 ? yct_buf(0) : nullptr, y_ss, emb, rows,
                                     (skip & 4) ? &beam : nullptr,
-                                    (skip & 8) ? e->forced + static_cast<size_t>(row0) * Lmax : nullptr, Lmax, rp, s);
+                                    (skip & 8) ? e->forced + static_cast<size_t>(row0) * Lmax : nullptr, Lmax, rp, ls, s);
   }
   LayerDev& L = e->dec[op >> 3];
   switch (op & 7) {
@@ -613,16 +632,19 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     case 6:
       return mt3k::launch_gemm(dt, normed(L.wi, h_d, 2 * c.mlp_dim, c.mlp_dim), !split, nrm, MT3_EPI_GEGLU, small, s);
     default:
-      if (fold && (op >> 3) + 1 < nl) {
-        // MLP out-projection + residual, and -- as 4HD extra output columns with a two-source K = mlp + emb -- the NEXT
-        // layer's unnormalised q | k | v | cross-q.  The residual rows move to the other buffer (see `cur`).
-        mt3k::GemmArgs g = gemm_args(h_d, L.w_fold, y_buf(cur ^ 1), rows, emb + 4 * hd, c.mlp_dim + emb, emb);
+      if (fold) {
+        // MLP out-projection + residual, and -- as extra output columns with a two-source K = mlp + emb -- what consumes
+        // the updated row next, unnormalised: the NEXT layer's q | k | v | cross-q (4HD columns into qkvf), or after
+        // the last layer the logits (vocab columns).  The residual rows move to the other buffer (see `cur`).
+        const bool last = (op >> 3) + 1 == nl;
+        const int nx = last ? c.vocab_size : 4 * hd;
+        mt3k::GemmArgs g = gemm_args(h_d, L.w_fold, y_buf(cur ^ 1), rows, emb + nx, c.mlp_dim + emb, emb);
         g.lda = c.mlp_dim;
         g.resid_src = y;
         g.out_ct = f32 ? nullptr : yct_buf(cur ^ 1);
         g.out_ss = y_ss;
-        g.out2 = qkvf;
-        g.ld2 = 4 * hd;
+        g.out2 = last ? logits : qkvf;
+        g.ld2 = nx;
         g.n_split = emb;
         g.A2 = y_ct;
         g.lda2 = emb;

@@ -95,6 +95,14 @@ struct RowProj {
   float* q_out;
   int q_n;
 };
+// logits that arrive UNNORMALISED (the logits projection folded into the last layer's MLP out-projection launch): the
+// kernel that picks the token applies the decoder_norm row scale rsqrt(sum(ss[b][0 .. n_ss)) / dim + 1e-6) itself and
+// writes the scaled logits back (ss == nullptr: the logits are final)
+struct LogitScale {
+  const float* ss;
+  int n_ss;
+  int dim;
+};
 int launch_embed(const float* table, const float* pos, const int* tok, const int* step, float* y, void* y_ct,
                  float* y_ss, int B, int dim, const RowProj& rp, hipStream_t s);
 // per-row state of the beam-1 search (t5x beam_search, num_decodes = 1): f = [live_logp | best finished
@@ -108,10 +116,10 @@ struct BeamState {
 };
 // token pick + bookkeeping for one decode step (see decode_ops.hip); beam == nullptr: greedy;
 // forced != nullptr (greedy only): teacher forcing, the next input token is forced[b * forced_stride + t]
-int launch_argmax_step(const float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
+int launch_argmax_step(float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
                        float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam,
-                       const int* forced, int forced_stride, const RowProj& rp, hipStream_t s);
+                       const int* forced, int forced_stride, const RowProj& rp, const LogitScale& ls, hipStream_t s);
 int launch_set_float(float* dst, float v, hipStream_t s);
 int launch_delay_us(int us, hipStream_t s);
 int launch_beam1_finalize(int* ids, int L, const int* beam_len, int B, hipStream_t s);
