@@ -29,6 +29,7 @@ for st in $STAGES; do
       done
       cd "$R"
       python tools/pmc_summary.py gpurun_out/pmc gpurun_out/pmc r3 > gpurun_out/pmc/summary.log 2>&1; tail -12 gpurun_out/pmc/summary.log
+      cp gpurun_out/pmc/r3_pmc_summary.json profiles/ 2>/dev/null   # a later "bench" stage of the same call reads it
       python - <<'PY'
 import json
 try:
