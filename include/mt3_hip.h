@@ -172,7 +172,8 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch,
  * stops once every row has emitted EOS / finished its search (this synchronises the stream).
  * Schedule: a batch of >= 128 rows is decoded as TWO row groups, each on an engine-owned stream restricted to half of
  * the compute units (hipExtStreamCreateWithCUMask) and driven by its own host thread with direct launches, so that one
- * group's HBM-bound attention runs beside the other group's latency-bound GEMMs (+6 % at batch 256); the caller's
+ * group's HBM-bound attention runs beside the other group's latency-bound GEMMs (+6 % at batch 256; a masked stream
+ * owns a hardware queue -- two plain streams serialise); the caller's
  * stream is ordered before and after the groups by events, the ids are bit-identical to the single-stream schedule
  * (rows are independent), the call returns when both groups are ENQUEUED.  MT3_DECODE_SINGLE_STREAM / _NO_GRAPH /
  * _CHAINS(n), decode_chains > 1 or MT3_OPT_NO_CU_PARTITION keep everything on `stream`. */

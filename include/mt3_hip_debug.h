@@ -27,10 +27,12 @@ int mt3_debug_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int
 
 /* EXPERIMENT (VERDICT r2, next #2 iii): the decode batch dealt to `n_groups` (2 .. 4) row groups, each driven by its own
  * host thread with DIRECT launches (no graph) on its own stream created with hipExtStreamCreateWithCUMask, so that one
- * group's HBM-bound attention kernels run beside another group's latency-bound GEMMs on DISJOINT compute units.
+ * group's HBM-bound attention kernels run beside another group's latency-bound GEMMs (measured: it is the hardware queue
+ * a masked stream owns that makes them overlap -- full masks do as well as disjoint ones, plain streams serialise).
  * mask_mode: 0 = no CU mask (plain streams), 1 = group g owns the g-th contiguous block of CU-mask bits, 2 = group g
  * owns the bits i with i % n_groups == g; 3 .. 6 = as 2, and group g starts after a device-side delay of g x
- * {8, 15, 25, 40} us (does a phase offset between the groups survive, and does it help?).  Greedy decode only; ids are identical to mt3_engine_decode's (rows are
+ * {8, 15, 25, 40} us (does a phase offset between the groups survive, and does it help?); 7 .. 9 (two groups only) =
+ * OVERLAPPING masks, each group on 5/8, 3/4, 7/8 of the CUs (bits i % 8 < k / i % 8 >= 8 - k), the middle ones shared; 10 = every group's stream with a FULL mask.  Greedy decode only; ids are identical to mt3_engine_decode's (rows are
  * independent).  Synchronises: returns when every group has finished.  h_ms (may be NULL) receives the wall time of
  * the decode loop in milliseconds. */
 int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t n_groups, int32_t mask_mode,

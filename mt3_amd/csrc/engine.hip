@@ -169,8 +169,9 @@ struct mt3_engine {
   // CU-partitioned decode schedule (round 3): the batch as two row groups, each on its own stream restricted to half of
   // the compute units (hipExtStreamCreateWithCUMask, interleaved mask bits), each driven by its own host thread with
   // direct launches -- one group's HBM-bound attention kernels run beside the other group's latency-bound GEMMs.
-  // Measured on MI355X at B = 256: 591 ms per 1024-step decode against 629 ms for one graph-replayed chain (without
-  // the masks the same two streams take 818 ms: every kernel then spreads over the whole chip and the groups serialise).
+  // Measured on MI355X at B = 256: 591 ms per 1024-step decode against 629 ms for one graph-replayed chain.  Two PLAIN
+  // streams take 818 ms (the groups serialise); two streams with FULL masks take the same 588 ms as the disjoint halves:
+  // what a masked stream brings is a hardware queue of its own (mt3_debug_engine_decode_split, mask_mode 7 .. 10).
   hipStream_t part_stream[4] = {};
   hipEvent_t part_done[4] = {};
   hipEvent_t part_begin = nullptr;
@@ -1283,10 +1284,16 @@ int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_step
   if (batch <= 0 || batch != e->cur_batch || num_steps <= 0 || num_steps > c.max_decode_len || !d_ids)
     return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: bad batch / steps / ids");
   // mask_mode 3 .. 6: interleaved masks + group g starts after a device-side delay of g x {8, 15, 25, 40} us
-  if (n_groups < 2 || n_groups > 4 || batch / n_groups < 16 || mask_mode < 0 || mask_mode > 6)
-    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: 2 .. 4 groups of >= 16 rows, mask_mode 0 .. 6");
-  static const int kStagger[7] = {0, 0, 0, 8, 15, 25, 40};
-  const int stagger_us = kStagger[mask_mode];
+  // mask_mode 7 .. 9 (two groups): OVERLAPPING masks -- each group owns 5/8, 3/4, 7/8 of the CUs (bits i % 8 < k for
+  // group 0, i % 8 >= 8 - k for group 1), the middle ones are shared
+  // mask_mode 10: every group's stream carries a FULL mask (all CUs): is it the disjoint CUs that help, or the hardware
+  // queue of its own that a masked stream gets?
+  if (n_groups < 2 || n_groups > 4 || batch / n_groups < 16 || mask_mode < 0 || mask_mode > 10 ||
+      (mask_mode > 6 && mask_mode < 10 && n_groups != 2))
+    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: 2 .. 4 groups of >= 16 rows, mask_mode 0 .. 10");
+  static const int kStagger[11] = {0, 0, 0, 8, 15, 25, 40, 0, 0, 0, 0};
+  static const int kOwned[11] = {0, 0, 0, 0, 0, 0, 0, 5, 6, 7, 8};
+  const int stagger_us = kStagger[mask_mode], owned = kOwned[mask_mode];
   if (mask_mode > 2) mask_mode = 2;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = c.max_decode_len;
@@ -1312,7 +1319,8 @@ int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_step
     } else {
       std::vector<uint32_t> mask(words, 0u);
       for (int i = 0; i < n_cu; ++i) {
-        const bool mine = mask_mode == 1 ? (i * n_groups / n_cu == g) : (i % n_groups == g);
+        const bool mine = owned ? (g == 0 ? i % 8 < owned : i % 8 >= 8 - owned)
+                                : mask_mode == 1 ? (i * n_groups / n_cu == g) : (i % n_groups == g);
         if (mine) mask[i >> 5] |= 1u << (i & 31);
       }
       MT3_HIP_CHECK(hipExtStreamCreateWithCUMask(&gs[g], static_cast<uint32_t>(words), mask.data()));

@@ -42,7 +42,14 @@ with torch.cuda.stream(stream):
                                                         (2, "interleaved CU-mask bits"))]
     cases += [(2, m, "interleaved, stagger %d us" % us) for m, us in ((3, 8), (4, 15), (5, 25), (6, 40))]
     cases += [(2, 2, "interleaved CU-mask bits (again)")]
-    if os.environ.get("AB_SPLIT_ONLY"):
+    cases += [(2, m, "OVERLAPPING masks, %d/8 of the CUs each" % k) for m, k in ((7, 5), (8, 6), (9, 7))]
+    cases += [(g, 10, "FULL mask (all CUs) on every stream") for g in (2, 3, 4)]
+    cases += [(2, 2, "interleaved CU-mask bits (3rd)")]
+    if os.environ.get("AB_SPLIT_ONLY") == "overlap":
+        cases = [c for c in cases if c[1] in (7, 8, 9, 10) or (c[0] == 2 and c[1] == 2)][1:]
+    elif os.environ.get("AB_SPLIT_ONLY") == "full":
+        cases = [c for c in cases if c[1] == 10 or (c[0] == 2 and c[1] == 2)][1:]
+    elif os.environ.get("AB_SPLIT_ONLY"):
         cases = [c for c in cases if c[0] == 2 and c[1] >= 2]
     for groups, mode, label in cases:
         if True:

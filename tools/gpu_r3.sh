@@ -101,6 +101,10 @@ PY
       timeout ${SPLIT_TIMEOUT:-240} python tools/ab_split.py > gpurun_out/ab_split.log 2>&1
       echo "exit $? : ab_split"; grep -v "^/opt\|Warning" gpurun_out/ab_split.log | tail -14
       ;;
+    fepmc)
+      bash tools/gpu_pmc_fe.sh > gpurun_out/pmc_fe.log 2>&1
+      echo "exit $? : pmc_fe"; grep "exit\|_per_frame\|share\|over_busy\|per_wave_cycle\|kernel_us" gpurun_out/pmc_fe.log | cut -c1-200 | tail -30
+      ;;
     *) echo "unknown stage $st";;
   esac
 done
