@@ -424,7 +424,7 @@ def main():
                     "decode_ms_without_cross_attn": t_nocross,
                     "small_kernel_us_per_step": (t_noself + t_nocross - t_full) * 1e3 / S,
                     "whole_step_hbm_frac": (self_bytes + cross_bytes) / (t_full * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    # the schedule the headline runs (CU-partitioned row groups at this batch): same bytes, its own clock
+                    # the schedule the headline runs (row groups at this batch): same bytes, its own clock
                     "decode_ms_product_schedule": t_prod, "product_schedule_row_groups": prod_groups,
                     "whole_step_hbm_frac_product_schedule": (self_bytes + cross_bytes) / (t_prod * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "cross_attn": {"achieved": cross_bytes / launches / (cross_us * 1e-6) / 1e9,
@@ -589,7 +589,7 @@ def main():
                        "file_segments": args.file_segments,
                        "parallelism": "dp%d (segments sharded, weights replicated, ONE RCCL gather of the token rows to rank 0)"
                                       % world if world > 1 else "single GPU",
-                       "decode_schedule": ("CU-partitioned: %d row groups on CU-masked streams, one host thread each, "
+                       "decode_schedule": ("%d row groups, each on a stream with its own hardware queue, one host thread each, "
                                            "direct launches" % decode_groups) if decode_groups > 1 else
                        ("one stream, hipGraph replay per step" if used_graph else
                         "one stream, DIRECT LAUNCHES (graph capture failed)"),

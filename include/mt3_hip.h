@@ -133,8 +133,8 @@ enum {
    * rides in the previous layer's MLP out-projection launch, and layer 0's comes from two table rows); the
    * cross-attention query stays folded */
   MT3_OPT_SEPARATE_QKV_PROJECTION = 8,
-  /* never use the CU-partitioned decode schedule (see mt3_engine_decode): every decode stays on the caller's stream */
-  MT3_OPT_NO_CU_PARTITION = 16
+  /* never use the row-group decode schedule (see mt3_engine_decode): every decode stays on the caller's stream */
+  MT3_OPT_NO_ROW_GROUPS = 16
 };
 
 typedef struct mt3_engine mt3_engine;
@@ -170,13 +170,14 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch,
  * are zero-filled).  d_first_logits: [batch, vocab] f32 logits of step 0, or NULL.
  * With MT3_DECODE_EARLY_EXIT the host polls a device flag every 32 steps and
  * stops once every row has emitted EOS / finished its search (this synchronises the stream).
- * Schedule: a batch of >= 128 rows is decoded as TWO row groups, each on an engine-owned stream restricted to half of
- * the compute units (hipExtStreamCreateWithCUMask) and driven by its own host thread with direct launches, so that one
- * group's HBM-bound attention runs beside the other group's latency-bound GEMMs (+6 % at batch 256; a masked stream
- * owns a hardware queue -- two plain streams serialise); the caller's
- * stream is ordered before and after the groups by events, the ids are bit-identical to the single-stream schedule
- * (rows are independent), the call returns when both groups are ENQUEUED.  MT3_DECODE_SINGLE_STREAM / _NO_GRAPH /
- * _CHAINS(n), decode_chains > 1 or MT3_OPT_NO_CU_PARTITION keep everything on `stream`. */
+ * Schedule: a batch of >= 128 rows is decoded as 2 or 4 ROW GROUPS (bf16 operands: 2 from 128 rows, 4 from 512; f32:
+ * 2 from 128, 4 from 256), each on an engine-owned stream with a hardware queue of its own (created with
+ * hipExtStreamCreateWithCUMask and a mask of all compute units: two plain HIP streams serialise)
+ * and driven by its own host thread with direct launches, so that one group's HBM-bound attention runs beside the other
+ * groups' latency-bound GEMMs (+6 % at batch 256 in bf16, +7 % in f32); the caller's stream is ordered before and after
+ * the groups by events, the ids are bit-identical to the single-stream schedule (rows are independent), the call returns
+ * when all groups have FINISHED (each group's host thread waits for its stream: a stream nobody waits on runs 7 % slower).  MT3_DECODE_SINGLE_STREAM / _NO_GRAPH /
+ * _CHAINS(n), decode_chains > 1 or MT3_OPT_NO_ROW_GROUPS keep everything on `stream`. */
 enum {
   MT3_DECODE_NO_GRAPH = 1,
   MT3_DECODE_EARLY_EXIT = 2,
@@ -209,7 +210,7 @@ enum { MT3_STATUS_GRAPH_FALLBACKS = 0, MT3_STATUS_LAST_DECODE_USED_GRAPH = 1, MT
        MT3_STATUS_KV_FP8 = 3, MT3_STATUS_Q_FOLD = 4 /* cross q-projection folded into the neighbouring launches */,
        MT3_STATUS_DENSE_FP8 = 5 /* encoder dense layers on the MXFP8 path */,
        MT3_STATUS_QKV_FOLD = 6 /* the decoder layers' q/k/v projections folded into the preceding launches */,
-       MT3_STATUS_LAST_DECODE_GROUPS = 7 /* 2: the most recent decode ran CU-partitioned; 1: on the caller's stream */,
+       MT3_STATUS_LAST_DECODE_GROUPS = 7 /* row groups of the most recent decode (2 or 4: the row-group schedule); 1: on the caller's stream */,
        MT3_STATUS_PARTITION_FALLBACKS = 8 /* decodes that wanted the partitioned schedule but could not set it up */ };
 int mt3_engine_status(const mt3_engine* e, int32_t what);
 

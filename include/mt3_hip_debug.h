@@ -32,7 +32,13 @@ int mt3_debug_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int
  * mask_mode: 0 = no CU mask (plain streams), 1 = group g owns the g-th contiguous block of CU-mask bits, 2 = group g
  * owns the bits i with i % n_groups == g; 3 .. 6 = as 2, and group g starts after a device-side delay of g x
  * {8, 15, 25, 40} us (does a phase offset between the groups survive, and does it help?); 7 .. 9 (two groups only) =
- * OVERLAPPING masks, each group on 5/8, 3/4, 7/8 of the CUs (bits i % 8 < k / i % 8 >= 8 - k), the middle ones shared; 10 = every group's stream with a FULL mask.  Greedy decode only; ids are identical to mt3_engine_decode's (rows are
+ * OVERLAPPING masks, each group on 5/8, 3/4, 7/8 of the CUs (bits i % 8 < k / i % 8 >= 8 - k), the middle ones shared; 10 = every group's stream with a FULL mask (what the product
+ * uses); 11 .. 14 = 10 with one property of the product path each (11 the caller drives group 0, 12 own done slots and
+ * begin / done events, 13 streams kept across calls, 14 group threads return when enqueued and the caller synchronises
+ * the group streams); 15 / 16 = the product's own decode_partitioned() on the engine's / on fresh streams; 17 = this
+ * function's loop on the engine's streams; 32 + bits = full masks with a combination (1 caller drives group 0, 2 events,
+ * 4 threads do not wait, 8 with 2 and 4: only the caller's stream -- which waits for the done events -- is synchronised:
+ * the variant that measures 6-15 % slower, i.e. every group stream needs a host thread waiting on it).  Greedy decode only; ids are identical to mt3_engine_decode's (rows are
  * independent).  Synchronises: returns when every group has finished.  h_ms (may be NULL) receives the wall time of
  * the decode loop in milliseconds. */
 int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t n_groups, int32_t mask_mode,

@@ -18,7 +18,7 @@ MT3_BF16, MT3_F32, MT3_FP8_E4M3 = 0, 1, 2
 EPI_STORE, EPI_RESID, EPI_GEGLU, EPI_POS, EPI_F32, EPI_HEADS = range(6)
 DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SINGLE_STREAM = 1, 2, 4, 8
 (OPT_SINGLE_RESIDUAL_STREAM, OPT_SEPARATE_PROJECTIONS, OPT_ENCODER_SINGLE_RESIDUAL_STREAM,
- OPT_SEPARATE_QKV_PROJECTION, OPT_NO_CU_PARTITION) = 1, 2, 4, 8, 16              # mt3_engine_config.options
+ OPT_SEPARATE_QKV_PROJECTION, OPT_NO_ROW_GROUPS) = 1, 2, 4, 8, 16              # mt3_engine_config.options
 # include/mt3_hip_debug.h (measurement / fault injection; not the product ABI)
 DEBUG_SKIP_SELF_ATTN, DEBUG_SKIP_CROSS_ATTN = 1, 2
 (DEBUG_KNOB_DEC_ATTN_WAVES, DEBUG_KNOB_DEC_ATTN_FP8_WAVES, DEBUG_KNOB_NO_LDS_DMA_GEMM, DEBUG_KNOB_F32_SPLIT_K,

@@ -334,7 +334,7 @@ int launch_argmax_step(float* logits, int vocab, int* ids, int ids_stride, int* 
 }
 
 // busy-wait on the device for ~us microseconds (one lane; wall_clock64 ticks at 100 MHz): the stagger of the
-// CU-partition experiment (mt3_debug_engine_decode_split)
+// row-group experiment (mt3_debug_engine_decode_split)
 __global__ void delay_kernel(long long ticks) {
   const long long t0 = wall_clock64();
   while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);

@@ -166,12 +166,12 @@ struct mt3_engine {
   int* beam_len = nullptr;       // [max_batch]
   float* beam_cfg = nullptr;     // [0] brevity penalty of the loop bound, [1 + n] brevity_penalty(n)
 
-  // CU-partitioned decode schedule (round 3): the batch as two row groups, each on its own stream restricted to half of
-  // the compute units (hipExtStreamCreateWithCUMask, interleaved mask bits), each driven by its own host thread with
-  // direct launches -- one group's HBM-bound attention kernels run beside the other group's latency-bound GEMMs.
-  // Measured on MI355X at B = 256: 591 ms per 1024-step decode against 629 ms for one graph-replayed chain.  Two PLAIN
-  // streams take 818 ms (the groups serialise); two streams with FULL masks take the same 588 ms as the disjoint halves:
-  // what a masked stream brings is a hardware queue of its own (mt3_debug_engine_decode_split, mask_mode 7 .. 10).
+  // Row-group decode schedule (round 3): the batch as 2 or 4 row groups (row_groups_for), each on an engine-owned stream
+  // with a hardware queue of its own, each driven by its own host thread with direct launches -- one group's HBM-bound
+  // attention kernels run beside the other groups' latency-bound GEMMs.  The streams are created with
+  // hipExtStreamCreateWithCUMask and a mask of ALL compute units: measured at B = 256 (bf16), two PLAIN streams take
+  // 818 ms per 1024-step decode (HIP multiplexes them onto its queue pool and the groups serialise), two masked ones
+  // 588 ms whether the masks are disjoint halves, overlap, or cover every CU (one graph-replayed chain: 626 ms).
   hipStream_t part_stream[4] = {};
   hipEvent_t part_done[4] = {};
   hipEvent_t part_begin = nullptr;
@@ -767,7 +767,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
   if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM |
-                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_CU_PARTITION))
+                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -1099,6 +1099,16 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
 // The decode loop as `groups` row groups on CU-masked streams, one host thread each (mt3_engine::part_stream).  The
 // caller's stream is never synchronised unless EARLY_EXIT polls: the groups start after an event recorded on it and it
 // waits for an event per group at the end.  MT3_ERR_CAPACITY = the streams could not be set up (caller falls back).
+// Row groups of the product decode schedule (mt3_engine::part_stream).  Measured on MI355X, ms per 1024-step decode,
+// 1 / 2 / 4 groups (profiles/r3_ab_row_groups_*.txt): bf16 B = 256: 626 / 588 / 608, B = 512: 1113 / 1048 / 1013;
+// f32 B = 128: 747 / 684 / 737, B = 256: 1178 / 1132 / 1098 -- groups of ~128 rows for bf16 operands, ~64 for f32.
+// (Three groups are never better than two or four.)
+static int row_groups_for(const mt3_engine_config& c, int batch) {
+  const bool f32 = c.compute_dtype != MT3_BF16;
+  if (batch >= (f32 ? 256 : 512)) return 4;
+  return batch >= 128 ? 2 : 1;
+}
+
 static int decode_partitioned(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int skip, int groups,
                               int* steps_run, hipStream_t s) {
   int n_cu = 0, dev = 0;
@@ -1107,8 +1117,10 @@ static int decode_partitioned(mt3_engine* e, int32_t batch, int32_t num_steps, i
     return MT3_ERR_CAPACITY;
   for (int g = 0; g < groups; ++g) {
     if (!e->part_stream[g]) {
+      // a mask of ALL compute units: the stream is created through the CU-mask entry point for the hardware queue of
+      // its own that comes with it, not to restrict it (see mt3_engine::part_stream)
       std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
-      for (int i = g; i < n_cu; i += groups) mask[i >> 5] |= 1u << (i & 31);       // interleaved CU-mask bits
+      for (int i = 0; i < n_cu; ++i) mask[i >> 5] |= 1u << (i & 31);
       if (hipExtStreamCreateWithCUMask(&e->part_stream[g], static_cast<uint32_t>(mask.size()), mask.data()) != hipSuccess) {
         e->part_stream[g] = nullptr;
         (void)hipGetLastError();
@@ -1141,6 +1153,11 @@ static int decode_partitioned(mt3_engine* e, int32_t batch, int32_t num_steps, i
     }
     if (rcs[g] != MT3_OK) errs[g] = mt3_last_error();
     if (he == hipSuccess) he = hipEventRecord(e->part_done[g], gs);
+    // The group's host thread WAITS for its stream.  Measured (mt3_debug_engine_decode_split, mask_mode 32 + bits; f32,
+    // B = 256, 4 groups): 1095 ms per 1024-step decode when every group stream has a host thread in
+    // hipStreamSynchronize, 1166-1170 ms when only the caller's stream (which waits for the done events) is
+    // synchronised -- a stream nobody waits on retires its commands through the runtime's interrupt path.
+    if (he == hipSuccess) he = hipStreamSynchronize(gs);
     if (rcs[g] == MT3_OK && he != hipSuccess) {
       rcs[g] = MT3_ERR_HIP;
       errs[g] = hipGetErrorString(he);
@@ -1205,19 +1222,17 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
     MT3_HIP_CHECK(hipMemsetAsync(e->beam_f, 0, static_cast<size_t>(2) * c.max_batch * 4, s));
     MT3_HIP_CHECK(hipMemsetAsync(e->beam_len, 0xFF, static_cast<size_t>(c.max_batch) * 4, s));   // -1
   }
-  // ---- the CU-partitioned schedule (see mt3_engine::part_stream): batches of >= 128 rows, unless the caller asked for
+  // ---- the row-group schedule (see mt3_engine::part_stream): batches of >= 128 rows, unless the caller asked for
   // one stream / direct launches / graph chains, or wants per-step logits (those live on the caller's stream)
   e->last_groups = 1;
-  // (bf16 operands only: the f32 engine's decode GEMMs are bound by each CU's L1 bandwidth, not by latency -- halving
-  // the CUs per group stretches them by more than the overlap returns: measured 1238 against 1213 ms per step)
-  if (batch >= 128 && c.compute_dtype == MT3_BF16 && !(flags & (MT3_DECODE_NO_GRAPH | MT3_DECODE_SINGLE_STREAM)) &&
-      ((flags >> 8) & 0xF) == 0 &&
-      e->cfg.decode_chains <= 1 && !(c.options & MT3_OPT_NO_CU_PARTITION) && debug_skip == 0 && !d_forced &&
+  const int groups = row_groups_for(c, batch);
+  if (groups > 1 && !(flags & (MT3_DECODE_NO_GRAPH | MT3_DECODE_SINGLE_STREAM)) && ((flags >> 8) & 0xF) == 0 &&
+      e->cfg.decode_chains <= 1 && !(c.options & MT3_OPT_NO_ROW_GROUPS) && debug_skip == 0 && !d_forced &&
       !d_step_logits && !d_first_logits) {
     int ran = 0;
-    const int prc = decode_partitioned(e, batch, num_steps, flags, skip, 2, &ran, s);
+    const int prc = decode_partitioned(e, batch, num_steps, flags, skip, groups, &ran, s);
     if (prc == MT3_OK) {
-      e->last_groups = 2;
+      e->last_groups = groups;
       e->last_used_graph = 0;
       if (beam1) MT3_TRY(mt3k::launch_beam1_finalize(e->ids, L, e->beam_len, batch, s));
       MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
@@ -1288,12 +1303,28 @@ int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_step
   // group 0, i % 8 >= 8 - k for group 1), the middle ones are shared
   // mask_mode 10: every group's stream carries a FULL mask (all CUs): is it the disjoint CUs that help, or the hardware
   // queue of its own that a masked stream gets?
-  if (n_groups < 2 || n_groups > 4 || batch / n_groups < 16 || mask_mode < 0 || mask_mode > 10 ||
+  // mask_mode 11 .. 13 = 10 with ONE property of the product path (decode_partitioned) each: 11 = group 0 is driven by
+  // the calling thread, 12 = every group counts its finished rows in a slot of its own and is bracketed by the
+  // begin / done events, 13 = the streams are created once per process and kept
+  // mask_mode 32 + bits: full masks with a COMBINATION of the product path's properties -- 1 = the caller drives group 0,
+  // 2 = own done slots + begin / done events, 4 = threads return when enqueued, 8 = (with 2 and 4) the caller's stream
+  // waits for the done events and only IT is synchronised
+  const int combo = mask_mode >= 32 && mask_mode < 48 ? mask_mode - 32 : 0;
+  if (mask_mode >= 32 && mask_mode < 48) mask_mode = 10;
+  if (n_groups < 2 || n_groups > 4 || batch / n_groups < 16 || mask_mode < 0 || mask_mode > 17 ||
       (mask_mode > 6 && mask_mode < 10 && n_groups != 2))
-    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: 2 .. 4 groups of >= 16 rows, mask_mode 0 .. 10");
-  static const int kStagger[11] = {0, 0, 0, 8, 15, 25, 40, 0, 0, 0, 0};
-  static const int kOwned[11] = {0, 0, 0, 0, 0, 0, 0, 5, 6, 7, 8};
+    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: 2 .. 4 groups of >= 16 rows, mask_mode 0 .. 17");
+  static const int kStagger[18] = {0, 0, 0, 8, 15, 25, 40, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  static const int kOwned[18] = {0, 0, 0, 0, 0, 0, 0, 5, 6, 7, 8, 8, 8, 8, 8, 8, 8, 8};
   const int stagger_us = kStagger[mask_mode], owned = kOwned[mask_mode];
+  // 14 = the group threads return once their launches are ENQUEUED (the caller synchronises the streams after the
+  // join), 15 = the product's own decode_partitioned(), timed here
+  const bool caller_drives = mask_mode == 11 || (combo & 1), bracket = mask_mode == 12 || (combo & 2), keep = mask_mode == 13,
+             late_sync = mask_mode == 14 || (combo & 4), tail_on_s = (combo & 14) == 14;
+  // 16 = decode_partitioned() on FRESH streams (the engine's own set aside for the call), 17 = this function's loop on
+  // the ENGINE's streams
+  const bool product_fn = mask_mode == 15 || mask_mode == 16, fresh_for_product = mask_mode == 16;
+  const bool engine_streams = mask_mode == 17;
   if (mask_mode > 2) mask_mode = 2;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = c.max_decode_len;
@@ -1308,12 +1339,49 @@ int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_step
                                c.compute_dtype == MT3_BF16 ? e->y_ct : nullptr, e->y_ss, batch, c.emb_dim, rp, s));
   }
   MT3_HIP_CHECK(hipStreamSynchronize(s));
+  if (product_fn) {
+    int ran = 0;
+    hipStream_t saved[4];
+    for (int g = 0; g < 4; ++g) {
+      saved[g] = e->part_stream[g];
+      if (fresh_for_product) e->part_stream[g] = nullptr;
+    }
+    const auto p0 = std::chrono::steady_clock::now();
+    const int prc = decode_partitioned(e, batch, num_steps, 0, 0, n_groups, &ran, s);
+    (void)hipStreamSynchronize(s);
+    if (h_ms) *h_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - p0).count();
+    if (fresh_for_product)
+      for (int g = 0; g < 4; ++g) {
+        if (e->part_stream[g]) (void)hipStreamDestroy(e->part_stream[g]);
+        e->part_stream[g] = saved[g];
+      }
+    MT3_TRY(prc);
+    MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
+    MT3_HIP_CHECK(hipStreamSynchronize(s));
+    return MT3_OK;
+  }
   int n_cu = 0, dev = 0;
   MT3_HIP_CHECK(hipGetDevice(&dev));
   MT3_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
   const int words = (n_cu + 31) / 32;
   std::vector<hipStream_t> gs(n_groups, nullptr);
+  static hipStream_t kept[4] = {};
+  hipEvent_t ev_begin = nullptr, ev_done[4] = {};
+  if (bracket) {
+    MT3_HIP_CHECK(hipEventCreateWithFlags(&ev_begin, hipEventDisableTiming));
+    for (int g = 0; g < n_groups; ++g) MT3_HIP_CHECK(hipEventCreateWithFlags(&ev_done[g], hipEventDisableTiming));
+    MT3_HIP_CHECK(hipEventRecord(ev_begin, s));
+  }
   for (int g = 0; g < n_groups; ++g) {
+    if (engine_streams) {
+      if (!e->part_stream[g]) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: run a product decode first");
+      gs[g] = e->part_stream[g];
+      continue;
+    }
+    if (keep && kept[g]) {
+      gs[g] = kept[g];
+      continue;
+    }
     if (mask_mode == 0) {
       MT3_HIP_CHECK(hipStreamCreateWithFlags(&gs[g], hipStreamNonBlocking));
     } else {
@@ -1324,31 +1392,47 @@ int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_step
         if (mine) mask[i >> 5] |= 1u << (i & 31);
       }
       MT3_HIP_CHECK(hipExtStreamCreateWithCUMask(&gs[g], static_cast<uint32_t>(words), mask.data()));
+      if (keep) kept[g] = gs[g];
     }
   }
   std::vector<int> rcs(n_groups, MT3_OK);
   std::vector<std::string> errs(n_groups);
   const auto t0 = std::chrono::steady_clock::now();
   {
+    auto body = [&](int g) {
+      (void)hipSetDevice(dev);
+      int row0, rows;
+      chain_rows(batch, n_groups, g, &row0, &rows);
+      if (bracket) (void)hipStreamWaitEvent(gs[g], ev_begin, 0);
+      if (stagger_us && g) rcs[g] = mt3k::launch_delay_us(g * stagger_us, gs[g]);
+      for (int t = 0; t < num_steps && rcs[g] == MT3_OK; ++t)
+        rcs[g] = enqueue_chain_step(e, row0, rows, g, batch, 0, gs[g], bracket ? g : 0);
+      if (rcs[g] != MT3_OK) errs[g] = mt3_last_error();
+      if (bracket) (void)hipEventRecord(ev_done[g], gs[g]);
+      const hipError_t he = late_sync ? hipSuccess : hipStreamSynchronize(gs[g]);
+      if (rcs[g] == MT3_OK && he != hipSuccess) {
+        rcs[g] = MT3_ERR_HIP;
+        errs[g] = hipGetErrorString(he);
+      }
+    };
     std::vector<std::thread> th;
-    for (int g = 0; g < n_groups; ++g)
-      th.emplace_back([&, g]() {
-        (void)hipSetDevice(dev);
-        int row0, rows;
-        chain_rows(batch, n_groups, g, &row0, &rows);
-        if (stagger_us && g) rcs[g] = mt3k::launch_delay_us(g * stagger_us, gs[g]);
-        for (int t = 0; t < num_steps && rcs[g] == MT3_OK; ++t) rcs[g] = enqueue_chain_step(e, row0, rows, g, batch, 0, gs[g]);
-        if (rcs[g] != MT3_OK) errs[g] = mt3_last_error();
-        const hipError_t he = hipStreamSynchronize(gs[g]);
-        if (rcs[g] == MT3_OK && he != hipSuccess) {
-          rcs[g] = MT3_ERR_HIP;
-          errs[g] = hipGetErrorString(he);
-        }
-      });
+    for (int g = caller_drives ? 1 : 0; g < n_groups; ++g) th.emplace_back(body, g);
+    if (caller_drives) body(0);
     for (std::thread& t : th) t.join();
+    if (tail_on_s) {
+      for (int g = 0; g < n_groups; ++g) (void)hipStreamWaitEvent(s, ev_done[g], 0);
+      (void)hipStreamSynchronize(s);
+    } else if (late_sync) {
+      for (hipStream_t g : gs) (void)hipStreamSynchronize(g);
+    }
   }
   const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  for (hipStream_t g : gs) (void)hipStreamDestroy(g);
+  if (!keep && !engine_streams)
+    for (hipStream_t g : gs) (void)hipStreamDestroy(g);
+  if (bracket) {
+    (void)hipEventDestroy(ev_begin);
+    for (int g = 0; g < n_groups; ++g) (void)hipEventDestroy(ev_done[g]);
+  }
   for (int g = 0; g < n_groups; ++g)
     if (rcs[g] != MT3_OK) return mt3::fail(rcs[g], "mt3_debug_engine_decode_split: group " + std::to_string(g) + ": " + errs[g]);
   if (h_ms) *h_ms = ms;

@@ -206,7 +206,7 @@ class Transformer:
         """Decode for the batch of the last `encode`: greedy until EOS, or with `beam1` the selection
         rule of t5x beam_search(num_decodes=1, alpha=0.6) that the reference's predict_tokens runs.
         Returns int32 CUDA [B, L] ids (and the step-0 logits [B, V] if asked).  Batches of >= 128 rows run
-        CU-partitioned (two row groups on CU-masked streams, include/mt3_hip.h) unless `single_stream`."""
+        decoded as 2 or 4 row groups on streams with hardware queues of their own (include/mt3_hip.h) unless `single_stream`."""
         import torch
         B, L = self._batch, self.max_decode_length
         ids = torch.empty((B, L), device="cuda", dtype=torch.int32)
@@ -236,7 +236,7 @@ class Transformer:
         return ids
 
     def debug_decode_split(self, num_steps: Optional[int] = None, groups: int = 2, mask_mode: int = 1):
-        """mt3_debug_engine_decode_split: the CU-partitioned two-stream overlap experiment (one host thread and one
+        """mt3_debug_engine_decode_split: the row-group overlap experiment (one host thread and one
         CU-masked stream per row group, direct launches).  Returns (ids, wall ms of the decode loop)."""
         import torch
         B, L = self._batch, self.max_decode_length

@@ -362,9 +362,9 @@ def test_folded_qkv_projection_bf16_and_fp8_caches_against_the_separate_launches
             assert d.max() < (2e-2 if not kv else 5e-2) and np.median(d) < 8e-3, (kv, name, d.max(), np.median(d))
 
 
-def test_cu_partitioned_decode_schedule_is_bit_identical():
-    """Batches of >= 128 rows decode as two row groups on CU-masked streams, one host thread each (include/mt3_hip.h,
-    "Schedule").  Rows are independent, so the ids must equal the single-stream graph-replayed schedule bit for bit:
+def test_row_group_decode_schedule_is_bit_identical():
+    """Batches of >= 128 rows decode as row groups on streams with hardware queues of their own, one host thread each
+    (include/mt3_hip.h, "Schedule").  Rows are independent, so the ids must equal the single-stream graph-replayed schedule bit for bit:
     greedy, beam-1, with early exit (every group stops on its own rows), odd batch sizes; the experiment entry
     (mt3_debug_engine_decode_split) as well."""
     cfg = network.T5Config(dtype="bfloat16", num_encoder_layers=2, num_decoder_layers=3)
@@ -382,7 +382,7 @@ def test_cu_partitioned_decode_schedule_is_bit_identical():
         a = eng.decode(num_steps=96, single_stream=True, **kw)
         assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 1 and eng.status(_lib.STATUS_LAST_DECODE_USED_GRAPH) == 1
         b = eng.decode(num_steps=96, **kw)
-        assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 2, "a batch of 131 rows should run CU-partitioned"
+        assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 2, "a batch of 131 rows should run as two row groups"
         assert eng.status(_lib.STATUS_PARTITION_FALLBACKS) == 0
         assert torch.equal(a, b), kw
     full = eng.decode(num_steps=L, single_stream=True)
@@ -395,11 +395,39 @@ def test_cu_partitioned_decode_schedule_is_bit_identical():
     eng.encode(lm[:64])
     eng.decode(num_steps=8)
     assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 1
-    e2 = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=_lib.OPT_NO_CU_PARTITION)
+    e2 = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=_lib.OPT_NO_ROW_GROUPS)
     e2.load_params(params)
     e2.encode(lm)
     c = e2.decode(num_steps=96)
     assert e2.status(_lib.STATUS_LAST_DECODE_GROUPS) == 1 and torch.equal(c[:, :96], full[:, :96])
+
+
+@pytest.mark.parametrize("dtype,B,groups,options", [
+    ("float32", 259, 4, 0), ("float32", 130, 2, 0), ("bfloat16", 515, 4, 0),
+    ("float32", 257, 4, _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_SEPARATE_PROJECTIONS)])
+def test_row_group_counts_follow_operand_type_and_batch(dtype, B, groups, options):
+    """The group count of the schedule (engine.hip: row_groups_for -- bf16 operands: 2 groups from 128 rows, 4 from
+    512; f32: 2 from 128, 4 from 256): the ids of every count equal the single-stream schedule bit for bit (greedy,
+    beam-1, early exit), for ragged group sizes and for the f32 engine's round-2 layout as well."""
+    cfg = network.T5Config(dtype=dtype, num_encoder_layers=2, num_decoder_layers=3)
+    params = network.init_random_params(cfg, seed=6, norm_scale_jitter=0.1)
+    k = params["decoder/logits_dense/kernel"].copy()
+    k[:, 1] *= 3.0
+    params["decoder/logits_dense/kernel"] = k
+    from mt3_amd import spectrograms, synthetic
+    lm = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(B, seed=9), None)
+    eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=options)
+    eng.load_params(params)
+    eng.encode(lm)
+    for kw in (dict(), dict(beam1=True)):
+        a = eng.decode(num_steps=64, single_stream=True, **kw)
+        assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 1
+        b = eng.decode(num_steps=64, **kw)
+        assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == groups and eng.status(_lib.STATUS_PARTITION_FALLBACKS) == 0
+        assert torch.equal(a, b), kw
+    full = eng.decode(num_steps=L, single_stream=True)
+    ee = eng.decode(num_steps=L, early_exit=True)
+    assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == groups and torch.equal(ee, full)
 
 
 def test_bench_batch_256_bf16_against_the_f32_engine_at_all_1024_positions():

@@ -1,4 +1,4 @@
-"""Robustness soak of the CU-partitioned decode path: 60 back-to-back decodes (greedy / beam-1 / early exit alternating)
+"""Robustness soak of the row-group decode path: 60 back-to-back decodes (greedy / beam-1 / early exit alternating)
 on one engine, ids compared with the single-stream schedule every time; then InferenceModel end to end with
 batch_size 256 (early exit, beam-1) on 70 s of synthetic audio."""
 import os
