@@ -45,11 +45,11 @@ PY
       find gpurun_out/pmc -name "*.db" -delete; find gpurun_out/pmc -name "*kernel_trace.csv" -size +4M -delete
       ;;
     prof)
-      rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
-      for v in "r3:" "r3_f32:--dtype float32"; do
+      [ -z "$PROF_VARIANTS" ] && rm -rf gpurun_out/prof; mkdir -p gpurun_out/prof
+      for v in ${PROF_VARIANTS:-"r3:" "r3_f32:--dtype=float32"}; do
         name="${v%%:*}"; flags="${v#*:}"
         cd /tmp
-        timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o $name -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-extras $flags > "$R/gpurun_out/bench_prof_$name.log" 2>&1
+        timeout ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o $name -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-extras $flags > "$R/gpurun_out/bench_prof_$name.log" 2>&1
         echo "exit $? : rocprof bench $flags"
         cd "$R"
         f=$(find gpurun_out/prof -name "${name}_kernel_stats.csv" | head -1)
