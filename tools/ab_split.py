@@ -12,7 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mt3_amd import network, spectrograms, synthetic  # noqa: E402
 
 B = int(os.environ.get("AB_B", "256"))
-cfg = network.T5Config(dtype=os.environ.get("AB_DTYPE", "bfloat16"))
+import dataclasses  # noqa: E402
+cfg = dataclasses.replace(network.MT3_BASE if os.environ.get("AB_MODEL") == "base" else network.MT3_SMALL,
+                          dtype=os.environ.get("AB_DTYPE", "bfloat16"), kv_dtype=os.environ.get("AB_KV", ""))
 eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=B)
 eng.load_params(network.init_random_params(cfg, seed=0))
 stream = torch.cuda.Stream()
