@@ -211,7 +211,7 @@ enum { MT3_STATUS_GRAPH_FALLBACKS = 0, MT3_STATUS_LAST_DECODE_USED_GRAPH = 1, MT
        MT3_STATUS_DENSE_FP8 = 5 /* encoder dense layers on the MXFP8 path */,
        MT3_STATUS_QKV_FOLD = 6 /* the decoder layers' q/k/v projections folded into the preceding launches */,
        MT3_STATUS_LAST_DECODE_GROUPS = 7 /* row groups of the most recent decode (2 or 4: the row-group schedule); 1: on the caller's stream */,
-       MT3_STATUS_PARTITION_FALLBACKS = 8 /* decodes that wanted the partitioned schedule but could not set it up */ };
+       MT3_STATUS_PARTITION_FALLBACKS = 8 /* decodes that wanted the row-group schedule but could not set it up */ };
 int mt3_engine_status(const mt3_engine* e, int32_t what);
 
 /* GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271): -1 from the
