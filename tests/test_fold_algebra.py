@@ -46,3 +46,25 @@ def test_folded_projections_equal_the_separate_ones():
     # the per-16-column partial sums the kernels carry add up to the row's sum of squares (emb a multiple of 16)
     parts = (y0.reshape(B, emb // 16, 16) ** 2).sum(-1)
     assert np.allclose(1.0 / np.sqrt(parts.sum(-1, keepdims=True) / emb + 1e-6), _rs(y0))
+
+
+def test_logits_ride_in_the_last_layers_fold_launch():
+    """Last decoder layer (engine.hip: build_qkv_fold, `last`): there is no next layer to project for, so the fold
+    launch's extra columns are the logits weights scaled by decoder_norm (mt3/network.py:244-261: decoder_norm, then
+    logits_dense; no 1/sqrt(emb) rescale since logits_via_embedding is False, mt3/network.py:41).  The launch writes the
+    UNNORMALISED product and the row's per-16-column sums of squares; the token-pick kernel multiplies by 1/rms of the
+    final residual row (decode_ops.hip: argmax_step_kernel, LogitScale) before it searches -- the arg-max of the scaled
+    row is what the reference takes, and scaling by a positive row scalar cannot change it."""
+    rng = np.random.default_rng(1)
+    B, emb, mlp, V = 7, 64, 96, 50
+    sn = rng.uniform(0.5, 1.5, emb)                                            # decoder_norm scale
+    Wl, Wo_mlp = rng.standard_normal((emb, V)) / 8, rng.standard_normal((mlp, emb)) / 10
+    y2, h = rng.standard_normal((B, emb)), rng.standard_normal((B, mlp))
+    y_out = y2 + h @ Wo_mlp                                                    # last layer's MLP residual (:150)
+    logits = (y_out * _rs(y_out) * sn) @ Wl                                    # the reference's two steps
+    Wp = sn[:, None] * Wl
+    unnorm = np.concatenate([h, y2], 1) @ np.concatenate([Wo_mlp @ Wp, Wp], 0)   # the launch's vocab columns
+    parts = (y_out.reshape(B, emb // 16, 16) ** 2).sum(-1)                     # written by the same launch's epilogue
+    rs = 1.0 / np.sqrt(parts.sum(-1, keepdims=True) / emb + 1e-6)
+    assert np.allclose(unnorm * rs, logits, rtol=1e-11, atol=1e-12)
+    assert np.array_equal(np.argmax(unnorm, -1), np.argmax(logits, -1))        # rs > 0: the pick itself needs no scale
