@@ -77,9 +77,21 @@ class ShardedTranscriber:
     returns for the file whose segments start at global index `first` (rows: numpy [n, L])."""
 
     def __init__(self, n_items: int, rank: int, world: int, transcribe: Callable, notes: Callable, call_segments: int,
-                 file_segments: int, host_threads: int = 8, on_gather: Optional[Callable] = None):
+                 file_segments: int, host_threads: int = 8, on_gather: Optional[Callable] = None,
+                 row_length: Optional[int] = None, device=None):
+        """row_length / device: shape and placement of the token rows `transcribe` returns.  Only needed when a rank
+        can end up with an EMPTY shard (n_items < world): that rank has no `transcribe` result to take them from and
+        still has to enter the gather with a [0, row_length] tensor, or the other ranks wait for it forever.  Without
+        them a corpus smaller than the world is refused here -- on EVERY rank (all of them see the same n_items and
+        world), so the job fails loudly instead of hanging."""
         from concurrent.futures import ThreadPoolExecutor
+        if n_items <= 0:
+            raise ValueError("ShardedTranscriber: empty corpus")
+        if n_items < world and row_length is None:
+            raise ValueError("ShardedTranscriber: %d segments over %d ranks leaves ranks without a shard; pass "
+                             "row_length (and device) so that they can still enter the gather" % (n_items, world))
         self.n_items, self.rank, self.world = n_items, rank, world
+        self.row_length, self.device = row_length, device
         self.lo, self.hi = shard_range(n_items, rank, world)
         self.call_segments = max(1, call_segments)
         self.files = file_ranges(n_items, file_segments)
@@ -92,7 +104,10 @@ class ShardedTranscriber:
         import torch
         parts = [self._transcribe(s, min(self.call_segments, self.hi - s))
                  for s in range(self.lo, self.hi, self.call_segments)]
-        tokens = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
+        if not parts:       # an empty shard (n_items < world): this rank still enters the collective
+            tokens = torch.zeros((0, self.row_length), dtype=torch.int32, device=self.device or "cpu")
+        else:
+            tokens = parts[0] if len(parts) == 1 else torch.cat(parts, 0)
         if self.world > 1:
             if self._on_gather:
                 self._on_gather(0)

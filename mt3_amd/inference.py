@@ -191,6 +191,8 @@ class InferenceModel(object):
 def _varint(buf: bytes, i: int):
     v, shift = 0, 0
     while True:
+        if i >= len(buf) or shift > 63:
+            raise ValueError("note_sequence_id: truncated or malformed protobuf varint")
         b = buf[i]
         i += 1
         v |= (b & 0x7F) << shift
@@ -221,12 +223,20 @@ def note_sequence_id(sequence) -> str:
             i += 4
         elif wt == 2:
             n, i = _varint(buf, i)
+            if i + n > len(buf):
+                raise ValueError("note_sequence_id: length-delimited field runs past the end of the buffer")
             if field == 1:
                 return buf[i:i + n].decode("utf-8")
             i += n
         else:
             raise ValueError("note_sequence_id: unsupported protobuf wire type %d" % wt)
     return ""                                     # proto3 default: an unset id is the empty string
+
+
+class MissingSequenceError(AssertionError, ValueError):
+    """A track of the task dataset has no NoteSequence (or a NoteSequence has no track).  The reference trips a bare
+    `assert` there (mt3/inference.py:114), so callers that catch AssertionError keep working; it is a real exception
+    here, not an assert statement, so `python -O` does not turn it into a KeyError further down."""
 
 
 def write_inferences_to_file(path: str, inferences: Sequence[Any], task_ds, mode: str, vocabulary=None,
@@ -278,8 +288,11 @@ def write_inferences_to_file(path: str, inferences: Sequence[Any], task_ds, mode
     full = metrics_utils.combine_predictions_by_id(
         predictions, lambda preds: metrics_utils.event_predictions_to_ns(preds, codec=codec,
                                                                          encoding_spec=encoding_spec))
-    if any_sequence:
-        assert sorted(ref_ids.keys()) == sorted(full.keys())          # mt3/inference.py:114
+    if any_sequence and sorted(ref_ids.keys()) != sorted(full.keys()):      # the reference asserts it, mt3/inference.py:114
+        missing = sorted(set(full) - set(ref_ids))
+        extra = sorted(set(ref_ids) - set(full))
+        raise MissingSequenceError("write_inferences_to_file: tracks without a NoteSequence in 'sequence': %s; "
+                                   "sequences without a track: %s" % (missing[:8], extra[:8]))
     with open(path, "w") as f:
         for uid in sorted(full.keys()):
             notes = [{"start_time": n.start_time, "end_time": n.end_time, "pitch": n.pitch, "velocity": n.velocity,

@@ -103,6 +103,9 @@ def precision_recall_f1_overlap(ref_intervals, ref_pitches, est_intervals, est_p
     n_ref, n_est = len(np.asarray(ref_pitches)), len(np.asarray(est_pitches))
     if n_ref == 0 or n_est == 0:
         return 0.0, 0.0, 0.0
+    # mir_eval.transcription.validate -> util.validate_frequencies rejects pitches that are not positive
+    if (np.asarray(ref_pitches, np.float64) <= 0).any() or (np.asarray(est_pitches, np.float64) <= 0).any():
+        raise ValueError("precision_recall_f1_overlap: pitches must be positive (mir_eval.transcription.validate)")
     m = match_notes(ref_intervals, ref_pitches, est_intervals, est_pitches, onset_tolerance, pitch_tolerance,
                     offset_ratio, offset_min_tolerance, strict)
     p, r = m / n_est, m / n_ref

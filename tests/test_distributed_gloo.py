@@ -168,3 +168,54 @@ def test_gather_needs_no_size_exchange_and_rejects_wrong_shards():
     assert distributed.gather_token_rows(t, 3) is t and distributed.gather_token_rows(t, 3, dst=0) is t
     src = open(os.path.join(ROOT, "mt3_amd", "distributed.py")).read()
     assert ".item()" not in src and src.count("dist.all_gather(") == 1 and "dist.gather(" in src
+
+
+# ------------------------------------------------------------------------------------------------------------
+# A corpus SMALLER than the world: the rank without a shard must still enter the gather (it used to die
+# in torch.cat([]) while the other rank waited in dist.gather forever), or the job must refuse on every rank.
+def _tiny_job_worker(rank, world, port, n_items, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from mt3_amd import distributed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        distributed.ShardedTranscriber(n_items, rank, world, None, None, call_segments=4, file_segments=4)
+        refused = False
+    except ValueError:
+        refused = True                                    # on EVERY rank: nobody is left waiting in a collective
+    calls = []
+
+    def transcribe(first, count):
+        calls.append((first, count))
+        return torch.from_numpy(_stub_rows(first, count))
+    job = distributed.ShardedTranscriber(n_items, rank, world, transcribe, _notes_of_file_factory(), call_segments=4,
+                                         file_segments=4, host_threads=2, row_length=L_STUB)
+    job.step()
+    res = job.drain()
+    lo, hi = distributed.shard_range(n_items, rank, world)
+    assert calls == ([(lo, hi - lo)] if hi > lo else [])
+    q.put((rank, refused, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_corpus_smaller_than_the_world_neither_hangs_nor_loses_rows():
+    from mt3_amd import distributed
+    assert distributed.shard_range(1, 0, 2) == (0, 1) and distributed.shard_range(1, 1, 2) == (1, 1)
+    single = distributed.ShardedTranscriber(1, 0, 1, lambda f, c: torch.from_numpy(_stub_rows(f, c)),
+                                            _notes_of_file_factory(), call_segments=4, file_segments=4, host_threads=2)
+    single.step()
+    want = single.drain()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tiny_job_worker, args=(r, 2, port, 1, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == [(0, True, want), (1, True, [])]

@@ -198,6 +198,9 @@ def test_id_comes_from_the_reference_note_sequence(tmp_path):
     for ex in ds:
         if ex["unique_id"][0] == b"u1":
             ex["sequence"] = np.array([b""], dtype=object)
-    with pytest.raises(AssertionError):
+    with pytest.raises(AssertionError) as ei:              # the reference's exception type ...
         inference.write_inferences_to_file(p, infs, ds, mode="predict", vocabulary=vocab, vocab_config=cfg,
                                            onsets_only=False, use_ties=True)
+    assert isinstance(ei.value, ValueError) and "u1" in str(ei.value)      # ... raised, not asserted: survives python -O
+    with pytest.raises(ValueError):                        # truncated proto bytes: an error, not an IndexError
+        inference.note_sequence_id(_proto_note_sequence("abcdef")[:4])
