@@ -3,10 +3,17 @@
 
 One "step" = one full pass of the hot path over one batch of synthetic 16 kHz segments that are
 already resident in HBM:  log-mel frontend -> T5 encoder -> cross-K/V -> 1024-step greedy decode
-(hipGraph replay per step, NO early exit: random weights never emit EOS reliably)
--> ids->tokens kernel -> (N>1: RCCL all-gather of the int32 token rows) -> host run-length /
-note decoding of every row (C++ in libmt3hip.so; on rank 0, on a worker thread that overlaps the next
-batch's launches and is joined before the clock stops).
+(NO early exit: random weights never emit EOS reliably; at batch >= 128 the decode runs
+as 2 or 4 ROW GROUPS, each replaying its own captured step graph on a stream with a hardware queue of
+its own -- `config.decode_schedule` says what ran) -> ids->tokens kernel -> (N>1: RCCL gather of the
+int32 token rows) -> host run-length / note decoding of every row (C++ in libmt3hip.so; on rank 0, on a
+worker thread that overlaps the next batch's launches and is joined before the clock stops).
+
+Precision: the headline computes in FLOAT32, the reference's own precision (mt3/gin/model.gin:50
+`dtype = 'float32'`; f32 MFMA operands, f32 K/V caches, token-exact against the oracle).  The bf16
+engine, the e4m3-cache engine and BASELINE configs[4] are reported as `extra` blocks with their own
+rooflines; `extra.eos_schedule` is SURVEY.md 8(d)'s second figure (synthetic output lengths ~ clipped
+N(300,100), early exit + row retirement), `extra.uniform_noise` its pure-noise input run.
 
 Workload at N=1: BASELINE.json configs[2] ("MT3-base full encoder-decoder greedy decode, batch=256
 synthetic segments, 1xMI355X with hipGraph") -- the largest single-GPU configuration and the only
@@ -23,7 +30,9 @@ Prints ONE JSON line on rank 0.
 import argparse
 import hashlib
 import json
+import math
 import os
+import resource
 import socket
 import subprocess
 import sys
@@ -177,10 +186,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="segments per GPU per step (c3: 256)")
     ap.add_argument("--decode-steps", type=int, default=1024)
-    ap.add_argument("--dtype", default="bfloat16", choices=["bfloat16", "float32"])
+    ap.add_argument("--dtype", default="float32", choices=["bfloat16", "float32"],
+                    help="MFMA operand / K/V cache type of the HEADLINE engine: float32 = the reference's own precision "
+                         "(mt3/gin/model.gin:50); bfloat16 is always reported as an extra next to it")
     ap.add_argument("--kv-dtype", default="", choices=["", "fp8_e4m3"],
                     help="K/V cache format: '' = the compute dtype; fp8_e4m3 = OCP e4m3 rows + per-row scales "
-                         "(BASELINE configs[4]'s fp8 path; NOT the default line: the headline stays bf16)")
+                         "(BASELINE configs[4]'s fp8 path, with --dtype bfloat16; NOT the default line)")
     ap.add_argument("--dense-dtype", default="", choices=["", "fp8_e4m3"],
                     help="encoder dense layers + cross-K/V projections: '' = the compute dtype; fp8_e4m3 = MXFP8 on the "
                          "block-scaled MFMA (BASELINE configs[4]'s fp8 MFMA path; NOT the default line)")
@@ -200,7 +211,9 @@ def main():
                     help="the corpus is a list of files of this many consecutive segments (256 x 2.048 s = 8.7 min of "
                          "audio); host note decoding is sequential inside a file and parallel across files")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the f32 line and the stage (frontend/encoder) extras")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other-precision blocks and the stage (frontend/encoder) extras")
+    ap.add_argument("--eos-mean", type=float, default=300.0, help="synthetic EOS schedule: mean output length (SURVEY 8d)")
+    ap.add_argument("--eos-sd", type=float, default=100.0)
     ap.add_argument("--cpu-segments", type=int, default=8)
     ap.add_argument("--cpu-small-segments", type=int, default=32, help="batch of the CPU batch-scaling probe (0: skip)")
     ap.add_argument("--cpu-enc-segments", type=int, default=64)
@@ -384,10 +397,26 @@ def main():
                 return min(timed(lambda: engine.debug_decode(num_steps=args.decode_steps, chains=1, **kw))
                            for _ in range(reps))
             t_full = decode_ms()
-            with torch.cuda.stream(stream):
-                engine.decode(num_steps=2)
-            t_prod = min(timed(lambda: engine.decode(num_steps=args.decode_steps)) for _ in range(reps))
-            prod_groups = engine.status(_lib.STATUS_LAST_DECODE_GROUPS)
+
+            def product_decode(**kw):
+                """(ms, host CPU seconds of the whole process, row groups, graph replay?) of one decode as the product
+                schedules it: HIP events for the device side, getrusage (user + system, all threads: the engine's group
+                workers included) for the host side"""
+                with torch.cuda.stream(stream):
+                    engine.decode(num_steps=2, **kw)
+                torch.cuda.synchronize()
+                best = None
+                for _ in range(reps):
+                    r0 = resource.getrusage(resource.RUSAGE_SELF)
+                    ms = timed(lambda: engine.decode(num_steps=args.decode_steps, **kw))
+                    r1 = resource.getrusage(resource.RUSAGE_SELF)
+                    cpu = (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)
+                    if best is None or ms < best[0]:
+                        best = (ms, cpu)
+                return best + (engine.status(_lib.STATUS_LAST_DECODE_GROUPS),
+                               engine.status(_lib.STATUS_LAST_DECODE_USED_GRAPH))
+            t_prod, cpu_prod, prod_groups, prod_graph = product_decode()
+            t_direct, cpu_direct, _, _ = product_decode(use_graph=False)
             t_noself = decode_ms(skip_self_attn=True)
             t_nocross = decode_ms(skip_cross_attn=True)
             esz = 2 if ecfg.dtype == "bfloat16" else 4
@@ -417,8 +446,9 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_src,
                     "avg_launch_us": self_us, "algorithmic_bytes_per_launch": self_bytes / launches,
                     "launches": launches,
-                    "method": "HIP events on the launch stream around the whole graph-replayed single-stream decode "
-                              "(the kernel at full-GPU width, one launch at a time, as rocprofv3 times it), with and "
+                    "method": "HIP events on the launch stream around the whole SINGLE-STREAM graph-replayed debug decode "
+                              "(the kernel at full-GPU width, one launch at a time, as rocprofv3 times it; NOT the "
+                              "product's row-group schedule, whose clock is decode_ms_product_schedule), with and "
                               "without this kernel in the step graph; (difference)/launches",
                     "decode_ms_single_chain": t_full, "decode_ms_without_self_attn": t_noself,
                     "decode_ms_without_cross_attn": t_nocross,
@@ -426,6 +456,9 @@ def main():
                     "whole_step_hbm_frac": (self_bytes + cross_bytes) / (t_full * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     # the schedule the headline runs (row groups at this batch): same bytes, its own clock
                     "decode_ms_product_schedule": t_prod, "product_schedule_row_groups": prod_groups,
+                    "product_schedule_graph_replay": bool(prod_graph),
+                    "host_cpu_s_per_decode": cpu_prod,
+                    "decode_ms_direct_launches": t_direct, "host_cpu_s_per_decode_direct_launches": cpu_direct,
                     "whole_step_hbm_frac_product_schedule": (self_bytes + cross_bytes) / (t_prod * 1e-3) / 1e9 / HBM_PEAK_GBS,
                     "cross_attn": {"achieved": cross_bytes / launches / (cross_us * 1e-6) / 1e9,
                                    "frac": cross_bytes / launches / (cross_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -517,48 +550,189 @@ def main():
                     extras[key] = {"value": None, "error": repr(ex)[:300]}
                     return extras[key]
 
-            if args.dtype == "bfloat16":
-                # ---- the same workload at the REFERENCE'S OWN precision (gin/model.gin:50 `dtype = 'float32'`): f32 MFMA
-                # operands, f32 K/V caches, token-exact against the oracle (tests/test_gpu_parity_deep.py); >= 5 timed
-                # steps and its own roofline block (VERDICT r2, next #1a)
-                r32 = other_engine("f32", network.T5Config(dtype="float32"), "MT3 (model.gin) shape, reference precision",
-                                   max(5, min(args.steps, 8)), True)
-                if r32.get("value"):
-                    r32["note"] = ("reference precision (model.gin:50 dtype float32): f32 MFMA operands "
-                                   "(4 x v_mfma_f32_16x16x4_f32 per chunk), f32 K/V cache; token-exact vs the oracle")
-                # ---- BASELINE configs[4] ingredients, one warm-up + 3 timed steps each (not the headline):
-                #   fp8_kv    : this workload with e4m3 K/V caches (half the bytes of the HBM-bound decode stream)
-                #   fp8_kv_mx8: the same plus the encoder's dense layers / cross-K/V projections as MXFP8 on the scaled MFMA
-                #   configs4  : the ismir2022/base.gin shape (emb 768, 12 heads, 12+12 layers, mlp 2048) with both
-                for key, shp, dense, label, wr in (
-                        ("fp8_kv", network.MT3_SMALL, "", "MT3 (model.gin) shape", True),
-                        ("fp8_kv_mx8", network.MT3_SMALL, "fp8_e4m3", "MT3 (model.gin) shape", False),
-                        ("configs4", network.MT3_BASE, "fp8_e4m3", "BASELINE configs[4]: ismir2022/base.gin shape", True)):
-                    c8 = dataclasses.replace(shp, dtype="bfloat16", kv_dtype="fp8_e4m3", dense_dtype=dense)
-                    rec = other_engine(key, c8, label, 3, wr)
-                    if key == "fp8_kv_mx8" and rec.get("value"):
-                        tf8 = ENC_GFLOP_PER_SEGMENT * Br / (rec["encoder_ms"] * 1e-3) / 1e3
-                        extras["encoder_mx8"] = {"segments": Br, "ms": rec["encoder_ms"], "bound": "mfma", "achieved": tf8,
-                                                 "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                 "frac": tf8 / MFMA_FP8_PEAK_TFLOPS,
-                                                 "note": "encoder + cross-K/V projections with MXFP8 operands "
-                                                         "(v_mfma_scale_f32_16x16x128_f8f6f4); attention stays bf16"}
-                # ---- how far the reduced-precision engines' FREE-RUNNING decodes drift from the f32 engine's on the
-                # same 256 segments x 1024 steps (random-init weights: one flipped arg-max re-rolls the rest of a row,
-                # so this is an upper bound on what trained, peaked distributions would show); VERDICT r2 #1c
+            # ---- the same workload in the OTHER operand precision (>= 5 timed steps, own roofline block): the headline is
+            # float32 = the reference's own (gin/model.gin:50 `dtype = 'float32'`; f32 MFMA operands, f32 K/V caches,
+            # token-exact against the oracle: tests/test_gpu_parity_deep.py), so this block is the bf16 engine -- or the
+            # f32 one when the line was asked for with --dtype bfloat16
+            other = "bfloat16" if args.dtype == "float32" else "float32"
+            okey = "bf16" if other == "bfloat16" else "f32"
+            r_other = other_engine(okey, network.T5Config(dtype=other), "MT3 (model.gin) shape, %s operands" % okey,
+                              max(5, min(args.steps, 8)), True)
+            if r_other.get("value"):
+                r_other["note"] = ("bf16 MFMA operands and K/V caches, f32 accumulation / residual / softmax: NOT the reference's "
+                              "precision -- see extra.divergence_vs_f32 for how far its free-running tokens drift"
+                              if other == "bfloat16" else
+                              "reference precision (model.gin:50 dtype float32): f32 MFMA operands "
+                              "(4 x v_mfma_f32_16x16x4_f32 per chunk), f32 K/V cache; token-exact vs the oracle")
+            # ---- BASELINE configs[4] ingredients, one warm-up + 3 timed steps each (never the headline):
+            #   fp8_kv    : this workload with e4m3 K/V caches (half the bytes of the HBM-bound decode stream)
+            #   fp8_kv_mx8: the same plus the encoder's dense layers / cross-K/V projections as MXFP8 on the scaled MFMA
+            #   configs4  : the ismir2022/base.gin shape (emb 768, 12 heads, 12+12 layers, mlp 2048) with both
+            for key, shp, dense, label, wr in (
+                    ("fp8_kv", network.MT3_SMALL, "", "MT3 (model.gin) shape", True),
+                    ("fp8_kv_mx8", network.MT3_SMALL, "fp8_e4m3", "MT3 (model.gin) shape", False),
+                    ("configs4", network.MT3_BASE, "fp8_e4m3", "BASELINE configs[4]: ismir2022/base.gin shape", True)):
+                c8 = dataclasses.replace(shp, dtype="bfloat16", kv_dtype="fp8_e4m3", dense_dtype=dense)
+                rec = other_engine(key, c8, label, 3, wr)
+                if key == "fp8_kv_mx8" and rec.get("value"):
+                    tf8 = ENC_GFLOP_PER_SEGMENT * Br / (rec["encoder_ms"] * 1e-3) / 1e3
+                    extras["encoder_mx8"] = {"segments": Br, "ms": rec["encoder_ms"], "bound": "mfma", "achieved": tf8,
+                                             "peak": MFMA_FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                             "frac": tf8 / MFMA_FP8_PEAK_TFLOPS,
+                                             "note": "encoder + cross-K/V projections with MXFP8 operands "
+                                                     "(v_mfma_scale_f32_16x16x128_f8f6f4); attention stays bf16"}
+            # ---- how far the reduced-precision engines' FREE-RUNNING decodes drift from the f32 engine's on the
+            # same 256 segments x 1024 steps (random-init weights: one flipped arg-max re-rolls the rest of a row,
+            # so this is an upper bound on what trained, peaked distributions would show); VERDICT r2 #1c
+            try:
+                from mt3_amd import metrics
+                with torch.cuda.stream(stream):
+                    free_running["f32" if args.dtype == "float32" else "bf16"] = transcribe(lo, Br).cpu().numpy()
                 if "f32" in free_running:
-                    try:
-                        from mt3_amd import metrics
+                    extras["divergence_vs_f32"] = {
+                        k: metrics.token_stream_divergence(free_running["f32"], free_running[k], codec)
+                        for k in ("bf16", "fp8_kv", "fp8_kv_mx8") if k in free_running}
+                    extras["divergence_vs_f32"]["note"] = (
+                        "free-running greedy decode of the same %d segments x %d steps, reference = this repo's f32 "
+                        "engine (token-exact vs the oracle); random-init weights" % (Br, args.decode_steps))
+            except Exception as ex:
+                extras["divergence_vs_f32"] = {"error": repr(ex)[:300]}
+
+            # ---- SURVEY.md 8(d), second figure: a SYNTHETIC EOS SCHEDULE -- output lengths ~ clipped N(300, 100) imposed
+            # through the bench-only hook of include/mt3_hip_debug.h (row r's distribution at step len[r] - 1 becomes a
+            # point mass on EOS; everything before is the model's own arithmetic), decode with EARLY EXIT = finished rows
+            # are retired (no K/V streamed for them, live rows compacted at the 32-step poll).  Same pipeline as the
+            # headline; real transcriptions are a few hundred tokens of the 1024, so this is the cost in use, the
+            # full-length headline the upper bound.  LABELLED SYNTHETIC: the lengths are imposed, not predicted.
+            def eos_schedule(engine, ecfg, key, n_steps=3):
+                try:
+                    rng = np.random.default_rng(0)
+                    lens = np.clip(np.rint(rng.normal(args.eos_mean, args.eos_sd, Br)), 1, args.decode_steps).astype(np.int32)
+                    engine.debug_set_eos_schedule(lens)
+                    stats = {}
+
+                    def one_step(**kw):
                         with torch.cuda.stream(stream):
-                            free_running["bf16"] = transcribe(lo, Br).cpu().numpy()
-                        extras["divergence_vs_f32"] = {
-                            k: metrics.token_stream_divergence(free_running["f32"], free_running[k], codec)
-                            for k in ("bf16", "fp8_kv", "fp8_kv_mx8") if k in free_running}
-                        extras["divergence_vs_f32"]["note"] = (
-                            "free-running greedy decode of the same %d segments x %d steps, reference = this repo's f32 "
-                            "engine (token-exact vs the oracle); random-init weights" % (Br, args.decode_steps))
-                    except Exception as ex:
-                        extras["divergence_vs_f32"] = {"error": repr(ex)[:300]}
+                            engine.encode(spectrograms.compute_spectrogram_batch(a256, None))
+                            ids = engine.decode(num_steps=args.decode_steps, early_exit=True, **kw)
+                            stats["steps_run"] = engine.steps_run
+                            stats["compactions"] = engine.status(_lib.STATUS_LAST_DECODE_COMPACTIONS)
+                            stats["groups"] = engine.status(_lib.STATUS_LAST_DECODE_GROUPS)
+                            host = vocab.decode_tf(ids).cpu().numpy()
+                        return host, host_stage(host)
+
+                    def timed_steps(**kw):
+                        host, futs = one_step(**kw)
+                        for f in futs:
+                            f.result()
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        futs = []
+                        for _ in range(n_steps):
+                            futs += one_step(**kw)[1]
+                        for f in futs:
+                            f.result()
+                        torch.cuda.synchronize()
+                        return (time.perf_counter() - t1) / n_steps, host
+
+                    def decode_only(**kw):
+                        with torch.cuda.stream(stream):
+                            engine.decode(num_steps=args.decode_steps, early_exit=True, **kw)
+                        torch.cuda.synchronize()
+                        r0 = resource.getrusage(resource.RUSAGE_SELF)
+                        t1 = time.perf_counter()
+                        with torch.cuda.stream(stream):
+                            engine.decode(num_steps=args.decode_steps, early_exit=True, **kw)
+                        torch.cuda.synchronize()
+                        dt1 = time.perf_counter() - t1
+                        r1 = resource.getrusage(resource.RUSAGE_SELF)
+                        return dt1 * 1e3, (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime)
+                    d, host = timed_steps()
+                    got_len = np.where((host == -1).any(1), (host == -1).argmax(1) + 1, host.shape[1])
+                    dec_ms, dec_cpu = decode_only()
+                    dec_ms_direct, dec_cpu_direct = decode_only(use_graph=False)
+                    dec_ms_single, _ = decode_only(single_stream=True)
+                    esz = 2 if ecfg.dtype == "bfloat16" else 4
+                    H, nl = ecfg.num_heads, ecfg.num_decoder_layers
+                    kv1 = H * (2.0 * 64 + 8.0) if ecfg.kv_dtype else 2.0 * H * 64 * esz        # K + V bytes of one cached position of one row
+                    qo = 2.0 * H * 64 * esz
+                    ll = lens.astype(np.float64)
+                    # a row of length n runs steps t = 0 .. n - 1: reads its t cached positions + appends one, reads the
+                    # 256 cross positions; bytes the LIVE rows need (retired rows need none)
+                    self_b = nl * float((kv1 * (ll * (ll + 1) / 2) + (kv1 + qo) * ll).sum())
+                    cross_b = nl * float(((kv1 * 256 + qo) * ll).sum())
+                    full_b = nl * Br * (kv1 * args.decode_steps * (args.decode_steps + 1) / 2 +
+                                        (kv1 + qo) * args.decode_steps + (kv1 * 256 + qo) * args.decode_steps)
+                    extras.setdefault("eos_schedule", {})[key] = {
+                        "value": Br * SEG_SECONDS / d, "unit": "audio-s/s", "ms_per_step": d * 1e3, "steps": n_steps, "warmup": 1,
+                        "dtype": "bf16" if ecfg.dtype == "bfloat16" else "f32",
+                        "workload": "SYNTHETIC EOS SCHEDULE (SURVEY.md 8(d)): batch=%d, output lengths ~ clipped "
+                                    "N(%g, %g) imposed per row (seed 0), greedy decode with early exit + row retirement, "
+                                    "same pipeline as the headline (frontend, encoder, ids->tokens, host note decoding)"
+                                    % (Br, args.eos_mean, args.eos_sd),
+                        "lengths": {"mean": float(ll.mean()), "min": int(lens.min()), "max": int(lens.max()),
+                                    "decoded_mean": float(got_len.mean()),
+                                    "decoded_not_longer_than_imposed_frac": float((got_len <= lens).mean())},
+                        "decode_ms": dec_ms, "decode_steps_run": stats["steps_run"], "row_groups": stats["groups"],
+                        "compactions_per_decode": stats["compactions"],
+                        "host_cpu_s_per_decode": dec_cpu,
+                        "decode_ms_direct_launches": dec_ms_direct, "host_cpu_s_per_decode_direct_launches": dec_cpu_direct,
+                        "decode_ms_single_stream": dec_ms_single,
+                        "live_row_kv_bytes_per_decode": self_b + cross_b,
+                        "live_bytes_over_full_length_bytes": (self_b + cross_b) / full_b,
+                        "whole_decode_hbm_frac_on_live_bytes": (self_b + cross_b) / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                except Exception as ex:
+                    extras.setdefault("eos_schedule", {})[key] = {"value": None, "error": repr(ex)[:300]}
+                finally:
+                    try:
+                        engine.debug_set_eos_schedule(None)
+                    except Exception:
+                        pass
+
+            eos_schedule(eng, cfg, "f32" if args.dtype == "float32" else "bf16")
+            try:
+                ocfg = network.T5Config(dtype=other)
+                e3 = network.Transformer(ocfg, input_length=256, max_decode_length=L, max_batch=Br)
+                e3.load_params(network.init_random_params(ocfg, seed=0))
+                eos_schedule(e3, ocfg, okey)
+                del e3
+            except Exception as ex:
+                extras.setdefault("eos_schedule", {})[okey] = {"value": None, "error": repr(ex)[:300]}
+
+            # ---- "also report a pure uniform(-1, 1) noise run, which has no empty-energy bins": the
+            # headline pipeline on white-noise segments (3 timed steps after a warm-up)
+            try:
+                gen = torch.Generator(device="cuda").manual_seed(0)
+                noise = (torch.rand((Br, a256.shape[1]), device="cuda", generator=gen) * 2.0 - 1.0).to(torch.float32)
+
+                def noise_step():
+                    with torch.cuda.stream(stream):
+                        lmn = spectrograms.compute_spectrogram_batch(noise, None)
+                        eng.encode(lmn)
+                        host = vocab.decode_tf(eng.decode(num_steps=args.decode_steps)).cpu().numpy()
+                    return lmn, host_stage(host)
+                lmn, futs = noise_step()
+                for f in futs:
+                    f.result()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                futs = []
+                for _ in range(3):
+                    futs += noise_step()[1]
+                for f in futs:
+                    f.result()
+                torch.cuda.synchronize()
+                dn = (time.perf_counter() - t1) / 3
+                extras["uniform_noise"] = {
+                    "value": Br * SEG_SECONDS / dn, "unit": "audio-s/s", "ms_per_step": dn * 1e3, "steps": 3, "warmup": 1,
+                    "dtype": "f32" if args.dtype == "float32" else "bf16",
+                    "workload": "uniform(-1, 1) white-noise segments (no empty-energy mel bins), batch=%d, otherwise the "
+                                "headline pipeline" % Br,
+                    "logmel_min": float(lmn.min()), "logmel_at_floor_frac": float((lmn <= math.log(1e-5) + 1e-6).float().mean())}
+            except Exception as ex:
+                extras["uniform_noise"] = {"value": None, "error": repr(ex)[:300]}
+            with torch.cuda.stream(stream):
+                eng.encode(lm256)                                    # leave the engine at the bench batch
 
     if rank == 0:
         segs = n_global * args.steps
@@ -589,8 +763,9 @@ def main():
                        "file_segments": args.file_segments,
                        "parallelism": "dp%d (segments sharded, weights replicated, ONE RCCL gather of the token rows to rank 0)"
                                       % world if world > 1 else "single GPU",
-                       "decode_schedule": ("%d row groups, each on a stream with its own hardware queue, one host thread each, "
-                                           "direct launches" % decode_groups) if decode_groups > 1 else
+                       "decode_schedule": ("%d row groups, each on a stream with its own hardware queue and driven by its own "
+                                           "engine worker thread, %s" % (decode_groups, "one captured hipGraph per group, "
+                                           "replayed per step" if used_graph else "direct launches")) if decode_groups > 1 else
                        ("one stream, hipGraph replay per step" if used_graph else
                         "one stream, DIRECT LAUNCHES (graph capture failed)"),
                        "graph_fallbacks": graph_fallbacks, "partition_fallbacks": partition_fallbacks,
@@ -598,8 +773,10 @@ def main():
             "segments_per_s": segs / dt,
             "rccl_world": dist.get_world_size() if world > 1 else 1,
             "per_rank_ms_per_step": per_rank_ms, "gather_ms": gather_ms,
-            "f32_value": extras.get("f32", {}).get("value"),
-            "f32": extras.get("f32"),
+            # the other operand precision of the same workload (float32 = the reference's; whichever is not the headline)
+            "f32_value": value if args.dtype == "float32" else extras.get("f32", {}).get("value"),
+            "bf16_value": value if args.dtype == "bfloat16" else extras.get("bf16", {}).get("value"),
+            "eos_schedule_value": (extras.get("eos_schedule", {}).get("f32" if args.dtype == "float32" else "bf16") or {}).get("value"),
             "roofline": roof,
             "extra": extras,
         }

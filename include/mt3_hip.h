@@ -16,11 +16,21 @@
  *   - `d_*` pointers are DEVICE pointers owned by the caller (torch tensors in
  *     the Python mirror); `h_*` are host pointers.  The library never frees or
  *     reallocates caller memory.  Work is enqueued on `stream` (a hipStream_t
- *     passed as void*) and the call returns without synchronising, except
- *     mt3_engine_load_weight / mt3_engine_finalize (setup) and the pure-host
- *     functions.
+ *     passed as void*) and the call returns without synchronising, EXCEPT:
+ *     mt3_engine_load_weight / mt3_engine_finalize (setup), the pure-host
+ *     functions, and mt3_engine_decode -- which (a) with MT3_DECODE_EARLY_EXIT
+ *     waits for the device at every poll, and (b) on the row-group schedule
+ *     (batches of >= 128 rows, see "Schedule" there) returns only when the decode
+ *     has FINISHED on the device, unless the caller passes MT3_DECODE_ASYNC and
+ *     joins with mt3_engine_decode_wait (the caller's thread is free in between).
  *   - one engine per (device, stream); an engine is not thread-safe, distinct
- *     engines are independent.
+ *     engines are independent.  An engine owns up to four worker threads (one
+ *     per row group; created with the first decode that needs them, joined by
+ *     mt3_engine_destroy) and four streams with hardware queues of their own.
+ *     Those streams are BLOCKING streams in HIP's sense: work the application
+ *     puts on the legacy NULL stream while a decode runs serialises with them
+ *     (pass an explicit stream, as every caller of this header does anyway).
+ *     mt3_engine_decode must not be called while `stream` is being captured.
  */
 #ifndef MT3_HIP_H_
 #define MT3_HIP_H_
@@ -165,31 +175,50 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch,
  * prefix+EOS with score logp/((5+len)/6)^alpha; a row stops once its best finished
  * score exceeds live_logp/((5+L+1)/6)^alpha; the best finished hypothesis is
  * returned, or the live one if none finished.
- * Runs `num_steps` (<= L) steps; each step is one hipGraph replay unless
+ * Runs `num_steps` (<= L) steps; each step is one hipGraph replay (per row group) unless
  * flags & MT3_DECODE_NO_GRAPH.  d_ids [batch, L] int32 (columns >= num_steps
  * are zero-filled).  d_first_logits: [batch, vocab] f32 logits of step 0, or NULL.
- * With MT3_DECODE_EARLY_EXIT the host polls a device flag every 32 steps and
- * stops once every row has emitted EOS / finished its search (this synchronises the stream).
+ * With MT3_DECODE_EARLY_EXIT the host polls a device counter every 32 steps and
+ * stops once every row has emitted EOS / finished its search (this synchronises the stream), and finished rows
+ * are RETIRED, as the reference's beam_search stops extending finished rows (mt3/models.py:126-127; everything past
+ * a row's EOS is cut by _trim_eos anyway, NB:358-363): from the step after a row finishes, the attention kernels stream
+ * nothing for it (a wave-uniform exit before the first cache request) and the token kernel skips it; at a poll where
+ * the live rows of a row group fit fewer 32-row GEMM tiles than the group occupies, the live rows' per-step state is
+ * compacted to the front of the group (a slot -> row map finds their K/V caches, which never move), so attention
+ * grids AND the GEMMs' M shrink with the live set.  The ids of every row up to and including its EOS are bit-identical
+ * to the schedule without EARLY_EXIT (rows are independent; tests/test_gpu_retire.py).  Without EARLY_EXIT every row
+ * runs all `num_steps` steps (the canonical full-length workload bench.py's headline is quoted on).
  * Schedule: a batch of >= 128 rows is decoded as 2 or 4 ROW GROUPS (bf16 operands: 2 from 128 rows, 4 from 512; f32:
  * 2 from 128, 4 from 256), each on an engine-owned stream with a hardware queue of its own (created with
  * hipExtStreamCreateWithCUMask and a mask of all compute units: two plain HIP streams serialise)
- * and driven by its own host thread with direct launches, so that one group's HBM-bound attention runs beside the other
- * groups' latency-bound GEMMs (+6 % at batch 256 in bf16, +7 % in f32); the caller's stream is ordered before and after
- * the groups by events, the ids are bit-identical to the single-stream schedule (rows are independent), the call returns
- * when all groups have FINISHED (each group's host thread waits for its stream: a stream nobody waits on runs 7 % slower).  MT3_DECODE_SINGLE_STREAM / _NO_GRAPH /
- * _CHAINS(n), decode_chains > 1 or MT3_OPT_NO_ROW_GROUPS keep everything on `stream`. */
+ * and driven by one of the engine's worker threads (one captured step graph per group, replayed per step;
+ * MT3_DECODE_NO_GRAPH: direct launches), so that one group's HBM-bound attention runs beside the other groups'
+ * latency-bound GEMMs (+6 % at batch 256 in bf16, +7 % in f32); the groups start after an event on the caller's stream,
+ * the ids are bit-identical to the single-stream schedule (rows are independent), and the decode is complete when all
+ * groups have FINISHED (each group's thread waits for its stream: a stream nobody waits on runs 7 % slower) -- which is
+ * when mt3_engine_decode returns, or, with MT3_DECODE_ASYNC, when mt3_engine_decode_wait does.
+ * MT3_DECODE_SINGLE_STREAM / _CHAINS(n), decode_chains > 1 or MT3_OPT_NO_ROW_GROUPS keep everything on `stream`. */
 enum {
   MT3_DECODE_NO_GRAPH = 1,
   MT3_DECODE_EARLY_EXIT = 2,
   MT3_DECODE_BEAM1 = 4,
-  /* keep the whole decode on the caller's stream (no helper streams / threads): see "schedule" below */
-  MT3_DECODE_SINGLE_STREAM = 8
+  /* keep the whole decode on the caller's stream (no helper streams): see "Schedule" above */
+  MT3_DECODE_SINGLE_STREAM = 8,
+  /* return as soon as the decode has been handed to the engine's worker threads; the caller MUST call
+   * mt3_engine_decode_wait before it reads d_ids, enqueues anything else on `stream`, or calls any other function of
+   * this engine (they fail with MT3_ERR_INVALID while a decode is in flight).  h_steps_run is not written by the
+   * asynchronous call (mt3_engine_decode_wait reports it). */
+  MT3_DECODE_ASYNC = 16
   /* bits 8..11: number of decode chains for this call (1..8); 0 = the engine's configured default.
    * Any other bit is rejected with MT3_ERR_INVALID (profiling variants live in mt3_hip_debug.h). */
 };
 #define MT3_DECODE_CHAINS(n) (((n) & 0xF) << 8)
 int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags,
                       int32_t* d_ids, float* d_first_logits, int32_t* h_steps_run, void* stream);
+/* Joins the decode an MT3_DECODE_ASYNC call started: blocks (sleeping, not spinning) until the engine's worker threads
+ * are done, then enqueues the copy of the ids into that call's d_ids on that call's stream (and the beam-1
+ * finalisation before it) and reports errors of the decode loop.  MT3_ERR_INVALID when no decode is in flight. */
+int mt3_engine_decode_wait(mt3_engine* e, int32_t* h_steps_run);
 
 /* Teacher-forced cached decode: Transformer.decode (mt3/network.py:303-361) on GIVEN decoder inputs, driven one
  * token per call through the same cached step (layers.py:246-314) the autoregressive loop uses -- the input of
@@ -211,7 +240,8 @@ enum { MT3_STATUS_GRAPH_FALLBACKS = 0, MT3_STATUS_LAST_DECODE_USED_GRAPH = 1, MT
        MT3_STATUS_DENSE_FP8 = 5 /* encoder dense layers on the MXFP8 path */,
        MT3_STATUS_QKV_FOLD = 6 /* the decoder layers' q/k/v projections folded into the preceding launches */,
        MT3_STATUS_LAST_DECODE_GROUPS = 7 /* row groups of the most recent decode (2 or 4: the row-group schedule); 1: on the caller's stream */,
-       MT3_STATUS_PARTITION_FALLBACKS = 8 /* decodes that wanted the row-group schedule but could not set it up */ };
+       MT3_STATUS_PARTITION_FALLBACKS = 8 /* decodes that wanted the row-group schedule but could not set it up */,
+       MT3_STATUS_LAST_DECODE_COMPACTIONS = 9 /* live-row compactions of the most recent decode (all row groups) */ };
 int mt3_engine_status(const mt3_engine* e, int32_t what);
 
 /* GenericTokenVocabulary._decode_tf (mt3/vocabularies.py:241-271): -1 from the

@@ -4,9 +4,10 @@
  * NOT part of the product ABI (include/mt3_hip.h): nothing here has a counterpart in the reference
  * (magenta/mt3), a drop-in caller never needs it, and results of the "skip" variants are meaningless.
  * bench.py uses mt3_debug_engine_decode for the in-situ duration of the decode-attention kernels
- * (a difference of whole-decode times instead of 8192 per-launch event pairs), tests use
- * mt3_debug_engine_poison_caches to prove that stale cache contents cannot leak into results, and
- * tools/ sweeps launch shapes with mt3_debug_set_knob.  Same conventions as mt3_hip.h.
+ * (a difference of whole-decode times instead of 8192 per-launch event pairs) and
+ * mt3_debug_engine_set_eos_schedule for its synthetic-length figure; tests use
+ * mt3_debug_engine_poison_caches to prove that stale cache contents cannot leak into results.
+ * Same conventions as mt3_hip.h.
  */
 #ifndef MT3_HIP_DEBUG_H_
 #define MT3_HIP_DEBUG_H_
@@ -25,24 +26,15 @@ enum { MT3_DEBUG_SKIP_SELF_ATTN = 1, MT3_DEBUG_SKIP_CROSS_ATTN = 2 };
 int mt3_debug_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t skip,
                             int32_t* d_ids, void* stream);
 
-/* EXPERIMENT (VERDICT r2, next #2 iii): the decode batch dealt to `n_groups` (2 .. 4) row groups, each driven by its own
- * host thread with DIRECT launches (no graph) on its own stream created with hipExtStreamCreateWithCUMask, so that one
- * group's HBM-bound attention kernels run beside another group's latency-bound GEMMs (measured: it is the hardware queue
- * a masked stream owns that makes them overlap -- full masks do as well as disjoint ones, plain streams serialise).
- * mask_mode: 0 = no CU mask (plain streams), 1 = group g owns the g-th contiguous block of CU-mask bits, 2 = group g
- * owns the bits i with i % n_groups == g; 3 .. 6 = as 2, and group g starts after a device-side delay of g x
- * {8, 15, 25, 40} us (does a phase offset between the groups survive, and does it help?); 7 .. 9 (two groups only) =
- * OVERLAPPING masks, each group on 5/8, 3/4, 7/8 of the CUs (bits i % 8 < k / i % 8 >= 8 - k), the middle ones shared; 10 = every group's stream with a FULL mask (what the product
- * uses); 11 .. 14 = 10 with one property of the product path each (11 the caller drives group 0, 12 own done slots and
- * begin / done events, 13 streams kept across calls, 14 group threads return when enqueued and the caller synchronises
- * the group streams); 15 / 16 = the product's own decode_partitioned() on the engine's / on fresh streams; 17 = this
- * function's loop on the engine's streams; 32 + bits = full masks with a combination (1 caller drives group 0, 2 events,
- * 4 threads do not wait, 8 with 2 and 4: only the caller's stream -- which waits for the done events -- is synchronised:
- * the variant that measures 6-15 % slower, i.e. every group stream needs a host thread waiting on it).  Greedy decode only; ids are identical to mt3_engine_decode's (rows are
- * independent).  Synchronises: returns when every group has finished.  h_ms (may be NULL) receives the wall time of
- * the decode loop in milliseconds. */
-int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t n_groups, int32_t mask_mode,
-                                  int32_t* d_ids, float* h_ms, void* stream);
+/* SYNTHETIC EOS SCHEDULE (bench.py's `eos_schedule` figure, SURVEY.md 8(d): "a second figure with a synthetic EOS
+ * schedule (lengths ~ clipped N(300,100))"; tests of the row retirement): random-init weights never emit EOS reliably, so
+ * the output LENGTH of row r is imposed -- at decode step h_lengths[r] - 1 (0-based) the model's distribution of that
+ * row is replaced by a point mass on EOS: the greedy decode emits EOS there (the row's output has h_lengths[r] tokens,
+ * the last one EOS), the beam-1 search finishes `prefix + EOS` with log-probability 0 and closes.  Everything before
+ * that step is the model's own arithmetic.  h_lengths [n] host int32, each >= 1 (rows >= n: never forced);
+ * NULL switches the schedule off.  Synchronous (a setup call); applies to every later mt3_engine_decode of the engine,
+ * not to mt3_engine_decode_forced. */
+int mt3_debug_engine_set_eos_schedule(mt3_engine* e, const int32_t* h_lengths, int32_t n);
 
 /* Fill the engine's self-attention K/V caches (and, with fp8 caches, their scale arrays) with the byte `pattern`
  * (0xFF = NaN in bf16 / f32 / e4m3; 0x7F.. etc.), and with cross != 0 also the cross-attention K/V buffers
@@ -50,29 +42,9 @@ int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_step
  * return exactly the ids it returns over zero-filled caches. */
 int mt3_debug_engine_poison_caches(mt3_engine* e, int32_t pattern, int32_t cross, void* stream);
 
-/* Process-wide launch-shape knobs (results do not change, only speed); value 0 = back to the default.
- *   DEC_ATTN_WAVES / DEC_ATTN_FP8_WAVES: waves per (row, head) workgroup of the decode attention (2, 3, 4)
- *   NO_LDS_DMA_GEMM: encoder GEMMs on the register-staged tile instead of the LDS-DMA ring
- *   F32_SPLIT_K: decode-sized f32 GEMM tiles with eight waves (K-groups split two ways) instead of four (summation
- *                order changes: ~1e-7; measured 1 % slower)
- *   XCD_N_MAJOR: decode-sized GEMM tiles dealt to the XCDs by weight-column slice instead of by row block:
- *                0 = automatically for weight matrices above 3 MB, 1 = always, 2 = never
- *   NO_K768_SPLIT: the K = 768 decode tiles (base.gin shape) always take K in one slice
- *   NO_GLDS_256: encoder GEMMs never take the 256 x 128 LDS-DMA tile
- *   FOLD_WIDE_TILE: the decoder's two-source fold launch on 32 x 64 tiles instead of 32 x 32 (measured slower)
- *   FRONTEND_32_FRAME_TILES: the log-mel kernel on 32-frame tiles (halves the halo re-read: traffic 1.18x -> 1.09x
- *                algorithmic; measured 17 % slower)
- *   ENC_ATTN_4_WAVES: encoder attention (bf16, T = 256) with four waves per (batch, head) workgroup instead of eight
- *   GLDS_FRAG_DB: encoder GEMMs on the 128-row LDS-DMA tile with a four-stage ring and double-buffered fragments
- *   GEGLU_NARROW_TILE: the decode step's GEGLU launch on 32 x 32 two-wave tiles (two workgroups per CU)
- *   PREFETCH2: decode-sized multi-slice GEMM tiles keep TWO K slices in flight instead of one (measured slower) */
-enum { MT3_DEBUG_KNOB_DEC_ATTN_WAVES = 0, MT3_DEBUG_KNOB_DEC_ATTN_FP8_WAVES = 1, MT3_DEBUG_KNOB_NO_LDS_DMA_GEMM = 2,
-       MT3_DEBUG_KNOB_F32_SPLIT_K = 3, MT3_DEBUG_KNOB_XCD_N_MAJOR = 4, MT3_DEBUG_KNOB_PREFETCH2 = 5,
-       MT3_DEBUG_KNOB_NO_K768_SPLIT = 6, MT3_DEBUG_KNOB_NO_GLDS_256 = 7,
-       MT3_DEBUG_KNOB_FOLD_WIDE_TILE = 8, MT3_DEBUG_KNOB_FRONTEND_32_FRAME_TILES = 9,
-       MT3_DEBUG_KNOB_ENC_ATTN_4_WAVES = 10, MT3_DEBUG_KNOB_GLDS_FRAG_DB = 11,
-       MT3_DEBUG_KNOB_GEGLU_NARROW_TILE = 12 };
-int mt3_debug_set_knob(int32_t knob, int32_t value);
+/* (Rounds 2-3 had thirteen process-wide launch-shape knobs here -- mt3_debug_set_knob -- and a row-group experiment
+ * entry, mt3_debug_engine_decode_split.  What they measured is recorded in DESIGN.md sections 3 and 5 and under
+ * profiles/r3_ab_*; the variants that lost are no longer compiled into the library, the ones that won are the code.) */
 
 #ifdef __cplusplus
 }

@@ -16,17 +16,14 @@ LIB_PATH = os.path.join(HERE, "libmt3hip.so")
 MT3_OK, MT3_ERR_INVALID, MT3_ERR_HIP, MT3_ERR_CAPACITY, MT3_ERR_MISSING = 0, -1, -2, -3, -4
 MT3_BF16, MT3_F32, MT3_FP8_E4M3 = 0, 1, 2
 EPI_STORE, EPI_RESID, EPI_GEGLU, EPI_POS, EPI_F32, EPI_HEADS = range(6)
-DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SINGLE_STREAM = 1, 2, 4, 8
+DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SINGLE_STREAM, DECODE_ASYNC = 1, 2, 4, 8, 16
 (OPT_SINGLE_RESIDUAL_STREAM, OPT_SEPARATE_PROJECTIONS, OPT_ENCODER_SINGLE_RESIDUAL_STREAM,
  OPT_SEPARATE_QKV_PROJECTION, OPT_NO_ROW_GROUPS) = 1, 2, 4, 8, 16              # mt3_engine_config.options
 # include/mt3_hip_debug.h (measurement / fault injection; not the product ABI)
 DEBUG_SKIP_SELF_ATTN, DEBUG_SKIP_CROSS_ATTN = 1, 2
-(DEBUG_KNOB_DEC_ATTN_WAVES, DEBUG_KNOB_DEC_ATTN_FP8_WAVES, DEBUG_KNOB_NO_LDS_DMA_GEMM, DEBUG_KNOB_F32_SPLIT_K,
- DEBUG_KNOB_XCD_N_MAJOR, DEBUG_KNOB_PREFETCH2, DEBUG_KNOB_NO_K768_SPLIT, DEBUG_KNOB_NO_GLDS_256,
- DEBUG_KNOB_FOLD_WIDE_TILE, DEBUG_KNOB_FRONTEND_32_FRAME_TILES, DEBUG_KNOB_ENC_ATTN_4_WAVES,
- DEBUG_KNOB_GLDS_FRAG_DB, DEBUG_KNOB_GEGLU_NARROW_TILE) = range(13)
 (STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8, STATUS_Q_FOLD,
- STATUS_DENSE_FP8, STATUS_QKV_FOLD, STATUS_LAST_DECODE_GROUPS, STATUS_PARTITION_FALLBACKS) = range(9)
+ STATUS_DENSE_FP8, STATUS_QKV_FOLD, STATUS_LAST_DECODE_GROUPS, STATUS_PARTITION_FALLBACKS,
+ STATUS_LAST_DECODE_COMPACTIONS) = range(10)
 EV_SHIFT, EV_PITCH, EV_VELOCITY, EV_TIE, EV_PROGRAM, EV_DRUM = range(6)
 EVENT_TYPE_NAMES = ("shift", "pitch", "velocity", "tie", "program", "drum")
 SPEC_ONSETS, SPEC_NOTES, SPEC_TIES = range(3)
@@ -81,13 +78,12 @@ SIGNATURES = {
     "mt3_engine_device_bytes": (C.c_int64, [_P]),
     "mt3_engine_encode": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "mt3_engine_decode": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), _P]),
+    "mt3_engine_decode_wait": (C.c_int, [_P, C.POINTER(C.c_int32)]),
     "mt3_engine_decode_forced": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "mt3_engine_status": (C.c_int, [_P, C.c_int32]),
     "mt3_debug_engine_decode": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mt3_debug_engine_poison_caches": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
-    "mt3_debug_engine_decode_split": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
-                                                C.POINTER(C.c_float), _P]),
-    "mt3_debug_set_knob": (C.c_int, [C.c_int32, C.c_int32]),
+    "mt3_debug_engine_set_eos_schedule": (C.c_int, [_P, _P, C.c_int32]),
     "mt3_ids_to_tokens": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mt3_op_gemm": (C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                               C.c_int32, _P, C.c_int32, C.c_int32, _P]),

@@ -308,11 +308,9 @@ __global__ __launch_bounds__(256) void enc_attn_split_kernel(const CT* __restric
 int launch_encoder_attention(int dtype, const void* qkv, void* out, int B, int T, int H, hipStream_t s) {
   if (!qkv || !out || B <= 0 || H <= 0) return mt3::fail(MT3_ERR_INVALID, "encoder_attention: bad arguments");
   const dim3 grid(B * H), block(256);
-  if (dtype == MT3_BF16 && T == 256 && !g_knobs.enc_attn_4_waves) {
+  if (dtype == MT3_BF16 && T == 256) {
+    // eight waves per (batch, head) workgroup: two such workgroups per CU (r3: 78 against 104 us per launch with four)
     hipLaunchKernelGGL((enc_attn_kernel<__bf16, 256, 8>), grid, dim3(512), 0, s, static_cast<const __bf16*>(qkv),
-                       static_cast<__bf16*>(out), H);
-  } else if (dtype == MT3_BF16 && T == 256) {
-    hipLaunchKernelGGL((enc_attn_kernel<__bf16, 256>), grid, block, 0, s, static_cast<const __bf16*>(qkv),
                        static_cast<__bf16*>(out), H);
   } else if (dtype == MT3_BF16 && T == 512) {
     hipLaunchKernelGGL((enc_attn_kernel<__bf16, 512>), grid, block, 0, s, static_cast<const __bf16*>(qkv),
@@ -401,8 +399,16 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPK, slot = lane / LPK;
-  const CT* kc = static_cast<const CT*>(a.kcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;
-  const CT* vc = static_cast<const CT*>(a.vcache) + (static_cast<size_t>(b) * a.H + h) * a.cap * D;
+  // Row retirement (a.done != nullptr; uniform over the launch, both loads scalar): a finished slot costs no cache
+  // byte -- the workgroup returns before its first request (its `out` row keeps the previous step's finite values; only
+  // the slot's own, ignored, residual row ever sees them); a live slot finds its cache row through the slot map.
+  int crow = b;
+  if (a.done) {
+    if (a.done[b]) return;
+    if (a.cache_row) crow = a.cache_row[b];
+  }
+  const CT* kc = static_cast<const CT*>(a.kcache) + (static_cast<size_t>(crow) * a.H + h) * a.cap * D;
+  const CT* vc = static_cast<const CT*>(a.vcache) + (static_cast<size_t>(crow) * a.H + h) * a.cap * D;
   // The first group of keys is requested BEFORE the row's position counter is known (its load would otherwise sit
   // in front of every cache load: one dependent memory round trip per launch): positions past the row's length are
   // discarded below, the memory behind them is always addressable (the cache is allocated to `cap` rows); its
@@ -464,7 +470,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
                                               h * D + sub * KPL);
     }
     if (tid < LPK) {
-      const size_t at = ((static_cast<size_t>(b) * a.H + h) * a.cap + pos) * D + sub * KPL;
+      const size_t at = ((static_cast<size_t>(crow) * a.H + h) * a.cap + pos) * D + sub * KPL;
       *reinterpret_cast<u32x4*>(static_cast<CT*>(a.kcache) + at) = new_k;
       *reinterpret_cast<u32x4*>(static_cast<CT*>(a.vcache) + at) = new_v;
     }
@@ -663,7 +669,12 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 3, slot = lane >> 2;
-  const size_t head = (static_cast<size_t>(b) * a.H + h) * a.cap;
+  int crow = b;                                        // row retirement: see dec_attn_kernel
+  if (a.done) {
+    if (a.done[b]) return;
+    if (a.cache_row) crow = a.cache_row[b];
+  }
+  const size_t head = (static_cast<size_t>(crow) * a.H + h) * a.cap;
   const uint8_t* kc = static_cast<const uint8_t*>(a.kcache) + head * D;
   const uint8_t* vc = static_cast<const uint8_t*>(a.vcache) + head * D;
   const float2* sc2 = a.kv_scale + head;
@@ -902,41 +913,22 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
   if (append && !a.new_v) return mt3::fail(MT3_ERR_INVALID, "decode_attention: new_k without new_v");
   // waves per (batch, head) workgroup.  B*H workgroups must all be resident for an even HBM stream:
   // at 84 VGPRs a CU holds 20 waves, so 3 waves per workgroup keeps B*H = 1536 groups (4608 waves)
-  // co-resident on 256 CUs, while 4 would leave a 256-group second round running at 1/5 occupancy.
-  const int nw = g_knobs.dec_attn_waves ? g_knobs.dec_attn_waves : 3;
+  // co-resident on 256 CUs, while 4 would leave a 256-group second round running at 1/5 occupancy
+  // (2 / 3 / 4 waves measured within 2 % of each other; r1).
   if (a.kv_scale) {
-    // waves per (row, head) workgroup, measured on MI355X at B = 256 (tools/gpu_fp8.sh): the growing self-attention
-    // cache streams best with 3 (22.8 us against 23.7 / 24.0 with 2 / 4 at the mean depth); the fixed 256-key
-    // cross-attention with 4 (one whole 64-key x 4 pass per wave: 12.4 us against 13.4 with 3)
-    const int nw = g_knobs.dec_attn_fp8_waves ? g_knobs.dec_attn_fp8_waves : (append ? 3 : 4);
-    const dim3 grid(a.B * a.H), block(nw * 64);
+    // measured on MI355X at B = 256 (r2): the growing self-attention cache streams best with 3 waves (22.8 us against
+    // 23.7 / 24.0 with 2 / 4 at the mean depth); the fixed 256-key cross-attention with 4 (one whole 64-key x 4 pass
+    // per wave: 12.4 us against 13.4 with 3)
     // fp8 (e4m3) K/V cache; activations (q, new rows, out) are bf16
     if (dtype != MT3_BF16) return mt3::fail(MT3_ERR_INVALID, "decode_attention: the fp8 K/V cache needs bf16 activations");
-#define MT3_LAUNCH_FP8(AP)                                                                       \
-  do {                                                                                           \
-    if (nw == 2) hipLaunchKernelGGL((dec_attn_fp8_kernel<AP, 2>), grid, block, 0, s, a);         \
-    else if (nw == 3) hipLaunchKernelGGL((dec_attn_fp8_kernel<AP, 3>), grid, block, 0, s, a);    \
-    else hipLaunchKernelGGL((dec_attn_fp8_kernel<AP, 4>), grid, block, 0, s, a);                 \
-  } while (0)
-    if (append) MT3_LAUNCH_FP8(true);
-    else MT3_LAUNCH_FP8(false);
-#undef MT3_LAUNCH_FP8
+    if (append) hipLaunchKernelGGL((dec_attn_fp8_kernel<true, 3>), dim3(a.B * a.H), dim3(192), 0, s, a);
+    else hipLaunchKernelGGL((dec_attn_fp8_kernel<false, 4>), dim3(a.B * a.H), dim3(256), 0, s, a);
     MT3_HIP_CHECK(hipGetLastError());
     return MT3_OK;
   }
-  const dim3 grid(a.B * a.H), block(nw * 64);
-#define MT3_LAUNCH_DEC(CT, AP)                                                                    \
-  do {                                                                                            \
-    if (nw == 2) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 2>), grid, block, 0, s, a);          \
-    else if (nw == 3) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 3>), grid, block, 0, s, a);     \
-    else hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 4>), grid, block, 0, s, a);                  \
-  } while (0)
-#define MT3_LAUNCH_DEC_Q(CT, AP)                                                                        \
-  do {                                                                                                  \
-    if (nw == 2) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 2, true>), grid, block, 0, s, a);          \
-    else if (nw == 3) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 3, true>), grid, block, 0, s, a);     \
-    else hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 4, true>), grid, block, 0, s, a);                  \
-  } while (0)
+  const dim3 grid(a.B * a.H), block(3 * 64);
+#define MT3_LAUNCH_DEC(CT, AP) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 3>), grid, block, 0, s, a)
+#define MT3_LAUNCH_DEC_Q(CT, AP) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 3, true>), grid, block, 0, s, a)
   if (dtype == MT3_BF16 && a.q_f32) {
     if (append) MT3_LAUNCH_DEC_Q(__bf16, true);
     else MT3_LAUNCH_DEC_Q(__bf16, false);

@@ -180,14 +180,19 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(float* __restrict__ lo
                                                            float* __restrict__ y_next, void* __restrict__ y_ct,
                                                            float* __restrict__ y_ss, int dim,
                                                            float* __restrict__ beam_f, int* __restrict__ beam_len,
+                                                           int* __restrict__ beam_len_row,
                                                            const float* __restrict__ beam_cfg, int beam_rows,
                                                            const int* __restrict__ forced, int forced_stride,
-                                                           RowProj rp, LogitScale ls) {
+                                                           RowProj rp, LogitScale ls, StepRetire rt) {
   __shared__ float s_v[8], s_sum[4];
   __shared__ int s_i[8];
   __shared__ int s_tok, s_t;
   __shared__ float s_rs;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // row retirement: a finished slot is not touched again (its ids stay at the 0 they were initialised to, its
+  // position counter stops: nothing reads it any more)
+  if (rt.retire && done[b]) return;
+  const int out_row = rt.slot_row ? rt.slot_row[b] : b;        // row of `ids` / `eos_at` this slot decodes
   float* row = logits + static_cast<size_t>(b) * vocab;
   if (ls.ss) {
     // folded logits projection: the row arrives unnormalised; 1/rms of the final residual row from its partial sums
@@ -205,11 +210,12 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(float* __restrict__ lo
     // (each thread re-reads below exactly the elements it just wrote: no barrier needed)
   }
   // thread 0 issues its state loads up front so that their latency hides behind the reductions
-  int was_done = 0, t = 0, blen = -1;
+  int was_done = 0, t = 0, blen = -1, eos_len = 0x7fffffff;
   float live = 0.f, best = 0.f, bp_max = 1.f, bp_t = 1.f;
   if (tid == 0) {
     was_done = done[b];
     t = step[b];
+    if (rt.eos_at) eos_len = rt.eos_at[out_row];
     if (BEAM1) {
       live = beam_f[b];
       best = beam_f[beam_rows + b];
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(float* __restrict__ lo
     int tok;
     if (!BEAM1) {
       if (forced) was_done = 0;           // teacher forcing: every step reports its own arg-max, no EOS bookkeeping
-      tok = was_done ? 0 : t2.i1;
+      tok = was_done ? 0 : (t + 1 >= eos_len ? 1 : t2.i1);      // synthetic EOS schedule: a point mass on EOS
       if (!was_done && tok == 1 && !forced) {        // EOS
         done[b] = 1;
         atomicAdd(n_done, 1);
@@ -269,8 +275,13 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(float* __restrict__ lo
 #pragma unroll
         for (int w = 0; w < 4; ++w) sum += s_sum[w] * __expf(s_v[w] - m);
         const float lse = m + __logf(sum);
-        const float lp1 = t2.v1 - lse, lp2 = t2.v2 - lse;
-        const int eos_slot = t2.i1 == 1 ? 1 : (t2.i2 == 1 ? 2 : 0);
+        float lp1 = t2.v1 - lse, lp2 = t2.v2 - lse;
+        int eos_slot = t2.i1 == 1 ? 1 : (t2.i2 == 1 ? 2 : 0);
+        if (t + 1 >= eos_len) {           // synthetic EOS schedule: EOS with probability 1, everything else impossible
+          eos_slot = 1;
+          lp1 = 0.f;
+          lp2 = -1.0e30f;
+        }
         if (eos_slot) {
           const float score = (live + (eos_slot == 1 ? lp1 : lp2)) / bp_t;
           if (blen < 0 || score > best) {
@@ -283,13 +294,14 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(float* __restrict__ lo
         beam_f[b] = live;
         beam_f[beam_rows + b] = best;
         beam_len[b] = blen;
+        beam_len_row[out_row] = blen;
         if (blen >= 0 && best > live / bp_max) {
           done[b] = 1;
           atomicAdd(n_done, 1);
         }
       }
     }
-    ids[static_cast<size_t>(b) * ids_stride + t] = tok;
+    ids[static_cast<size_t>(out_row) * ids_stride + t] = tok;
     // teacher forcing (Transformer.decode on given decoder_input_tokens, network.py:303-361): the NEXT input is
     // the caller's token for position t + 1, whatever this step predicted
     if (!BEAM1 && forced) tok = forced[static_cast<size_t>(b) * forced_stride + t];
@@ -315,8 +327,12 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(float* __restrict__ lo
 int launch_argmax_step(float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
                        float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam,
-                       const int* forced, int forced_stride, const RowProj& rp, const LogitScale& ls, hipStream_t s) {
+                       const int* forced, int forced_stride, const RowProj& rp, const LogitScale& ls,
+                       const StepRetire& rt, hipStream_t s) {
   if (beam && forced) return mt3::fail(MT3_ERR_INVALID, "argmax_step: teacher forcing is a greedy-path feature");
+  if (beam && !beam->len_row) return mt3::fail(MT3_ERR_INVALID, "argmax_step: the beam state needs its row-indexed lengths");
+  if (forced && (rt.retire || rt.slot_row || rt.eos_at))
+    return mt3::fail(MT3_ERR_INVALID, "argmax_step: teacher forcing keeps every row live and in place");
   if (ls.ss && (ls.n_ss <= 0 || ls.n_ss > 64 || ls.dim <= 0))
     return mt3::fail(MT3_ERR_INVALID, "argmax_step: the row scale needs 1 .. 64 partial sums");
   if (rp.q_out && (!y_next || !rp.ew || !rp.pw || rp.q_n % 4))
@@ -324,23 +340,99 @@ int launch_argmax_step(float* logits, int vocab, int* ids, int ids_stride, int* 
   if (beam)
     hipLaunchKernelGGL(argmax_step_kernel<true>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
                        done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, beam->f, beam->len,
-                       beam->cfg, beam->rows, nullptr, 0, rp, ls);
+                       beam->len_row, beam->cfg, beam->rows, nullptr, 0, rp, ls, rt);
   else
     hipLaunchKernelGGL(argmax_step_kernel<false>, dim3(B), dim3(256), 0, s, logits, vocab, ids, ids_stride, cur_tok,
-                       done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, nullptr, nullptr, nullptr, 0,
-                       forced, forced_stride, rp, ls);
+                       done, n_done, step, table, pos_table, max_pos, y_next, y_ct, y_ss, dim, nullptr, nullptr, nullptr,
+                       nullptr, 0, forced, forced_stride, rp, ls, rt);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }
 
-// busy-wait on the device for ~us microseconds (one lane; wall_clock64 ticks at 100 MHz): the stagger of the
-// row-group experiment (mt3_debug_engine_decode_split)
-__global__ void delay_kernel(long long ticks) {
-  const long long t0 = wall_clock64();
-  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+// ---------------------------------------------------------------------------------------------- row retirement
+// Compaction of a row group's live slots (CompactArgs, kernels.h).  Three launches on the group's stream, issued at a
+// poll of the early-exit loop when the live rows fit a smaller number of 32-row GEMM tiles:
+//   plan    one wave: perm[i] = i-th live slot (ascending: the order of the rows never changes), perm[rows] = n_live
+//   gather  block i < n_live: state of slot perm[i] -> scratch slot i
+//   scatter block i: scratch slot i -> slot i, done = 0 (i < n_live);  done = 1 (i >= n_live)
+// (two passes because perm[i] >= i: slot k is the source of one block and the destination of another)
+__global__ __launch_bounds__(64) void compact_plan_kernel(const int* __restrict__ done, int* __restrict__ perm, int rows) {
+  const int lane = threadIdx.x;
+  int n = 0;
+  for (int base = 0; base < rows; base += 64) {
+    const int i = base + lane;
+    const bool live = i < rows && done[i] == 0;
+    const unsigned long long m = __ballot(live);
+    if (live) perm[n + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    n += __popcll(m);
+  }
+  if (lane == 0) perm[rows] = n;
 }
-int launch_delay_us(int us, hipStream_t s) {
-  hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(1), 0, s, static_cast<long long>(us) * 100);
+
+template <bool GATHER>
+__global__ __launch_bounds__(128) void compact_move_kernel(CompactArgs c) {
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const int n_live = c.perm[c.rows];
+  if (i >= n_live) {
+    if (!GATHER && tid == 0) c.done[i] = 1;
+    return;
+  }
+  const size_t src = GATHER ? static_cast<size_t>(c.perm[i]) : static_cast<size_t>(i), dst = i;
+  const float *y = GATHER ? c.y : c.s_y, *ss = GATHER ? c.y_ss : c.s_y_ss, *q = GATHER ? c.qkvf : c.s_qkvf;
+  float *yo = GATHER ? c.s_y : c.y, *sso = GATHER ? c.s_y_ss : c.y_ss, *qo = GATHER ? c.s_qkvf : c.qkvf;
+  const uint2* ct = static_cast<const uint2*>(GATHER ? c.y_ct : c.s_y_ct);
+  uint2* cto = static_cast<uint2*>(GATHER ? c.s_y_ct : c.y_ct);
+  for (int k = tid; k < c.emb / 4; k += 128) {
+    reinterpret_cast<float4*>(yo + dst * c.emb)[k] = reinterpret_cast<const float4*>(y + src * c.emb)[k];
+    if (ct) cto[dst * (c.emb / 4) + k] = ct[src * (c.emb / 4) + k];
+  }
+  if (ss)
+    for (int k = tid; k < c.emb / 16; k += 128) sso[dst * (c.emb / 16) + k] = ss[src * (c.emb / 16) + k];
+  if (q)
+    for (int k = tid; k < c.q_n / 4; k += 128)
+      reinterpret_cast<float4*>(qo + dst * c.q_n)[k] = reinterpret_cast<const float4*>(q + src * c.q_n)[k];
+  if (tid == 0) {
+    if (GATHER) {
+      c.s_int[4 * dst + 0] = c.slot_row[src];
+      c.s_int[4 * dst + 1] = c.step[src];
+      c.s_int[4 * dst + 2] = c.cur_tok[src];
+      c.s_int[4 * dst + 3] = c.beam_len ? c.beam_len[src] : 0;
+      if (c.beam_f) {
+        c.s_beam[2 * dst + 0] = c.beam_f[src];
+        c.s_beam[2 * dst + 1] = c.beam_f[c.beam_rows + src];
+      }
+    } else {
+      c.slot_row[dst] = c.s_int[4 * dst + 0];
+      c.step[dst] = c.s_int[4 * dst + 1];
+      c.cur_tok[dst] = c.s_int[4 * dst + 2];
+      if (c.beam_len) c.beam_len[dst] = c.s_int[4 * dst + 3];
+      if (c.beam_f) {
+        c.beam_f[dst] = c.s_beam[2 * dst + 0];
+        c.beam_f[c.beam_rows + dst] = c.s_beam[2 * dst + 1];
+      }
+      c.done[dst] = 0;
+    }
+  }
+}
+
+int launch_compact(const CompactArgs& c, hipStream_t s) {
+  if (!c.done || !c.slot_row || !c.step || !c.cur_tok || !c.y || !c.s_y || !c.s_int || !c.perm || c.rows <= 0 ||
+      c.emb % 16 || c.q_n % 4 || (c.y_ct && !c.s_y_ct) || (c.y_ss && !c.s_y_ss) || (c.qkvf && !c.s_qkvf) ||
+      (c.beam_f && (!c.s_beam || !c.beam_len)))
+    return mt3::fail(MT3_ERR_INVALID, "compact: bad arguments");
+  hipLaunchKernelGGL(compact_plan_kernel, dim3(1), dim3(64), 0, s, c.done, c.perm, c.rows);
+  hipLaunchKernelGGL(compact_move_kernel<true>, dim3(c.rows), dim3(128), 0, s, c);
+  hipLaunchKernelGGL(compact_move_kernel<false>, dim3(c.rows), dim3(128), 0, s, c);
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+
+__global__ void iota_kernel(int* dst, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dst[i] = i;
+}
+int launch_iota(int* dst, int n, hipStream_t s) {
+  hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, dst, n);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

@@ -26,11 +26,14 @@
 //     (B=256: ~3.3 GB KV cache + ~0.9 GB cross K/V + ~0.5 GB activations in bf16).
 #include <hip/hip_runtime.h>
 
-#include <chrono>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -83,6 +86,45 @@ struct LayerDev {
   // fp8 (e4m3) K/V caches only: {k_scale, v_scale} per cached row
   float2* self_scale = nullptr;    // [Bm][H][L]
   float2* cross_scale = nullptr;   // [B][H][T]
+};
+
+// Variant bits of one decode step (index of a captured step graph): 1 / 2 = mt3_debug_engine_decode's skipped kernels,
+// 4 = beam-1 token selection, 8 = teacher forcing, 16 = row retirement (finished slots cost nothing, the slot map is
+// in use), 32 = the synthetic EOS schedule (mt3_debug_engine_set_eos_schedule)
+constexpr int kVarBeam = 4, kVarForced = 8, kVarRetire = 16, kVarEos = 32, kNumVariants = 64;
+constexpr int kMaxGroups = 4;
+
+// One persistent host thread per row group (created with the first decode that needs it, joined at destroy): a
+// decode call hands each group's loop to one of them instead of spawning threads per call, and with
+// MT3_DECODE_ASYNC the caller gets its own thread back while they run.
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, quit = false;
+};
+
+// a captured decode step of rows [row0, row0 + rows) of a `batch`-row decode
+struct GroupGraph {
+  int variant, batch, row0, rows, slot;
+  hipGraph_t graph;
+  hipGraphExec_t exec;
+};
+
+// what mt3_engine_decode left for mt3_engine_decode_wait
+struct PendingDecode {
+  bool active = false;
+  int posted = 0;               // workers that hold a job of this decode
+  int groups = 1;
+  bool beam1 = false;
+  bool used_graph[kMaxGroups] = {};
+  int batch = 0;
+  int32_t* d_ids = nullptr;
+  hipStream_t s = nullptr;
+  int rcs[kMaxGroups] = {};
+  int ran[kMaxGroups] = {};
+  std::string errs[kMaxGroups];
 };
 
 }  // namespace
@@ -160,10 +202,32 @@ struct mt3_engine {
   int* n_done = nullptr;
   int* h_pinned = nullptr;
   int* forced = nullptr;         // [max_batch][L] teacher-forcing tokens of the current mt3_engine_decode_forced call
-  int graph_fallbacks = 0;       // decode calls whose step graph could not be captured (ran as direct launches)
+  std::atomic<int> graph_fallbacks{0};   // decode loops whose step graph could not be captured (ran as direct launches)
   int last_used_graph = 0;
+  // Row retirement (MT3_DECODE_EARLY_EXIT): per-row-of-the-batch state lives in SLOTS; slot_row maps a slot to the row
+  // whose caches / ids it works on.  Live slots are compacted to the front of their row group at the early-exit poll
+  // (launch_compact), so attention grids and the GEMMs' M shrink with the live set while the caches stay in place.
+  int* slot_row = nullptr;       // [max_batch]
+  int* eos_at = nullptr;         // [max_batch] synthetic EOS schedule (mt3_debug_engine_set_eos_schedule)
+  bool eos_on = false;
+  float* cs_y = nullptr;         // compaction scratch: same shapes as y / y_ct / y_ss / qkvf, 4 ints + 2 floats per slot
+  void* cs_y_ct = nullptr;
+  float* cs_y_ss = nullptr;
+  float* cs_qkvf = nullptr;
+  int* cs_int = nullptr;
+  float* cs_beam = nullptr;
+  int* cs_perm = nullptr;        // [max_batch + kMaxChains]: rows + 1 entries per group
+  int compactions = 0;           // compactions of the most recent decode (all groups; written at the end of the decode)
+  std::atomic<int> compactions_now{0};
+  // step graphs of single row groups (the single-stream schedule is the group [0, batch))
+  std::vector<GroupGraph> group_graphs;
+  std::mutex graph_mu;
+  Worker* workers[kMaxGroups] = {};
+  int device = 0;
+  PendingDecode pending;
   float* beam_f = nullptr;       // [2][max_batch]: live log-prob | best finished score (MT3_DECODE_BEAM1)
-  int* beam_len = nullptr;       // [max_batch]
+  int* beam_len = nullptr;       // [max_batch] per slot
+  int* beam_len_row = nullptr;   // [max_batch] per row (read by the finalisation)
   float* beam_cfg = nullptr;     // [0] brevity penalty of the loop bound, [1 + n] brevity_penalty(n)
 
   // Row-group decode schedule (round 3): the batch as 2 or 4 row groups (row_groups_for), each on an engine-owned stream
@@ -173,7 +237,6 @@ struct mt3_engine {
   // 818 ms per 1024-step decode (HIP multiplexes them onto its queue pool and the groups serialise), two masked ones
   // 588 ms whether the masks are disjoint halves, overlap, or cover every CU (one graph-replayed chain: 626 ms).
   hipStream_t part_stream[4] = {};
-  hipEvent_t part_done[4] = {};
   hipEvent_t part_begin = nullptr;
   int part_failed = 0;           // partitioned decodes that fell back to the single-stream schedule (stream creation failed)
   int last_groups = 1;           // row groups of the most recent decode
@@ -183,8 +246,8 @@ struct mt3_engine {
   hipEvent_t cap_event[8] = {};
   // one captured decode step per (batch, variant); variant bits: 1 = no self-attention, 2 = no
   // cross-attention (differential profiling only), 4 = beam-1 token selection, 8 = teacher forcing
-  hipGraphExec_t graph_exec[16][9] = {};   // [variant][chains]
-  hipGraph_t graph[16][9] = {};
+  hipGraphExec_t graph_exec[kNumVariants][9] = {};   // [variant][chains]: the step graph with `chains` parallel branches
+  hipGraph_t graph[kNumVariants][9] = {};
   int graph_batch = 0;
 
   int HD() const { return cfg.num_heads * cfg.head_dim; }
@@ -498,6 +561,10 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   const bool small = true;
   const int nl = c.num_decoder_layers;
   const bool split = e->y_split, fold = e->qkv_fold;
+  // row retirement: the step's slots [row0, row0 + rows) reach their cache rows / id rows through e->slot_row, so the
+  // cache and id base pointers stay those of the whole batch
+  const bool retire = (skip & kVarRetire) != 0;
+  const size_t crow0 = retire ? 0 : static_cast<size_t>(row0);
   // Which of the two residual buffers is current (qkv-fold only: the two-source launch at the end of layer l reads the
   // rows it replaces, so the rows move to the other buffer there): layer l works on buffer l & 1; the logits and the
   // arg-max read the last layer's, the arg-max writes the next step's input row into buffer 0.
@@ -546,15 +613,18 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
                              small, s);
   }
   if (op == 8 * nl + 1) {
-    const mt3k::BeamState beam{e->beam_f + row0, e->beam_len + row0, e->beam_cfg, c.max_batch};
+    const mt3k::BeamState beam{e->beam_f + row0, e->beam_len + row0, e->beam_cfg, c.max_batch, e->beam_len_row + crow0};
     const mt3k::RowProj rp{e->ew0, e->pw0, qkvf, 4 * hd};
     // folded logits arrive unnormalised: the row scale comes from the final residual row's partial sums
     const mt3k::LogitScale ls{fold ? y_ss : nullptr, emb / 16, emb};
-    return mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + static_cast<size_t>(row0) * Lmax, Lmax,
+    const mt3k::StepRetire rt{retire ? 1 : 0, retire ? e->slot_row + row0 : nullptr,
+                              (skip & kVarEos) ? e->eos_at + crow0 : nullptr};
+    return mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + crow0 * Lmax, Lmax,
                                     e->cur_tok + row0, e->done + row0, e->n_done + done_slot, step, e->embedding, e->pos_table,
                                     kMaxPos, y_buf(0), split && !f32 ? yct_buf(0) : nullptr, y_ss, emb, rows,
-                                    (skip & 4) ? &beam : nullptr,
-                                    (skip & 8) ? e->forced + static_cast<size_t>(row0) * Lmax : nullptr, Lmax, rp, ls, s);
+                                    (skip & kVarBeam) ? &beam : nullptr,
+                                    (skip & kVarForced) ? e->forced + static_cast<size_t>(row0) * Lmax : nullptr, Lmax, rp, ls,
+                                    rt, s);
   }
   LayerDev& L = e->dec[op >> 3];
   switch (op & 7) {
@@ -572,9 +642,13 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
       mt3k::DecAttnArgs a{};
       a.q = qkv_d;
       a.q_stride = 3 * hd;
-      a.kcache = static_cast<char*>(L.self_k) + static_cast<size_t>(row0) * H * Lmax * 64 * kes;
-      a.vcache = static_cast<char*>(L.self_v) + static_cast<size_t>(row0) * H * Lmax * 64 * kes;
-      a.kv_scale = e->kv_fp8 ? L.self_scale + static_cast<size_t>(row0) * H * Lmax : nullptr;
+      a.kcache = static_cast<char*>(L.self_k) + crow0 * H * Lmax * 64 * kes;
+      a.vcache = static_cast<char*>(L.self_v) + crow0 * H * Lmax * 64 * kes;
+      a.kv_scale = e->kv_fp8 ? L.self_scale + crow0 * H * Lmax : nullptr;
+      if (retire) {
+        a.done = e->done + row0;
+        a.cache_row = e->slot_row + row0;
+      }
       a.cap = Lmax;
       a.new_k = qkv_d + static_cast<size_t>(hd) * es;
       a.new_v = qkv_d + static_cast<size_t>(2 * hd) * es;
@@ -618,9 +692,13 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
         x.q_ss = y_ss;
         x.q_ss_n = emb / 16;
       }
-      x.kcache = static_cast<char*>(L.cross_kv) + static_cast<size_t>(row0) * H * T * 64 * kes;
-      x.vcache = static_cast<char*>(L.cross_kv) + (static_cast<size_t>(B_total) + row0) * H * T * 64 * kes;
-      x.kv_scale = e->kv_fp8 ? L.cross_scale + static_cast<size_t>(row0) * H * T : nullptr;
+      x.kcache = static_cast<char*>(L.cross_kv) + crow0 * H * T * 64 * kes;
+      x.vcache = static_cast<char*>(L.cross_kv) + (static_cast<size_t>(B_total) + crow0) * H * T * 64 * kes;
+      x.kv_scale = e->kv_fp8 ? L.cross_scale + crow0 * H * T : nullptr;
+      if (retire) {
+        x.done = e->done + row0;
+        x.cache_row = e->slot_row + row0;
+      }
       x.cap = T;
       x.n_keys = T;
       x.out = attn_d;
@@ -689,7 +767,7 @@ int enqueue_decode_step(mt3_engine* e, int B, int skip, int n, hipStream_t s) {
 }
 
 void drop_graph(mt3_engine* e) {
-  for (int v = 0; v < 16; ++v)
+  for (int v = 0; v < kNumVariants; ++v)
     for (int n = 0; n < 9; ++n) {
       if (e->graph_exec[v][n]) (void)hipGraphExecDestroy(e->graph_exec[v][n]);
       if (e->graph[v][n]) (void)hipGraphDestroy(e->graph[v][n]);
@@ -743,6 +821,9 @@ int ensure_graph(mt3_engine* e, int B, int skip, int n) {
 
 extern "C" {
 
+static void workers_stop(mt3_engine* e);
+static void drop_group_graphs(mt3_engine* e);
+
 int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (!cfg || !out) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: null argument");
   if (cfg->head_dim != 64) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: head_dim must be 64");
@@ -772,6 +853,10 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
   e->cfg = *cfg;
+  if (hipGetDevice(&e->device) != hipSuccess) {
+    (void)hipGetLastError();
+    e->device = 0;                 // no GPU: the failure is reported by the first call that needs one (finalize)
+  }
   e->dense_fp8 = cfg->dense_dtype == MT3_FP8_E4M3;
   e->esize = cfg->compute_dtype == MT3_BF16 ? 2 : 4;
   e->kv_fp8 = cfg->kv_cache_dtype == MT3_FP8_E4M3;
@@ -782,15 +867,15 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
 
 void mt3_engine_destroy(mt3_engine* e) {
   if (!e) return;
+  workers_stop(e);                 // joins a decode that is still in flight
   drop_graph(e);
+  drop_group_graphs(e);
   for (int k = 0; k < kMaxChains; ++k) {
     if (e->cap_stream[k]) (void)hipStreamDestroy(e->cap_stream[k]);
     if (e->cap_event[k]) (void)hipEventDestroy(e->cap_event[k]);
   }
-  for (int g = 0; g < 4; ++g) {
+  for (int g = 0; g < 4; ++g)
     if (e->part_stream[g]) (void)hipStreamDestroy(e->part_stream[g]);
-    if (e->part_done[g]) (void)hipEventDestroy(e->part_done[g]);
-  }
   if (e->part_begin) (void)hipEventDestroy(e->part_begin);
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   for (void* p : e->allocs) (void)hipFree(p);
@@ -968,8 +1053,19 @@ int mt3_engine_finalize(mt3_engine* e) {
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->step), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->n_done), 4 * kMaxChains))) return rc;   // one counter per row group
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->forced), static_cast<size_t>(Bm) * L * 4))) return rc;
+  // row retirement: slot map, synthetic EOS schedule, compaction scratch
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->slot_row), static_cast<size_t>(Bm) * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->eos_at), static_cast<size_t>(Bm) * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->cs_y), static_cast<size_t>(Bm) * emb * 4))) return rc;
+  if (e->y_split && c.compute_dtype == MT3_BF16 && (rc = dmalloc(e, &e->cs_y_ct, static_cast<size_t>(Bm) * emb * 2))) return rc;
+  if (e->y_split && (rc = dmalloc(e, reinterpret_cast<void**>(&e->cs_y_ss), static_cast<size_t>(Bm) * (emb / 16) * 4))) return rc;
+  if (e->qkv_fold && (rc = dmalloc(e, reinterpret_cast<void**>(&e->cs_qkvf), static_cast<size_t>(Bm) * 4 * hd * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->cs_int), static_cast<size_t>(Bm) * 4 * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->cs_beam), static_cast<size_t>(Bm) * 2 * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->cs_perm), (static_cast<size_t>(Bm) + kMaxChains) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->beam_f), static_cast<size_t>(2) * Bm * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->beam_len), static_cast<size_t>(Bm) * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->beam_len_row), static_cast<size_t>(Bm) * 4))) return rc;
   {
     // beam_cfg[0]: loop bound of the current call; beam_cfg[1 + n] = brevity_penalty(n), n = 0 .. L + 1
     std::vector<float> bp(static_cast<size_t>(L) + 3, 0.f);
@@ -987,6 +1083,8 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
   if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: engine not finalized");
   if (!d_inputs || batch <= 0 || batch > e->cfg.max_batch)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: batch out of range");
+  if (e->pending.active)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: a decode is in flight (MT3_DECODE_ASYNC): call mt3_engine_decode_wait first");
   const mt3_engine_config& c = e->cfg;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), T = c.input_length;
@@ -1096,9 +1194,7 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
   return MT3_OK;
 }
 
-// The decode loop as `groups` row groups on CU-masked streams, one host thread each (mt3_engine::part_stream).  The
-// caller's stream is never synchronised unless EARLY_EXIT polls: the groups start after an event recorded on it and it
-// waits for an event per group at the end.  MT3_ERR_CAPACITY = the streams could not be set up (caller falls back).
+// ---------------------------------------------------------------------------------------------- the decode loop
 // Row groups of the product decode schedule (mt3_engine::part_stream).  Measured on MI355X, ms per 1024-step decode,
 // 1 / 2 / 4 groups (profiles/r3_ab_row_groups_*.txt): bf16 B = 256: 626 / 588 / 608, B = 512: 1113 / 1048 / 1013;
 // f32 B = 128: 747 / 684 / 737, B = 256: 1178 / 1132 / 1098 -- groups of ~128 rows for bf16 operands, ~64 for f32.
@@ -1109,73 +1205,247 @@ static int row_groups_for(const mt3_engine_config& c, int batch) {
   return batch >= 128 ? 2 : 1;
 }
 
-static int decode_partitioned(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int skip, int groups,
-                              int* steps_run, hipStream_t s) {
-  int n_cu = 0, dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess ||
-      hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 2 * groups)
-    return MT3_ERR_CAPACITY;
-  for (int g = 0; g < groups; ++g) {
-    if (!e->part_stream[g]) {
-      // a mask of ALL compute units: the stream is created through the CU-mask entry point for the hardware queue of
-      // its own that comes with it, not to restrict it (see mt3_engine::part_stream)
-      std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
-      for (int i = 0; i < n_cu; ++i) mask[i >> 5] |= 1u << (i & 31);
-      if (hipExtStreamCreateWithCUMask(&e->part_stream[g], static_cast<uint32_t>(mask.size()), mask.data()) != hipSuccess) {
-        e->part_stream[g] = nullptr;
-        (void)hipGetLastError();
-        return MT3_ERR_CAPACITY;
+// ---- persistent group workers
+static void worker_main(Worker* w, int dev) {
+  (void)hipSetDevice(dev);
+  std::unique_lock<std::mutex> lk(w->mu);
+  for (;;) {
+    w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+    if (!w->has_job) return;                       // quit (a posted job is always run first)
+    std::function<void()> job = std::move(w->job);
+    lk.unlock();
+    try {
+      job();
+    } catch (...) {                                // nothing may leave a thread of a C library
+    }
+    lk.lock();
+    w->has_job = false;
+    w->cv.notify_all();
+  }
+}
+
+// false: the worker thread could not be created (the caller falls back to the calling thread)
+static bool worker_post(mt3_engine* e, int g, std::function<void()> fn) {
+  if (!e->workers[g]) {
+    Worker* w = new (std::nothrow) Worker();
+    if (!w) return false;
+    try {
+      w->th = std::thread(worker_main, w, e->device);
+    } catch (...) {
+      delete w;
+      return false;
+    }
+    e->workers[g] = w;
+  }
+  Worker* w = e->workers[g];
+  {
+    std::lock_guard<std::mutex> lk(w->mu);
+    w->job = std::move(fn);
+    w->has_job = true;
+  }
+  w->cv.notify_all();
+  return true;
+}
+
+static void worker_wait(mt3_engine* e, int g) {
+  Worker* w = e->workers[g];
+  if (!w) return;
+  std::unique_lock<std::mutex> lk(w->mu);
+  w->cv.wait(lk, [&] { return !w->has_job; });
+}
+
+static void workers_stop(mt3_engine* e) {
+  for (int g = 0; g < kMaxGroups; ++g) {
+    Worker* w = e->workers[g];
+    if (!w) continue;
+    {
+      std::unique_lock<std::mutex> lk(w->mu);
+      w->cv.wait(lk, [&] { return !w->has_job; });
+      w->quit = true;
+    }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+    delete w;
+    e->workers[g] = nullptr;
+  }
+}
+
+static void drop_group_graphs(mt3_engine* e) {
+  for (GroupGraph& g : e->group_graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
+  e->group_graphs.clear();
+}
+
+// The captured step of slots [row0, row0 + rows) (nullptr: capture failed, the caller launches directly).  Captured on
+// an engine-owned stream in thread-local mode -- several group threads may be here at once, the cache is guarded.
+static hipGraphExec_t group_graph(mt3_engine* e, int variant, int batch, int row0, int rows, int slot) {
+  std::lock_guard<std::mutex> lk(e->graph_mu);
+  for (const GroupGraph& g : e->group_graphs)
+    if (g.variant == variant && g.batch == batch && g.row0 == row0 && g.rows == rows && g.slot == slot) return g.exec;
+  if (!e->cap_stream[slot] && hipStreamCreateWithFlags(&e->cap_stream[slot], hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  hipStream_t cs = e->cap_stream[slot];
+  if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  const int rc = enqueue_chain_step(e, row0, rows, slot, batch, variant, cs, slot);
+  hipGraph_t g = nullptr;
+  hipGraphExec_t x = nullptr;
+  const hipError_t end = hipStreamEndCapture(cs, &g);
+  if (rc != MT3_OK || end != hipSuccess || hipGraphInstantiate(&x, g, nullptr, nullptr, 0) != hipSuccess) {
+    if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  e->group_graphs.push_back(GroupGraph{variant, batch, row0, rows, slot, g, x});
+  return x;
+}
+
+// One row group's decode loop: slots [row0, row0 + rows) of a `batch`-row decode on stream `s` (the single-stream
+// schedule is the group [0, batch) on the caller's stream).
+struct GroupRun {
+  int row0, rows, batch, variant, num_steps, slot;
+  bool early, use_graph;
+  hipStream_t s;
+  float* d_first_logits;      // single-stream schedule only
+  float* d_step_logits;
+  int ran;
+  bool used_graph;
+};
+
+static int compact_group(mt3_engine* e, const GroupRun& r, int cur) {
+  const mt3_engine_config& c = e->cfg;
+  const size_t r0 = static_cast<size_t>(r.row0);
+  const int emb = c.emb_dim, n4 = 4 * e->HD();
+  mt3k::CompactArgs a{};
+  a.done = e->done + r0;
+  a.slot_row = e->slot_row + r0;
+  a.step = e->step + r0;
+  a.cur_tok = e->cur_tok + r0;
+  if (r.variant & kVarBeam) {
+    a.beam_f = e->beam_f + r0;
+    a.beam_len = e->beam_len + r0;
+    a.beam_rows = c.max_batch;
+    a.s_beam = e->cs_beam + 2 * r0;
+  }
+  a.y = e->y + r0 * emb;                                  // the arg-max kernel leaves the next input row in buffer 0
+  a.s_y = e->cs_y + r0 * emb;
+  if (e->y_split && c.compute_dtype == MT3_BF16) {
+    a.y_ct = static_cast<char*>(e->y_ct) + r0 * emb * 2;
+    a.s_y_ct = static_cast<char*>(e->cs_y_ct) + r0 * emb * 2;
+  }
+  if (e->y_split) {
+    a.y_ss = e->y_ss + r0 * (emb / 16);
+    a.s_y_ss = e->cs_y_ss + r0 * (emb / 16);
+  }
+  if (e->qkv_fold) {
+    a.qkvf = e->qkvf + r0 * n4;
+    a.s_qkvf = e->cs_qkvf + r0 * n4;
+  }
+  a.emb = emb;
+  a.q_n = n4;
+  a.s_int = e->cs_int + 4 * r0;
+  a.perm = e->cs_perm + r0 + r.slot;
+  a.rows = cur;
+  return mt3k::launch_compact(a, r.s);
+}
+
+static int run_group(mt3_engine* e, GroupRun& r) {
+  const mt3_engine_config& c = e->cfg;
+  const bool retire = (r.variant & kVarRetire) != 0;
+  const bool whole = r.row0 == 0 && r.rows == r.batch;
+  int cur = r.rows;                              // slots in use: shrinks with the live rows in 32-row (GEMM tile) steps
+  hipGraphExec_t exec = nullptr;
+  int exec_rows = -1;
+  r.ran = 0;
+  r.used_graph = r.use_graph;
+  for (int t = 0; t < r.num_steps; ++t) {
+    if (r.use_graph && exec_rows != cur) {
+      exec = group_graph(e, r.variant, r.batch, r.row0, cur, r.slot);
+      exec_rows = cur;
+      if (!exec) {                               // direct launches give the same ids; the fallback is RECORDED
+        r.use_graph = r.used_graph = false;
+        ++e->graph_fallbacks;
       }
     }
-    if (!e->part_done[g] && hipEventCreateWithFlags(&e->part_done[g], hipEventDisableTiming) != hipSuccess)
+    if (r.use_graph) MT3_HIP_CHECK(hipGraphLaunch(exec, r.s));
+    else MT3_TRY(enqueue_chain_step(e, r.row0, cur, r.slot, r.batch, r.variant, r.s, r.slot));
+    ++r.ran;
+    if (whole && t == 0 && r.d_first_logits)
+      MT3_HIP_CHECK(hipMemcpyAsync(r.d_first_logits, e->logits, static_cast<size_t>(r.batch) * c.vocab_size * 4,
+                                   hipMemcpyDeviceToDevice, r.s));
+    if (whole && r.d_step_logits)
+      MT3_HIP_CHECK(hipMemcpyAsync(r.d_step_logits + static_cast<size_t>(t) * r.batch * c.vocab_size, e->logits,
+                                   static_cast<size_t>(r.batch) * c.vocab_size * 4, hipMemcpyDeviceToDevice, r.s));
+    if (r.early && t % 32 == 31) {
+      // the poll: how many rows of THIS group are finished (every group stops as soon as its own rows are)
+      MT3_HIP_CHECK(hipMemcpyAsync(e->h_pinned + r.slot, e->n_done + r.slot, 4, hipMemcpyDeviceToHost, r.s));
+      MT3_HIP_CHECK(hipStreamSynchronize(r.s));
+      const int live = r.rows - e->h_pinned[r.slot];
+      if (live <= 0) break;
+      if (retire) {
+        int want = (live + 31) & ~31;
+        if (want > r.rows) want = r.rows;
+        if (want < cur) {                        // the live rows fit fewer GEMM row tiles: move them to the front
+          MT3_TRY(compact_group(e, r, cur));
+          cur = want;
+          ++e->compactions_now;
+        }
+      }
+    }
+  }
+  return MT3_OK;
+}
+
+// hardware-queue streams of the row groups (see mt3_engine::part_stream); MT3_ERR_CAPACITY = could not be set up
+static int ensure_group_streams(mt3_engine* e, int groups) {
+  int n_cu = 0;
+  if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess || n_cu < 2 * groups)
+    return MT3_ERR_CAPACITY;
+  for (int g = 0; g < groups; ++g) {
+    if (e->part_stream[g]) continue;
+    // a mask of ALL compute units: the stream is created through the CU-mask entry point for the hardware queue of
+    // its own that comes with it, not to restrict it (see mt3_engine::part_stream)
+    std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+    for (int i = 0; i < n_cu; ++i) mask[i >> 5] |= 1u << (i & 31);
+    if (hipExtStreamCreateWithCUMask(&e->part_stream[g], static_cast<uint32_t>(mask.size()), mask.data()) != hipSuccess) {
+      e->part_stream[g] = nullptr;
+      (void)hipGetLastError();
       return MT3_ERR_CAPACITY;
+    }
   }
   if (!e->part_begin && hipEventCreateWithFlags(&e->part_begin, hipEventDisableTiming) != hipSuccess)
     return MT3_ERR_CAPACITY;
-  MT3_HIP_CHECK(hipEventRecord(e->part_begin, s));
-  std::vector<int> rcs(groups, MT3_OK), ran(groups, 0);
-  std::vector<std::string> errs(groups);
-  const bool early = (flags & MT3_DECODE_EARLY_EXIT) != 0;
-  auto body = [&](int g) {
-    (void)hipSetDevice(dev);
-    hipStream_t gs = e->part_stream[g];
-    int row0, rows;
-    chain_rows(batch, groups, g, &row0, &rows);
-    hipError_t he = hipStreamWaitEvent(gs, e->part_begin, 0);
-    for (int t = 0; t < num_steps && rcs[g] == MT3_OK && he == hipSuccess; ++t) {
-      rcs[g] = enqueue_chain_step(e, row0, rows, g, batch, skip, gs, g);
-      ++ran[g];
-      if (early && t % 32 == 31 && rcs[g] == MT3_OK) {      // every group stops as soon as ITS rows are finished
-        he = hipMemcpyAsync(e->h_pinned + g, e->n_done + g, 4, hipMemcpyDeviceToHost, gs);
-        if (he == hipSuccess) he = hipStreamSynchronize(gs);
-        if (he == hipSuccess && e->h_pinned[g] >= rows) break;
-      }
-    }
-    if (rcs[g] != MT3_OK) errs[g] = mt3_last_error();
-    if (he == hipSuccess) he = hipEventRecord(e->part_done[g], gs);
-    // The group's host thread WAITS for its stream.  Measured (mt3_debug_engine_decode_split, mask_mode 32 + bits; f32,
-    // B = 256, 4 groups): 1095 ms per 1024-step decode when every group stream has a host thread in
-    // hipStreamSynchronize, 1166-1170 ms when only the caller's stream (which waits for the done events) is
-    // synchronised -- a stream nobody waits on retires its commands through the runtime's interrupt path.
-    if (he == hipSuccess) he = hipStreamSynchronize(gs);
-    if (rcs[g] == MT3_OK && he != hipSuccess) {
-      rcs[g] = MT3_ERR_HIP;
-      errs[g] = hipGetErrorString(he);
-    }
-  };
-  {
-    std::vector<std::thread> th;
-    for (int g = 1; g < groups; ++g) th.emplace_back(body, g);
-    body(0);                                        // the calling thread drives group 0
-    for (std::thread& t : th) t.join();
-  }
+  return MT3_OK;
+}
+
+// Joins the decode that is in flight: waits for its workers, then (on the caller's stream) the beam-1 finalisation
+// and the copy of the ids.  Every group thread has waited for its stream, so the caller's stream needs no event.
+static int decode_finish(mt3_engine* e, int32_t* h_steps_run) {
+  PendingDecode& p = e->pending;
+  if (!p.active) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode_wait: no decode in flight");
+  for (int g = 0; g < p.posted; ++g) worker_wait(e, g);
+  p.active = false;
+  e->compactions = e->compactions_now.exchange(0);
   int most = 0;
-  for (int g = 0; g < groups; ++g) {
-    if (rcs[g] != MT3_OK) return mt3::fail(rcs[g], "mt3_engine_decode (row group " + std::to_string(g) + "): " + errs[g]);
-    MT3_HIP_CHECK(hipStreamWaitEvent(s, e->part_done[g], 0));
-    most = ran[g] > most ? ran[g] : most;
+  for (int g = 0; g < p.groups; ++g) {
+    if (p.rcs[g] != MT3_OK)
+      return mt3::fail(p.rcs[g], "mt3_engine_decode (row group " + std::to_string(g) + "): " + p.errs[g]);
+    most = p.ran[g] > most ? p.ran[g] : most;
   }
-  *steps_run = most;
+  const int L = e->cfg.max_decode_len;
+  if (p.beam1) MT3_TRY(mt3k::launch_beam1_finalize(e->ids, L, e->beam_len_row, p.batch, p.s));
+  MT3_HIP_CHECK(hipMemcpyAsync(p.d_ids, e->ids, static_cast<size_t>(p.batch) * L * 4, hipMemcpyDeviceToDevice, p.s));
+  e->last_groups = p.groups;
+  e->last_used_graph = 1;
+  for (int g = 0; g < p.groups; ++g)
+    if (!p.used_graph[g]) e->last_used_graph = 0;
+  if (h_steps_run) *h_steps_run = most;
   return MT3_OK;
 }
 
@@ -1184,17 +1454,20 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
                        const int32_t* d_forced, float* d_step_logits, int32_t* d_ids, float* d_first_logits,
                        int32_t* h_steps_run, void* stream) {
   if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: engine not finalized");
+  if (e->pending.active)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: a decode is in flight (MT3_DECODE_ASYNC): call mt3_engine_decode_wait first");
   if (batch <= 0 || batch != e->cur_batch)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: batch must equal the batch of the preceding encode");
   const mt3_engine_config& c = e->cfg;
   if (num_steps <= 0 || num_steps > c.max_decode_len || !d_ids)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: num_steps out of range or null ids");
   if (flags & ~(MT3_DECODE_NO_GRAPH | MT3_DECODE_EARLY_EXIT | MT3_DECODE_BEAM1 | MT3_DECODE_SINGLE_STREAM |
-                MT3_DECODE_CHAINS(0xF)))
+                MT3_DECODE_ASYNC | MT3_DECODE_CHAINS(0xF)))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode: unknown flag bit");
-  const bool beam1 = (flags & MT3_DECODE_BEAM1) != 0;
-  if (d_forced && (beam1 || (flags & MT3_DECODE_EARLY_EXIT)))
-    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode_forced: not combinable with BEAM1 / EARLY_EXIT");
+  const bool beam1 = (flags & MT3_DECODE_BEAM1) != 0, early = (flags & MT3_DECODE_EARLY_EXIT) != 0;
+  const bool async = (flags & MT3_DECODE_ASYNC) != 0;
+  if (d_forced && (beam1 || early || async))
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode_forced: not combinable with BEAM1 / EARLY_EXIT / ASYNC");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = c.max_decode_len;
   MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, static_cast<size_t>(batch) * 4, s));
@@ -1210,10 +1483,15 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
     MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y,
                                c.compute_dtype == MT3_BF16 ? e->y_ct : nullptr, e->y_ss, batch, c.emb_dim, rp, s));
   }
+  // Row retirement comes with the early exit: rows that have finished cost nothing from then on (mt3_hip.h).  Without
+  // EARLY_EXIT every row runs every step -- the canonical full-length schedule the headline is quoted on.
+  const bool retire = early && debug_skip == 0;
+  if (retire) MT3_TRY(mt3k::launch_iota(e->slot_row, batch, s));
 
-  // step-graph variant: bits 1 / 2 = mt3_debug_engine_decode's skipped kernels (mt3_hip_debug.h; never set by the
-  // product entry points), 4 = beam-1 selection, 8 = teacher forcing
-  const int skip = (debug_skip & 3) | (beam1 ? 4 : 0) | (d_forced ? 8 : 0);
+  // step variant: bits 1 / 2 = mt3_debug_engine_decode's skipped kernels (mt3_hip_debug.h; never set by the product
+  // entry points), then kVar*
+  const int variant = (debug_skip & 3) | (beam1 ? kVarBeam : 0) | (d_forced ? kVarForced : 0) | (retire ? kVarRetire : 0) |
+                      (e->eos_on && !d_forced ? kVarEos : 0);
   if (beam1) {
     // t5x beam_search(alpha = 0.6): live log-prob 0, nothing finished; the loop bound uses the brevity
     // penalty of max_decode_len + 1 (the dummy start token extends the length by one).  The value travels as a
@@ -1221,61 +1499,136 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
     MT3_TRY(mt3k::launch_set_float(e->beam_cfg, brevity_penalty(num_steps + 1), s));
     MT3_HIP_CHECK(hipMemsetAsync(e->beam_f, 0, static_cast<size_t>(2) * c.max_batch * 4, s));
     MT3_HIP_CHECK(hipMemsetAsync(e->beam_len, 0xFF, static_cast<size_t>(c.max_batch) * 4, s));   // -1
+    MT3_HIP_CHECK(hipMemsetAsync(e->beam_len_row, 0xFF, static_cast<size_t>(c.max_batch) * 4, s));
   }
+  if (e->group_graphs.size() > 96) drop_group_graphs(e);      // (no worker is running here)
+  PendingDecode& p = e->pending;
+  p = PendingDecode();
+  p.beam1 = beam1;
+  p.batch = batch;
+  p.d_ids = d_ids;
+  p.s = s;
+  const bool use_graph = !(flags & MT3_DECODE_NO_GRAPH);
+  const int req_chains = (flags >> 8) & 0xF;
+
   // ---- the row-group schedule (see mt3_engine::part_stream): batches of >= 128 rows, unless the caller asked for
-  // one stream / direct launches / graph chains, or wants per-step logits (those live on the caller's stream)
-  e->last_groups = 1;
-  const int groups = row_groups_for(c, batch);
-  if (groups > 1 && !(flags & (MT3_DECODE_NO_GRAPH | MT3_DECODE_SINGLE_STREAM)) && ((flags >> 8) & 0xF) == 0 &&
-      e->cfg.decode_chains <= 1 && !(c.options & MT3_OPT_NO_ROW_GROUPS) && debug_skip == 0 && !d_forced &&
-      !d_step_logits && !d_first_logits) {
-    int ran = 0;
-    const int prc = decode_partitioned(e, batch, num_steps, flags, skip, groups, &ran, s);
-    if (prc == MT3_OK) {
-      e->last_groups = groups;
-      e->last_used_graph = 0;
-      if (beam1) MT3_TRY(mt3k::launch_beam1_finalize(e->ids, L, e->beam_len, batch, s));
-      MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
-      if (h_steps_run) *h_steps_run = ran;
-      return MT3_OK;
+  // one stream / graph chains, or wants per-step logits (those live on the caller's stream)
+  int groups = row_groups_for(c, batch);
+  if (groups > 1 && !(flags & MT3_DECODE_SINGLE_STREAM) && req_chains == 0 && e->cfg.decode_chains <= 1 &&
+      !(c.options & MT3_OPT_NO_ROW_GROUPS) && debug_skip == 0 && !d_forced && !d_step_logits && !d_first_logits) {
+    if (ensure_group_streams(e, groups) == MT3_OK) {
+      MT3_HIP_CHECK(hipEventRecord(e->part_begin, s));
+      p.groups = groups;
+      p.active = true;
+      for (int g = 0; g < groups; ++g) {
+        auto body = [e, g, groups, batch, variant, num_steps, early, use_graph]() {
+          PendingDecode& q = e->pending;
+          GroupRun r{};
+          chain_rows(batch, groups, g, &r.row0, &r.rows);
+          r.batch = batch;
+          r.variant = variant;
+          r.num_steps = num_steps;
+          r.slot = g;
+          r.early = early;
+          r.use_graph = use_graph;
+          r.s = e->part_stream[g];
+          hipError_t he = hipStreamWaitEvent(r.s, e->part_begin, 0);
+          if (he == hipSuccess) {
+            q.rcs[g] = run_group(e, r);
+            if (q.rcs[g] != MT3_OK) q.errs[g] = mt3_last_error();
+          }
+          q.ran[g] = r.ran;
+          q.used_graph[g] = r.used_graph;
+          // The group's host thread WAITS for its stream.  Measured (r3, f32, B = 256, 4 groups): 1095 ms per 1024-step
+          // decode when every group stream has a host thread in hipStreamSynchronize, 1166-1170 ms when only the
+          // caller's stream (waiting for events of the groups) is synchronised -- a stream nobody waits on retires its
+          // commands through the runtime's interrupt path.
+          if (he == hipSuccess) he = hipStreamSynchronize(r.s);
+          if (q.rcs[g] == MT3_OK && he != hipSuccess) {
+            q.rcs[g] = MT3_ERR_HIP;
+            q.errs[g] = hipGetErrorString(he);
+          }
+        };
+        if (worker_post(e, g, body)) {
+          p.posted = g + 1;
+        } else {            // no thread to be had: this group runs on the calling thread (after the posted ones started)
+          body();
+        }
+      }
+      if (async) return MT3_OK;
+      return decode_finish(e, h_steps_run);
     }
-    if (prc != MT3_ERR_CAPACITY) return prc;      // a launch failed: report it
     ++e->part_failed;                             // the masked streams could not be created: single stream, recorded
   }
-  bool use_graph = !(flags & MT3_DECODE_NO_GRAPH);
-  const int chains = chains_for(e, batch, (flags >> 8) & 0xF);
-  if (use_graph && ensure_graph(e, batch, skip, chains) != MT3_OK) {
-    // direct launches give the same ids; the fallback is RECORDED (mt3_engine_status), never silent
-    use_graph = false;
-    ++e->graph_fallbacks;
-  }
-  e->last_used_graph = use_graph ? 1 : 0;
-  int ran = 0;
-  for (int t = 0; t < num_steps; ++t) {
-    if (use_graph) MT3_HIP_CHECK(hipGraphLaunch(e->graph_exec[skip][chains], s));
-    else MT3_TRY(enqueue_decode_step(e, batch, skip, chains, s));
-    ++ran;
-    if (t == 0 && d_first_logits)
-      MT3_HIP_CHECK(hipMemcpyAsync(d_first_logits, e->logits, static_cast<size_t>(batch) * c.vocab_size * 4,
-                                   hipMemcpyDeviceToDevice, s));
-    if (d_step_logits)
-      MT3_HIP_CHECK(hipMemcpyAsync(d_step_logits + static_cast<size_t>(t) * batch * c.vocab_size, e->logits,
-                                   static_cast<size_t>(batch) * c.vocab_size * 4, hipMemcpyDeviceToDevice, s));
-    if ((flags & MT3_DECODE_EARLY_EXIT) && (t % 32 == 31)) {
-      MT3_HIP_CHECK(hipMemcpyAsync(e->h_pinned, e->n_done, 4, hipMemcpyDeviceToHost, s));
-      MT3_HIP_CHECK(hipStreamSynchronize(s));
-      if (e->h_pinned[0] >= batch) break;
+  p.groups = 1;
+  const int chains = chains_for(e, batch, req_chains);
+  if (chains > 1) {
+    // the step graph with `chains` parallel branches (r1's schedule, kept for comparison): inline on the caller's stream
+    bool graph = use_graph;
+    if (graph && ensure_graph(e, batch, variant, chains) != MT3_OK) {
+      graph = false;
+      ++e->graph_fallbacks;
     }
+    p.used_graph[0] = graph;
+    int ran = 0;
+    for (int t = 0; t < num_steps; ++t) {
+      if (graph) MT3_HIP_CHECK(hipGraphLaunch(e->graph_exec[variant][chains], s));
+      else MT3_TRY(enqueue_decode_step(e, batch, variant, chains, s));
+      ++ran;
+      if (t == 0 && d_first_logits)
+        MT3_HIP_CHECK(hipMemcpyAsync(d_first_logits, e->logits, static_cast<size_t>(batch) * c.vocab_size * 4,
+                                     hipMemcpyDeviceToDevice, s));
+      if (d_step_logits)
+        MT3_HIP_CHECK(hipMemcpyAsync(d_step_logits + static_cast<size_t>(t) * batch * c.vocab_size, e->logits,
+                                     static_cast<size_t>(batch) * c.vocab_size * 4, hipMemcpyDeviceToDevice, s));
+      if (early && (t % 32 == 31)) {
+        MT3_HIP_CHECK(hipMemcpyAsync(e->h_pinned, e->n_done, 4, hipMemcpyDeviceToHost, s));
+        MT3_HIP_CHECK(hipStreamSynchronize(s));
+        if (e->h_pinned[0] >= batch) break;
+      }
+    }
+    p.ran[0] = ran;
+    p.active = true;
+    if (async) return MT3_OK;
+    return decode_finish(e, h_steps_run);
   }
-  if (beam1) MT3_TRY(mt3k::launch_beam1_finalize(e->ids, L, e->beam_len, batch, s));
-  MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
-  if (h_steps_run) *h_steps_run = ran;
-  return MT3_OK;
+  // one group = the whole batch, on the caller's stream
+  auto body = [e, batch, variant, num_steps, early, use_graph, s, d_first_logits, d_step_logits]() {
+    PendingDecode& q = e->pending;
+    GroupRun r{};
+    r.row0 = 0;
+    r.rows = r.batch = batch;
+    r.variant = variant;
+    r.num_steps = num_steps;
+    r.slot = 0;
+    r.early = early;
+    r.use_graph = use_graph;
+    r.s = s;
+    r.d_first_logits = d_first_logits;
+    r.d_step_logits = d_step_logits;
+    q.rcs[0] = run_group(e, r);
+    if (q.rcs[0] != MT3_OK) q.errs[0] = mt3_last_error();
+    q.ran[0] = r.ran;
+    q.used_graph[0] = r.used_graph;
+  };
+  p.active = true;
+  if (async && worker_post(e, 0, body)) {
+    p.posted = 1;
+    return MT3_OK;
+  }
+  body();
+  if (async) return MT3_OK;
+  return decode_finish(e, h_steps_run);
 }
 
 int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t* d_ids,
                       float* d_first_logits, int32_t* h_steps_run, void* stream) {
   return decode_impl(e, batch, num_steps, flags, 0, nullptr, nullptr, d_ids, d_first_logits, h_steps_run, stream);
+}
+
+int mt3_engine_decode_wait(mt3_engine* e, int32_t* h_steps_run) {
+  if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode_wait: engine not finalized");
+  return decode_finish(e, h_steps_run);
 }
 
 int mt3_engine_decode_forced(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags,
@@ -1289,155 +1642,25 @@ int mt3_debug_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int
                             int32_t* d_ids, void* stream) {
   if (skip & ~(MT3_DEBUG_SKIP_SELF_ATTN | MT3_DEBUG_SKIP_CROSS_ATTN))
     return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode: unknown skip bit");
+  if (flags & MT3_DECODE_ASYNC) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode: not with MT3_DECODE_ASYNC");
   return decode_impl(e, batch, num_steps, flags, skip, nullptr, nullptr, d_ids, nullptr, nullptr, stream);
 }
 
-int mt3_debug_engine_decode_split(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t n_groups, int32_t mask_mode,
-                                  int32_t* d_ids, float* h_ms, void* stream) {
-  if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: engine not finalized");
-  const mt3_engine_config& c = e->cfg;
-  if (batch <= 0 || batch != e->cur_batch || num_steps <= 0 || num_steps > c.max_decode_len || !d_ids)
-    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: bad batch / steps / ids");
-  // mask_mode 3 .. 6: interleaved masks + group g starts after a device-side delay of g x {8, 15, 25, 40} us
-  // mask_mode 7 .. 9 (two groups): OVERLAPPING masks -- each group owns 5/8, 3/4, 7/8 of the CUs (bits i % 8 < k for
-  // group 0, i % 8 >= 8 - k for group 1), the middle ones are shared
-  // mask_mode 10: every group's stream carries a FULL mask (all CUs): is it the disjoint CUs that help, or the hardware
-  // queue of its own that a masked stream gets?
-  // mask_mode 11 .. 13 = 10 with ONE property of the product path (decode_partitioned) each: 11 = group 0 is driven by
-  // the calling thread, 12 = every group counts its finished rows in a slot of its own and is bracketed by the
-  // begin / done events, 13 = the streams are created once per process and kept
-  // mask_mode 32 + bits: full masks with a COMBINATION of the product path's properties -- 1 = the caller drives group 0,
-  // 2 = own done slots + begin / done events, 4 = threads return when enqueued, 8 = (with 2 and 4) the caller's stream
-  // waits for the done events and only IT is synchronised
-  const int combo = mask_mode >= 32 && mask_mode < 48 ? mask_mode - 32 : 0;
-  if (mask_mode >= 32 && mask_mode < 48) mask_mode = 10;
-  if (n_groups < 2 || n_groups > 4 || batch / n_groups < 16 || mask_mode < 0 || mask_mode > 17 ||
-      (mask_mode > 6 && mask_mode < 10 && n_groups != 2))
-    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: 2 .. 4 groups of >= 16 rows, mask_mode 0 .. 17");
-  static const int kStagger[18] = {0, 0, 0, 8, 15, 25, 40, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  static const int kOwned[18] = {0, 0, 0, 0, 0, 0, 0, 5, 6, 7, 8, 8, 8, 8, 8, 8, 8, 8};
-  const int stagger_us = kStagger[mask_mode], owned = kOwned[mask_mode];
-  // 14 = the group threads return once their launches are ENQUEUED (the caller synchronises the streams after the
-  // join), 15 = the product's own decode_partitioned(), timed here
-  const bool caller_drives = mask_mode == 11 || (combo & 1), bracket = mask_mode == 12 || (combo & 2), keep = mask_mode == 13,
-             late_sync = mask_mode == 14 || (combo & 4), tail_on_s = (combo & 14) == 14;
-  // 16 = decode_partitioned() on FRESH streams (the engine's own set aside for the call), 17 = this function's loop on
-  // the ENGINE's streams
-  const bool product_fn = mask_mode == 15 || mask_mode == 16, fresh_for_product = mask_mode == 16;
-  const bool engine_streams = mask_mode == 17;
-  if (mask_mode > 2) mask_mode = 2;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int L = c.max_decode_len;
-  MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, static_cast<size_t>(batch) * 4, s));
-  MT3_HIP_CHECK(hipMemsetAsync(e->n_done, 0, 4, s));
-  MT3_HIP_CHECK(hipMemsetAsync(e->done, 0, static_cast<size_t>(batch) * 4, s));
-  MT3_HIP_CHECK(hipMemsetAsync(e->cur_tok, 0, static_cast<size_t>(batch) * 4, s));
-  MT3_HIP_CHECK(hipMemsetAsync(e->ids, 0, static_cast<size_t>(batch) * L * 4, s));
-  {
-    const mt3k::RowProj rp{e->ew0, e->pw0, e->qkv_fold ? e->qkvf : nullptr, 4 * e->HD()};
-    MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y,
-                               c.compute_dtype == MT3_BF16 ? e->y_ct : nullptr, e->y_ss, batch, c.emb_dim, rp, s));
-  }
-  MT3_HIP_CHECK(hipStreamSynchronize(s));
-  if (product_fn) {
-    int ran = 0;
-    hipStream_t saved[4];
-    for (int g = 0; g < 4; ++g) {
-      saved[g] = e->part_stream[g];
-      if (fresh_for_product) e->part_stream[g] = nullptr;
-    }
-    const auto p0 = std::chrono::steady_clock::now();
-    const int prc = decode_partitioned(e, batch, num_steps, 0, 0, n_groups, &ran, s);
-    (void)hipStreamSynchronize(s);
-    if (h_ms) *h_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - p0).count();
-    if (fresh_for_product)
-      for (int g = 0; g < 4; ++g) {
-        if (e->part_stream[g]) (void)hipStreamDestroy(e->part_stream[g]);
-        e->part_stream[g] = saved[g];
-      }
-    MT3_TRY(prc);
-    MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
-    MT3_HIP_CHECK(hipStreamSynchronize(s));
+int mt3_debug_engine_set_eos_schedule(mt3_engine* e, const int32_t* h_lengths, int32_t n) {
+  if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_set_eos_schedule: engine not finalized");
+  if (e->pending.active) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_set_eos_schedule: a decode is in flight");
+  if (!h_lengths) {
+    e->eos_on = false;
     return MT3_OK;
   }
-  int n_cu = 0, dev = 0;
-  MT3_HIP_CHECK(hipGetDevice(&dev));
-  MT3_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-  const int words = (n_cu + 31) / 32;
-  std::vector<hipStream_t> gs(n_groups, nullptr);
-  static hipStream_t kept[4] = {};
-  hipEvent_t ev_begin = nullptr, ev_done[4] = {};
-  if (bracket) {
-    MT3_HIP_CHECK(hipEventCreateWithFlags(&ev_begin, hipEventDisableTiming));
-    for (int g = 0; g < n_groups; ++g) MT3_HIP_CHECK(hipEventCreateWithFlags(&ev_done[g], hipEventDisableTiming));
-    MT3_HIP_CHECK(hipEventRecord(ev_begin, s));
+  if (n <= 0 || n > e->cfg.max_batch) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_set_eos_schedule: 1 .. max_batch lengths");
+  std::vector<int32_t> h(static_cast<size_t>(e->cfg.max_batch), 0x7fffffff);       // rows past n: never
+  for (int i = 0; i < n; ++i) {
+    if (h_lengths[i] < 1) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_set_eos_schedule: lengths must be >= 1");
+    h[i] = h_lengths[i];
   }
-  for (int g = 0; g < n_groups; ++g) {
-    if (engine_streams) {
-      if (!e->part_stream[g]) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_decode_split: run a product decode first");
-      gs[g] = e->part_stream[g];
-      continue;
-    }
-    if (keep && kept[g]) {
-      gs[g] = kept[g];
-      continue;
-    }
-    if (mask_mode == 0) {
-      MT3_HIP_CHECK(hipStreamCreateWithFlags(&gs[g], hipStreamNonBlocking));
-    } else {
-      std::vector<uint32_t> mask(words, 0u);
-      for (int i = 0; i < n_cu; ++i) {
-        const bool mine = owned ? (g == 0 ? i % 8 < owned : i % 8 >= 8 - owned)
-                                : mask_mode == 1 ? (i * n_groups / n_cu == g) : (i % n_groups == g);
-        if (mine) mask[i >> 5] |= 1u << (i & 31);
-      }
-      MT3_HIP_CHECK(hipExtStreamCreateWithCUMask(&gs[g], static_cast<uint32_t>(words), mask.data()));
-      if (keep) kept[g] = gs[g];
-    }
-  }
-  std::vector<int> rcs(n_groups, MT3_OK);
-  std::vector<std::string> errs(n_groups);
-  const auto t0 = std::chrono::steady_clock::now();
-  {
-    auto body = [&](int g) {
-      (void)hipSetDevice(dev);
-      int row0, rows;
-      chain_rows(batch, n_groups, g, &row0, &rows);
-      if (bracket) (void)hipStreamWaitEvent(gs[g], ev_begin, 0);
-      if (stagger_us && g) rcs[g] = mt3k::launch_delay_us(g * stagger_us, gs[g]);
-      for (int t = 0; t < num_steps && rcs[g] == MT3_OK; ++t)
-        rcs[g] = enqueue_chain_step(e, row0, rows, g, batch, 0, gs[g], bracket ? g : 0);
-      if (rcs[g] != MT3_OK) errs[g] = mt3_last_error();
-      if (bracket) (void)hipEventRecord(ev_done[g], gs[g]);
-      const hipError_t he = late_sync ? hipSuccess : hipStreamSynchronize(gs[g]);
-      if (rcs[g] == MT3_OK && he != hipSuccess) {
-        rcs[g] = MT3_ERR_HIP;
-        errs[g] = hipGetErrorString(he);
-      }
-    };
-    std::vector<std::thread> th;
-    for (int g = caller_drives ? 1 : 0; g < n_groups; ++g) th.emplace_back(body, g);
-    if (caller_drives) body(0);
-    for (std::thread& t : th) t.join();
-    if (tail_on_s) {
-      for (int g = 0; g < n_groups; ++g) (void)hipStreamWaitEvent(s, ev_done[g], 0);
-      (void)hipStreamSynchronize(s);
-    } else if (late_sync) {
-      for (hipStream_t g : gs) (void)hipStreamSynchronize(g);
-    }
-  }
-  const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (!keep && !engine_streams)
-    for (hipStream_t g : gs) (void)hipStreamDestroy(g);
-  if (bracket) {
-    (void)hipEventDestroy(ev_begin);
-    for (int g = 0; g < n_groups; ++g) (void)hipEventDestroy(ev_done[g]);
-  }
-  for (int g = 0; g < n_groups; ++g)
-    if (rcs[g] != MT3_OK) return mt3::fail(rcs[g], "mt3_debug_engine_decode_split: group " + std::to_string(g) + ": " + errs[g]);
-  if (h_ms) *h_ms = ms;
-  MT3_HIP_CHECK(hipMemcpyAsync(d_ids, e->ids, static_cast<size_t>(batch) * L * 4, hipMemcpyDeviceToDevice, s));
-  MT3_HIP_CHECK(hipStreamSynchronize(s));
+  MT3_HIP_CHECK(hipMemcpy(e->eos_at, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+  e->eos_on = true;
   return MT3_OK;
 }
 
@@ -1462,7 +1685,7 @@ int mt3_debug_engine_poison_caches(mt3_engine* e, int32_t pattern, int32_t cross
 int mt3_engine_status(const mt3_engine* e, int32_t what) {
   if (!e) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_status: null engine");
   switch (what) {
-    case MT3_STATUS_GRAPH_FALLBACKS: return e->graph_fallbacks;
+    case MT3_STATUS_GRAPH_FALLBACKS: return e->graph_fallbacks.load();
     case MT3_STATUS_LAST_DECODE_USED_GRAPH: return e->last_used_graph;
     case MT3_STATUS_RESIDUAL_SPLIT: return e->y_split ? 1 : 0;
     case MT3_STATUS_KV_FP8: return e->kv_fp8 ? 1 : 0;
@@ -1471,6 +1694,7 @@ int mt3_engine_status(const mt3_engine* e, int32_t what) {
     case MT3_STATUS_QKV_FOLD: return e->qkv_fold ? 1 : 0;
     case MT3_STATUS_LAST_DECODE_GROUPS: return e->last_groups;
     case MT3_STATUS_PARTITION_FALLBACKS: return e->part_failed;
+    case MT3_STATUS_LAST_DECODE_COMPACTIONS: return e->compactions;
     default: return mt3::fail(MT3_ERR_INVALID, "mt3_engine_status: unknown item");
   }
 }

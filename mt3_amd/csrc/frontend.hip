@@ -28,7 +28,6 @@
 #include "common.h"
 #include "frontend_core.h"
 #include "frontend_tables.h"
-#include "knobs.h"
 #include "mt3_hip.h"
 
 namespace {
@@ -270,12 +269,10 @@ static int launch_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segme
                 static_cast<const cpx*>(fe->d_tw2048), static_cast<const int*>(fe->d_k0),
                 static_cast<const int*>(fe->d_cnt),    static_cast<const int*>(fe->d_off),
                 static_cast<const float*>(fe->d_w), static_cast<int>(fe->host.w.size())};
-  if (frames_per_segment % 32 == 0 && mt3k::g_knobs.frontend_32_frame_tiles)
-    hipLaunchKernelGGL(logmel_kernel<8>, dim3(n_segments * (frames_per_segment / 32)), dim3(512), 0, s, t, d_audio, d_n,
-                       frames_per_segment, d_logmel);
-  else
-    hipLaunchKernelGGL(logmel_kernel<4>, dim3(n_segments * (frames_per_segment / 16)), dim3(256), 0, s, t, d_audio, d_n,
-                       frames_per_segment, d_logmel);
+  // 16-frame tiles, four waves (r3 also measured 32-frame tiles on eight waves: HBM traffic 1.178 -> 1.091 x the
+  // algorithmic bytes, but 17-19 % slower -- one 135 KB workgroup per CU)
+  hipLaunchKernelGGL(logmel_kernel<4>, dim3(n_segments * (frames_per_segment / 16)), dim3(256), 0, s, t, d_audio, d_n,
+                     frames_per_segment, d_logmel);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

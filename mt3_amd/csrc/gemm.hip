@@ -300,20 +300,13 @@ __device__ __forceinline__ void gemm_epilogue(const f32x4 (&acc)[FM][FN], int wm
   }
 }
 
-// WK > 1: the K-groups of every slice are dealt to WK wave groups (split-K inside the workgroup; partial accumulators
-// meet in LDS).  For the decode-sized f32 tiles: a wave's 16x16 fragment over K = 512 is 128 dependent
-// v_mfma_f32_16x16x4_f32 = 1.7 us of matrix-pipe time on ONE of the CU's four SIMDs while the launch has fewer waves
-// than the chip has SIMDs -- eight waves per tile halve that chain.
-// PF = 2: TWO K slices in flight (a second set of staging registers): the loads of slice t + 2 are issued while slice t
-// is multiplied, and the first two slices are requested back to back at kernel entry -- a latency-bound tile with K in
-// 2 .. 4 slices (f32 operands: K = 512 / 1024; bf16: K = 1024 / 2048) pays one dependent memory round trip less per
-// pair of slices.
-template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8, int WK = 1,
-          int PF = 1>
-__global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
-  static_assert(PF == 1 || PF == 2, "prefetch depth");
-  constexpr int NT = WM * WN * WK * 64;
-  static_assert(WK == 1 || (!NORM && (BK / CTraits<CT>::KGROUP) % WK == 0), "split-K: norm-free tiles, K-groups divisible");
+// (Measured in round 3 and removed in round 4, DESIGN.md section 3: eight waves per f32 tile with the K-groups of a
+// slice split two ways -- 1 % slower, the extra LDS round and two barriers cost what the halved MFMA chain saves; two K
+// slices in flight on a second set of staging registers -- 4-16 % slower, the second slice queues up in the same CU's
+// L1 path in front of the first slice's last lines.)
+template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
+  constexpr int NT = WM * WN * 64;
   constexpr int KPL = CTraits<CT>::KPL;
   constexpr int KG = CTraits<CT>::KGROUP;
   constexpr int CPR = BK / KPL;          // 16-byte chunks per tile row
@@ -349,8 +342,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
 
   MT3_PROF_MARK(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wk = wave / (WM * WN), wmn = wave % (WM * WN);
-  const int wm = wmn / WN, wn = wmn % WN;
+  const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = gN / BN;
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
@@ -383,7 +375,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
   const int gLda2 = g.lda2, k1 = g.k_split;
   float xpre[FM][FN][4];
   const float* const gResidSrc = g.resid_src ? g.resid_src : static_cast<const float*>(gO);
-  if constexpr (kPre) if (wk == 0 && !(EPI == kEpiResidS && second)) {
+  if constexpr (kPre) if (!(EPI == kEpiResidS && second)) {
     const float* src = gResidSrc;
     int ld = gLdo, c0 = n0;
     if constexpr (EPI == kEpiResidQ) {
@@ -403,7 +395,7 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
           xpre[i][j][r] = src[static_cast<size_t>(row < gM ? row : gM - 1) * ld + c0 + wn * FN * 16 + j * 16 + (lane & 15)];
         }
   }
-  u32x4 a_reg[PF][A_PASSES], b_reg[PF][B_PASSES];
+  u32x4 a_reg[A_PASSES], b_reg[B_PASSES];
   float ss[A_PASSES];
 #pragma unroll
   for (int p = 0; p < A_PASSES; ++p) ss[p] = 0.f;
@@ -418,12 +410,8 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
   const CT* a_base = &As[(wm * FM * 16 + frag_row) * ROWE + frag_g * KPL];
   const CT* b_base = &Bs[(wn * FN * 16 + frag_row) * ROWE + frag_g * KPL];
 
-  gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg[0], b_reg[0], ss, gA, gW, m0, n0, tid, gM, gLda, gK, 0,
+  gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg, b_reg, ss, gA, gW, m0, n0, tid, gM, gLda, gK, 0,
                                                                 gA2, gLda2, k1);
-  if constexpr (PF == 2)
-    if (BK < kend)
-      gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg[1], b_reg[1], ss, gA, gW, m0, n0, tid, gM, gLda,
-                                                                    gK, BK, gA2, gLda2, k1);
   if constexpr (!NORM) {
     if (scale_rows) {
       float t = 0.f;
@@ -432,32 +420,29 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
       rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);                               // read after the K loop's barriers
     }
   }
-  // one K slice: staging registers of `slot` -> LDS, refill the slot with slice k0 + PF * BK, multiply
-  auto slice = [&](auto slot_c, int k0) {
-    constexpr int SLOT = decltype(slot_c)::value;
+  // one K slice: staging registers -> LDS, refill them with slice k0 + BK, multiply
+  for (int k0 = 0; k0 < kend; k0 += BK) {
     __syncthreads();                    // every wave is done reading the previous tile
     MT3_PROF_MARK(1);
 #pragma unroll
     for (int p = 0; p < A_PASSES; ++p) {
       int r, ch;
       tile_chunk<CPR, NT>(tid, p, &r, &ch);
-      *reinterpret_cast<u32x4*>(&As[r * ROWE + ch * KPL]) = a_reg[SLOT][p];
+      *reinterpret_cast<u32x4*>(&As[r * ROWE + ch * KPL]) = a_reg[p];
     }
 #pragma unroll
     for (int p = 0; p < B_PASSES; ++p) {
       int r, ch;
       tile_chunk<CPR, NT>(tid, p, &r, &ch);
-      *reinterpret_cast<u32x4*>(&Bs[r * ROWE + ch * KPL]) = b_reg[SLOT][p];
+      *reinterpret_cast<u32x4*>(&Bs[r * ROWE + ch * KPL]) = b_reg[p];
     }
     __syncthreads();
     MT3_PROF_MARK(2);
-    if (k0 + PF * BK < kend)            // a later slice in flight while the MFMAs below run
-      gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg[SLOT], b_reg[SLOT], ss, gA, gW, m0, n0, tid, gM,
-                                                                    gLda, gK, k0 + PF * BK, gA2, gLda2, k1);
-    constexpr int KSTEPS = BK / KG / WK;
+    if (k0 + BK < kend)                 // the next slice in flight while the MFMAs below run
+      gemm_load_tiles<CT, A_F32, NORM, A_PASSES, B_PASSES, CPR, NT>(a_reg, b_reg, ss, gA, gW, m0, n0, tid, gM, gLda, gK,
+                                                                    k0 + BK, gA2, gLda2, k1);
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int kk = wk * KSTEPS + ks;
+    for (int kk = 0; kk < BK / KG; ++kk) {
       u32x4 af[FM], bf[FN];
 #pragma unroll
       for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const u32x4*>(a_base + i * 16 * ROWE + kk * KG);
@@ -468,42 +453,8 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) mfma_chunk<CT>(af[i], bf[j], acc[i][j]);
     }
-  };
-  if constexpr (PF == 1) {
-    for (int k0 = 0; k0 < kend; k0 += BK) slice(std::integral_constant<int, 0>{}, k0);
-  } else {
-    for (int k0 = 0; k0 < kend; k0 += 2 * BK) {
-      slice(std::integral_constant<int, 0>{}, k0);
-      if (k0 + BK < kend) slice(std::integral_constant<int, 1>{}, k0 + BK);
-    }
   }
   MT3_PROF_MARK(3);
-  if constexpr (WK > 1) {
-    // the wave groups' partial accumulators meet in the (now idle) A tile; group 0 carries on alone
-    static_assert(sizeof(CT) * BM * ROWE >= sizeof(float) * (WK - 1) * WM * WN * FM * FN * 256, "split-K scratch");
-    float* red = reinterpret_cast<float*>(As);
-    __syncthreads();
-    if (wk > 0) {
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            red[(((wk - 1) * WM * WN + wmn) * FM * FN + i * FN + j) * 256 + r * 64 + lane] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (wk > 0) return;
-#pragma unroll
-    for (int q = 1; q < WK; ++q)
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc[i][j][r] += red[(((q - 1) * WM * WN + wmn) * FM * FN + i * FN + j) * 256 + r * 64 + lane];
-  }
 
   if constexpr (NORM) {
     // Each tile row was streamed by CPR consecutive lanes.  Their partial sums of squares meet on the DPP
@@ -553,10 +504,10 @@ __global__ __launch_bounds__(WM* WN* WK * 64) void gemm_kernel(GemmArgs g) {
 // BM_ = 256 (round 3; STORE / GEGLU / HEADS epilogues): a wave owns 128 x 64 outputs (8 x 4 fragments), so a K slice costs
 // 12 fragment reads for 32 MFMAs instead of 8 for 16 and the A panel is shared by twice the rows: the 128 x 128 tile's
 // K loop alone ran at 55 % of the matrix peak with LDS reads and MFMAs both at ~100 % of their own pipes.
-// DB (round 3 experiment, 128-row tile): FOUR ring stages and two sets of fragment registers -- the fragment reads of slice
-// t + 1 are issued before the MFMAs of slice t (slice t + 1 must have landed at iteration t's barrier, so three slices
-// are in flight instead of two and the ring grows to 64 KB: two workgroups per CU instead of three).
-template <int EPI, int NPV, int BM_ = 128, bool DB = false>
+// (Round 3 also built fragment double-buffering for the 128-row tile -- four ring stages, the fragment reads of slice
+// t + 1 issued before the MFMAs of slice t: 64 KB of ring and 180 VGPRs leave two workgroups per CU instead of three and
+// the encoder ran 6.17 against 5.34 ms; removed in round 4)
+template <int EPI, int NPV, int BM_ = 128>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   using CT = __bf16;
   constexpr int BM = BM_, BN = 128, BK = MT3_GLDS_BK, FM = BM / 32, FN = 4;
@@ -566,8 +517,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
   constexpr int RPP = 64 / CPROW;                    // rows per 1 KB DMA piece: 16 or 8
   constexpr int KSH = BK == 32 ? 2 : 1;              // swizzle key of row r: (r >> KSH) & (CPROW - 1)
   constexpr int STAGE_B = (BM + BN) * ROWB;          // 16 / 32 KB per stage: A rows, then W rows
-  constexpr int NS = DB ? 4 : MT3_GLDS_NS, DEPTH = NS - 1;    // ring stages / K slices in flight
-  static_assert(!DB || (BM_ == 128 && MT3_GLDS_BK == 32 && !MT3_GLDS_PROBE), "fragment double-buffering: 128-row tile");
+  constexpr int NS = MT3_GLDS_NS, DEPTH = NS - 1;    // ring stages / K slices in flight
   constexpr int PPW = (BM + BN) / RPP / 4;           // 1 KB pieces per wave per stage: 4 (8 with 128-byte rows), 6 at BM = 256
   static_assert(BK == 32 || BK == 64, "K slice");
   // ONE shared object (a second one makes hipcc drain the DMA queue before every k-step's first ds_read)
@@ -643,46 +593,6 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs g) {
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d)
     if (d < KT) issue(d, d);
-  if constexpr (DB) {
-    static_assert(!DB || PPW == 4, "vmcnt immediates below");
-    u32x4 af[2][FM], bf[2][FN];
-    const int so = (frag_g ^ key) * 16;
-    auto read_frags = [&](auto set_c, int t) {
-      constexpr int SET = decltype(set_c)::value;
-      const unsigned char* st = smem + (t % NS) * STAGE_B;
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[SET][i] = *reinterpret_cast<const u32x4*>(st + a_off + i * 16 * ROWB + so);
-#pragma unroll
-      for (int j = 0; j < FN; ++j) bf[SET][j] = *reinterpret_cast<const u32x4*>(st + b_off + j * 16 * ROWB + so);
-    };
-    // slice 0 landed (at most the two younger slices outstanding), then its fragments
-    if (KT >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (KT == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_frags(std::integral_constant<int, 0>{}, 0);
-    auto step = [&](auto set_c, int t) {
-      constexpr int SET = decltype(set_c)::value;
-      // slice t + 1 landed: only slice t + 2 (if it exists) may still be in flight
-      if (t + 2 <= KT - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      // after this barrier: every wave's pieces of slice t + 1 are in LDS, and every wave has issued the MFMAs of
-      // slice t - 1, i.e. its reads of stage (t - 1) % NS have returned -- the stage slice t + DEPTH goes to
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      if (t + DEPTH < KT) issue(t + DEPTH, (t + DEPTH) % NS);
-      if (t + 1 < KT) read_frags(std::integral_constant<int, 1 - SET>{}, t + 1);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) mfma_chunk<CT>(af[SET][i], bf[SET][j], acc[i][j]);
-    };
-    for (int t = 0; t < KT; t += 2) {
-      step(std::integral_constant<int, 0>{}, t);
-      if (t + 1 < KT) step(std::integral_constant<int, 1>{}, t + 1);
-    }
-  } else
   for (int t = 0; t < KT; ++t) {
     // slice t has landed once at most the (<= DEPTH - 1) younger slices' DMAs of this wave are still outstanding
     const int ahead = KT - 1 - t < DEPTH - 1 ? KT - 1 - t : DEPTH - 1;
@@ -848,7 +758,7 @@ static int launch_glds(const GemmArgs& g, hipStream_t s) {
     // B = 256 the tall tile is 5-9 % faster per launch (GEGLU 243 against 260 us, QKV 139 against 153), at B = 64
     // (1.1 rounds of tall tiles) 1 % slower
     const int grid256 = ((g.M + 255) / 256) * (g.N / 128);
-    if (!g_knobs.no_glds_256 && !g_knobs.glds_frag_db && grid256 >= 1024) {
+    if (grid256 >= 1024) {
       if (g.a_ss && g.K > 512)
         hipLaunchKernelGGL((gemm_glds_kernel<EPI, 16, 256>), dim3(grid256), dim3(256), 0, s, g);
       else
@@ -858,16 +768,6 @@ static int launch_glds(const GemmArgs& g, hipStream_t s) {
     }
   }
   const int grid = ((g.M + 127) / 128) * (g.N / 128);
-  if constexpr (MT3_GLDS_BK == 32 && !MT3_GLDS_PROBE) {
-    if (g_knobs.glds_frag_db) {      // experiment: fragment double-buffering on a four-stage ring
-      if (g.a_ss && g.K > 512)
-        hipLaunchKernelGGL((gemm_glds_kernel<EPI, 16, 128, true>), dim3(grid), dim3(256), 0, s, g);
-      else
-        hipLaunchKernelGGL((gemm_glds_kernel<EPI, 8, 128, true>), dim3(grid), dim3(256), 0, s, g);
-      MT3_HIP_CHECK(hipGetLastError());
-      return MT3_OK;
-    }
-  }
   if (g.a_ss && g.K > 512)
     hipLaunchKernelGGL((gemm_glds_kernel<EPI, 16>), dim3(grid), dim3(256), 0, s, g);
   else
@@ -877,21 +777,19 @@ static int launch_glds(const GemmArgs& g, hipStream_t s) {
 }
 // big tile, bf16, both operands bf16 in memory, K a multiple of 64 (<= 1024 with norm 2), N of 128
 static bool glds_eligible(const GemmArgs& g, bool a_f32, int norm, int epi) {
-  if (g_knobs.no_lds_dma_gemm || a_f32 || norm == 1 || g.K % 64 || g.N % 128 || g.lda % 8) return false;   // (K % 64: norm-2 partials)
+  if (a_f32 || norm == 1 || g.K % 64 || g.N % 128 || g.lda % 8) return false;   // (K % 64: norm-2 partials)
   if (norm == 2 && (!g.a_ss || g.K > 1024)) return false;
   return epi == MT3_EPI_STORE || epi == MT3_EPI_RESID || epi == MT3_EPI_GEGLU || epi == MT3_EPI_HEADS ||
          epi == MT3_EPI_F32;
 }
 
 // ------------------------------------------------------------------ dispatch
-template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8, int WK = 1,
-          int PF = 1>
+template <typename CT, int BM, int BN, int BK, int WM, int WN, bool A_F32, bool NORM, int EPI, int NPV = 8>
 static int launch_cfg(const GemmArgs& g, hipStream_t s) {
   if (g.N % BN != 0 || g.K % BK != 0) return mt3::fail(MT3_ERR_INVALID, "gemm: N/K not a multiple of the tile");
   if (g.a_ss && g.K > 64 * NPV) return mt3::fail(MT3_ERR_INVALID, "gemm: K too large for this tile's partial-sum registers");
   const int grid = ((g.M + BM - 1) / BM) * (g.N / BN);
-  hipLaunchKernelGGL((gemm_kernel<CT, BM, BN, BK, WM, WN, A_F32, NORM, EPI, NPV, WK, PF>), dim3(grid),
-                     dim3(WM * WN * WK * 64), 0, s, g);
+  hipLaunchKernelGGL((gemm_kernel<CT, BM, BN, BK, WM, WN, A_F32, NORM, EPI, NPV>), dim3(grid), dim3(WM * WN * 64), 0, s, g);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }
@@ -903,14 +801,10 @@ static int launch_cfg(const GemmArgs& g, hipStream_t s) {
 //         >= 100 workgroups on the chip, and the K step is as deep as LDS allows (16 K-groups = 512 bf16
 //         elements: K = 512 in ONE slice) so that every global load of the block is in flight at once
 //         instead of 8-16 dependent load->barrier->MFMA rounds.
-// decode-sized tile BMxBN with K slice BK.  Two slices in flight (PF = 2) is an opt-in debug knob: measured on MI355X
-// at B = 256 it is SLOWER than one (bf16 decode without attention 191 -> 199.5 us per step, f32 358 -> 415): the second
-// slice's 64-128 KB per workgroup queue up in the same CU's 64 B/clk L1 path in front of the first slice's
-// last lines, so the first multiply starts later and the second gains less than that
-template <typename CT, int BM, int BN, int BK, bool A_F32, bool NORM, int EPI, int NPV = 8, int WK = 1>
+// decode-sized tile BMxBN with K slice BK
+template <typename CT, int BM, int BN, int BK, bool A_F32, bool NORM, int EPI, int NPV = 8>
 static int launch_small(const GemmArgs& g, hipStream_t s) {
-  if (g.K > BK && g_knobs.prefetch2) return launch_cfg<CT, BM, BN, BK, 2, 2, A_F32, NORM, EPI, NPV, WK, 2>(g, s);
-  return launch_cfg<CT, BM, BN, BK, 2, 2, A_F32, NORM, EPI, NPV, WK, 1>(g, s);
+  return launch_cfg<CT, BM, BN, BK, 2, 2, A_F32, NORM, EPI, NPV>(g, s);
 }
 
 template <typename CT, bool A_F32, bool NORM, int EPI>
@@ -918,25 +812,8 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
   constexpr int KG = CTraits<CT>::KGROUP;
   if (small) {
     const bool deep = g.K % (16 * KG) == 0;
-    if constexpr (EPI == kEpiResidS) {
-      // the two-source fold launch (N = emb + 4 HD = 2048 columns, K up to 1536) on 32 x 64 tiles (25 % fewer operand
-      // bytes through each CU's L1, but 101 KB of LDS = one workgroup per CU): opt-in debug knob, measured SLOWER than the
-      // 32 x 32 tiles at two per CU (bf16 632.5 against 629.4 ms per decode, f32 1181.7 against 1164.0)
-      if (deep && g.N % 64 == 0 && g.n_split % 64 == 0 && g_knobs.fold_wide_tile)
-        return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI>(g, s);
-    }
-    if constexpr (!NORM && !A_F32 && KG == 16 && EPI != MT3_EPI_HEADS && EPI != MT3_EPI_POS) {
-      // f32 operands arriving in the compute type (the split residual form / plain activations): eight waves per
-      // tile, K-groups split two ways (see gemm_kernel; halves the staging registers per thread as well)
-      if (g_knobs.f32_split_k) {          // opt-in: measured 1 % SLOWER than four waves (1163 vs 1151 ms per decode)
-        if constexpr (EPI == MT3_EPI_GEGLU) {
-          if (deep) return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI, 8, 2>(g, s);
-        } else {
-          if (g.K == 24 * KG) return launch_small<CT, 32, 32, 12 * KG, A_F32, NORM, EPI, 8, 2>(g, s);
-          if (deep) return launch_small<CT, 32, 32, 16 * KG, A_F32, NORM, EPI, 8, 2>(g, s);
-        }
-      }
-    }
+    // (measured and removed, DESIGN.md section 3: the two-source fold launch on 32 x 64 tiles -- 25 % fewer operand
+    // bytes through a CU's L1 but one workgroup per CU, slower; eight-wave split-K f32 tiles, slower)
     if constexpr (!NORM && !A_F32 && KG == 32 && EPI != MT3_EPI_HEADS && EPI != MT3_EPI_POS) {
       // ismir2022/base.gin shape (emb = heads * 64 = 768): K = 768 as ONE slice too, with room for its 48 partial
       // sums of squares when the rows arrive as the bf16 residual copy (norm 2)
@@ -945,23 +822,17 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
         // -- QKV N = 3072: 768, GEGLU N = 4096: 512 -- would run in rounds; those take K in two slices of 384 instead,
         // 51 / 75 KB, three / two workgroups per CU, one round)
         if constexpr (EPI == MT3_EPI_GEGLU) {
-          if (((g.M + 31) / 32) * (g.N / 64) > 256 && !g_knobs.no_k768_split)
+          if (((g.M + 31) / 32) * (g.N / 64) > 256)
             return launch_cfg<CT, 32, 64, 12 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
           return launch_cfg<CT, 32, 64, 24 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
         } else {
-          if (((g.M + 31) / 32) * (g.N / 32) > 256 && !g_knobs.no_k768_split)
+          if (((g.M + 31) / 32) * (g.N / 32) > 256)
             return launch_cfg<CT, 32, 32, 12 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
           return launch_cfg<CT, 32, 32, 24 * KG, 2, 2, A_F32, NORM, EPI, 16>(g, s);
         }
       }
     }
     if constexpr (EPI == MT3_EPI_GEGLU) {
-      if constexpr (!NORM && !A_F32 && KG == 32) {
-        // experiment (debug knob): 32 x 32 GEGLU tiles of two waves (gate | linear fragment pair per wave), 67.6 KB of
-        // LDS = two workgroups per CU instead of one 32 x 64 tile of 101 KB
-        if (deep && g.K == 16 * KG && g_knobs.geglu_narrow_tile)
-          return launch_cfg<CT, 32, 32, 16 * KG, 2, 1, A_F32, NORM, EPI>(g, s);
-      }
       if (deep) return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 64, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
     } else {
@@ -1065,7 +936,7 @@ int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, int norm, int epi, boo
   // shape, f32 operands) dealing by column slice keeps an eighth of it there instead (measured: base.gin decode
   // without attention 644 -> 603 us per step; MT3 shape bf16, weights <= 2 MB: 198 -> 203, hence the threshold)
   const size_t w_bytes = static_cast<size_t>(g.N) * g.K * (dtype == MT3_BF16 ? 2 : 4);
-  gg.n_major = small && (g_knobs.xcd_n_major == 1 || (g_knobs.xcd_n_major == 0 && w_bytes > (3u << 20))) ? 1 : 0;
+  gg.n_major = small && w_bytes > (3u << 20) ? 1 : 0;
   if (dtype == MT3_BF16) return launch_typed<__bf16>(gg, a_f32, norm, epi, small, s);
   if (dtype == MT3_F32) return launch_typed<float>(gg, a_f32, norm, epi, small, s);
   return mt3::fail(MT3_ERR_INVALID, "gemm: unknown dtype");

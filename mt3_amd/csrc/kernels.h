@@ -5,7 +5,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "knobs.h"
 #include "mt3_hip.h"
 
 namespace mt3k {
@@ -74,6 +73,12 @@ struct DecAttnArgs {
   const float* q_f32;
   const float* q_ss;
   int q_ss_n;
+  // Row retirement (mt3_engine_decode with MT3_DECODE_EARLY_EXIT): `done` [B] per SLOT -- a workgroup whose slot has
+  // finished (EOS emitted / beam search closed) returns before it requests a single cache byte; `cache_row` [B] maps a
+  // slot to the row of kcache / vcache / kv_scale it owns (the live slots are compacted to the front of the batch while
+  // the caches stay where they are).  Both nullptr: slot b = row b, every row is attended (the canonical schedule).
+  const int* done;
+  const int* cache_row;
 };
 // bf16 K rows then V rows ([2][rows][64]) -> e4m3 [2][rows][64] + float2 scales [rows]
 int launch_kv_quantize_fp8(const void* src_bf16, void* dst_fp8, void* scales, int rows, hipStream_t s);
@@ -113,15 +118,59 @@ struct BeamState {
   int* len;
   const float* cfg;
   int rows;
+  // a copy of `len` indexed by the ROW a slot decodes (what the finalisation reads once the loop is over: under row
+  // retirement the slot-indexed state of a finished row is gone by then); the base of the step's rows, or -- with a
+  // slot map -- of the whole batch
+  int* len_row;
+};
+// Row retirement and the synthetic EOS schedule of one step (all nullptr / 0: the canonical schedule).
+//   retire  : a block whose slot is already done returns at once (its ids stay 0, its position counter stops)
+//   slot_row: [B] slot -> row of `ids` / `eos_at` (nullptr: identity); with it `ids` is the UN-offset base of the batch
+//   eos_at  : [rows] bench / test hook (mt3_debug_engine_set_eos_schedule): row r's distribution at step eos_at[r] - 1
+//             is replaced by a point mass on EOS -- greedy emits EOS there, the beam-1 search finishes prefix + EOS with
+//             log-prob 0 and closes (its live hypothesis drops to -inf)
+struct StepRetire {
+  int retire;
+  const int* slot_row;
+  const int* eos_at;
 };
 // token pick + bookkeeping for one decode step (see decode_ops.hip); beam == nullptr: greedy;
 // forced != nullptr (greedy only): teacher forcing, the next input token is forced[b * forced_stride + t]
 int launch_argmax_step(float* logits, int vocab, int* ids, int ids_stride, int* cur_tok, int* done,
                        int* n_done, int* step, const float* table, const float* pos_table, int max_pos,
                        float* y_next, void* y_ct, float* y_ss, int dim, int B, const BeamState* beam,
-                       const int* forced, int forced_stride, const RowProj& rp, const LogitScale& ls, hipStream_t s);
+                       const int* forced, int forced_stride, const RowProj& rp, const LogitScale& ls,
+                       const StepRetire& rt, hipStream_t s);
+// Compaction of the live slots of one row group to the front of the group (row retirement): the per-slot state that
+// lives from one step to the next -- the next step's input row in its three forms, layer 0's projected row, position
+// counter, current token, beam-search state, the slot -> row map -- moves from slot perm[i] to slot i (i < n_live) by
+// way of a scratch copy; slots [n_live, rows) are marked done.  All pointers are those of the group's first slot.
+struct CompactArgs {
+  int* done;
+  int* slot_row;
+  int* step;
+  int* cur_tok;
+  float* beam_f;        // [2][beam_rows] (nullptr: greedy)
+  int* beam_len;
+  int beam_rows;
+  float* y;             // [rows][emb] f32 input rows of the next step
+  void* y_ct;           // bf16 copy (nullptr: f32 engine)
+  float* y_ss;          // [rows][emb / 16] (nullptr: single residual stream)
+  float* qkvf;          // [rows][q_n] (nullptr: no qkv-fold)
+  int emb, q_n;
+  // scratch of the same shapes (slot-indexed from the group's first slot as well)
+  float* s_y;
+  void* s_y_ct;
+  float* s_y_ss;
+  float* s_qkvf;
+  int* s_int;           // [rows][4]: slot_row, step, cur_tok, beam_len
+  float* s_beam;        // [rows][2]
+  int* perm;            // [rows + 1]: perm[i] = source slot of new slot i; perm[rows] = n_live
+  int rows;             // slots of the group in use before the compaction
+};
+int launch_compact(const CompactArgs& c, hipStream_t s);
+int launch_iota(int* dst, int n, hipStream_t s);
 int launch_set_float(float* dst, float v, hipStream_t s);
-int launch_delay_us(int us, hipStream_t s);
 int launch_beam1_finalize(int* ids, int L, const int* beam_len, int B, hipStream_t s);
 int launch_ids_to_tokens(const int* ids, int B, int L, int num_regular, int* out, hipStream_t s);
 

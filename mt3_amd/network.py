@@ -202,11 +202,15 @@ class Transformer:
         return enc
 
     def decode(self, num_steps: Optional[int] = None, use_graph: bool = True, early_exit: bool = False,
-               return_first_logits: bool = False, chains: int = 0, beam1: bool = False, single_stream: bool = False):
+               return_first_logits: bool = False, chains: int = 0, beam1: bool = False, single_stream: bool = False,
+               wait: bool = True):
         """Decode for the batch of the last `encode`: greedy until EOS, or with `beam1` the selection
         rule of t5x beam_search(num_decodes=1, alpha=0.6) that the reference's predict_tokens runs.
-        Returns int32 CUDA [B, L] ids (and the step-0 logits [B, V] if asked).  Batches of >= 128 rows run
-        decoded as 2 or 4 row groups on streams with hardware queues of their own (include/mt3_hip.h) unless `single_stream`."""
+        Returns int32 CUDA [B, L] ids (and the step-0 logits [B, V] if asked).  Batches of >= 128 rows are
+        decoded as 2 or 4 row groups on streams with hardware queues of their own (include/mt3_hip.h) unless `single_stream`.
+        early_exit: stop when every row has finished, and RETIRE finished rows meanwhile (no K/V is streamed for them, the
+        live rows are compacted; ids up to each row's EOS are unchanged).  wait=False: MT3_DECODE_ASYNC -- the call returns
+        once the engine's worker threads have the decode; `decode_wait()` joins it and returns the ids."""
         import torch
         B, L = self._batch, self.max_decode_length
         ids = torch.empty((B, L), device="cuda", dtype=torch.int32)
@@ -214,13 +218,34 @@ class Transformer:
             if return_first_logits else None
         flags = (0 if use_graph else _lib.DECODE_NO_GRAPH) | (_lib.DECODE_EARLY_EXIT if early_exit else 0) | \
             ((chains & 0xF) << 8) | (_lib.DECODE_BEAM1 if beam1 else 0) | \
-            (_lib.DECODE_SINGLE_STREAM if single_stream else 0)
+            (_lib.DECODE_SINGLE_STREAM if single_stream else 0) | (0 if wait else _lib.DECODE_ASYNC)
         ran = C.c_int32()
         _lib.check(self._lib.mt3_engine_decode(self._h, B, num_steps or L, flags, ids.data_ptr(),
                                                logits.data_ptr() if logits is not None else None, C.byref(ran),
                                                torch.cuda.current_stream().cuda_stream))
+        if not wait:
+            self._async = (ids, logits)              # kept alive until decode_wait
+            return None
         self.steps_run = ran.value
         return (ids, logits) if return_first_logits else ids
+
+    def decode_wait(self):
+        """mt3_engine_decode_wait: join the decode a `decode(wait=False)` started; returns what that call would have."""
+        ran = C.c_int32()
+        _lib.check(self._lib.mt3_engine_decode_wait(self._h, C.byref(ran)))
+        ids, logits = self._async
+        self._async = None
+        self.steps_run = ran.value
+        return (ids, logits) if logits is not None else ids
+
+    def debug_set_eos_schedule(self, lengths=None):
+        """mt3_debug_engine_set_eos_schedule (include/mt3_hip_debug.h): impose output lengths -- row r's distribution at
+        step lengths[r] - 1 becomes a point mass on EOS (SURVEY.md 8(d)'s synthetic EOS schedule).  None: off."""
+        if lengths is None:
+            _lib.check(self._lib.mt3_debug_engine_set_eos_schedule(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(lengths, dtype=np.int32)
+        _lib.check(self._lib.mt3_debug_engine_set_eos_schedule(self._h, a.ctypes.data, int(a.size)))
 
     def debug_decode(self, num_steps: Optional[int] = None, skip_self_attn: bool = False,
                      skip_cross_attn: bool = False, chains: int = 0, use_graph: bool = True):
@@ -234,17 +259,6 @@ class Transformer:
         _lib.check(self._lib.mt3_debug_engine_decode(self._h, B, num_steps or L, flags, skip, ids.data_ptr(),
                                                      torch.cuda.current_stream().cuda_stream))
         return ids
-
-    def debug_decode_split(self, num_steps: Optional[int] = None, groups: int = 2, mask_mode: int = 1):
-        """mt3_debug_engine_decode_split: the row-group overlap experiment (one host thread and one
-        CU-masked stream per row group, direct launches).  Returns (ids, wall ms of the decode loop)."""
-        import torch
-        B, L = self._batch, self.max_decode_length
-        ids = torch.empty((B, L), device="cuda", dtype=torch.int32)
-        ms = C.c_float()
-        _lib.check(self._lib.mt3_debug_engine_decode_split(self._h, B, num_steps or L, groups, mask_mode, ids.data_ptr(),
-                                                           C.byref(ms), torch.cuda.current_stream().cuda_stream))
-        return ids, ms.value
 
     def debug_poison_caches(self, pattern: int = 0xFF, cross: bool = False):
         """mt3_debug_engine_poison_caches: fill the K/V caches with a byte pattern (0xFF = NaN in every cache format)."""
@@ -276,7 +290,7 @@ class Transformer:
         return ids, logits
 
     def status(self, what: int) -> int:
-        """mt3_engine_status: _lib.STATUS_GRAPH_FALLBACKS / STATUS_LAST_DECODE_USED_GRAPH / STATUS_RESIDUAL_SPLIT."""
+        """mt3_engine_status: _lib.STATUS_* (graph fallbacks, row groups / compactions of the last decode, ...)."""
         rc = int(self._lib.mt3_engine_status(self._h, what))
         if rc < 0:
             _lib.check(rc)

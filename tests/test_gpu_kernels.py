@@ -222,54 +222,44 @@ def test_gemm_glds_geglu_and_heads():
     assert rel_err(o2, r2) < 6e-3
 
 
-@pytest.mark.parametrize("tall", [True, False])
-def test_gemm_glds_256_row_tile_store_geglu_heads(tall):
-    """The 256 x 128 LDS-DMA tile (round 3; taken when a launch has >= 512 of them) against float64 on the same bf16
+def test_gemm_glds_256_row_tile_store_geglu_heads():
+    """The 256 x 128 LDS-DMA tile (round 3; taken when a launch has >= 1024 of them) against float64 on the same bf16
     operands, ragged M (the last tile holds 37 rows), every epilogue it serves, K = 512 and K = 1024 (norm-2 partial
-    sums in 16 registers); `tall=False` forces the 128 x 128 tile through the debug knob: both must agree with the
-    reference, and with each other bit for bit (same per-element summation order)."""
-    _lib.check(lib().mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_GLDS_256, 0 if tall else 1))
-    try:
-        g = torch.Generator(device="cuda").manual_seed(77)
-        outs = []
-        for (M, N, K) in ((256 * 57 + 37, 1152, 512), (256 * 40 + 5, 2048, 1024)):
-            x = torch.randn(M, K, device="cuda", generator=g) * torch.rand(M, 1, device="cuda", generator=g) * 4
-            Wt = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
-            ct, ss = _split(x)
-            rs = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-6)
-            out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-            run_gemm_ex(ct, 2, Wt, out, M, N, K, _lib.EPI_STORE, a_ss=ss)
-            ref = (ct.double() @ Wt.double().T) * rs
-            assert rel_err(out, ref) < 6e-3, (M, N, K, rel_err(out, ref))
-            worst = ((out.double() - ref).abs().amax(1) / ref.abs().amax(1)).max()
-            assert float(worst) < 2e-2, float(worst)                     # no row is garbage (ragged tail, tile seams)
-            outs.append(out)
-            # GEGLU on the same operands: N columns = interleaved gate / linear groups of 16
-            F = N // 2
-            og = torch.zeros(M, F, device="cuda", dtype=torch.bfloat16)
-            run_gemm_ex(ct, 2, Wt, og, M, N, K, _lib.EPI_GEGLU, a_ss=ss)
-            full = (ct.double() @ Wt.double().T) * rs
-            gate = full.view(M, F // 16, 2, 16)[:, :, 0].reshape(M, F)
-            lin = full.view(M, F // 16, 2, 16)[:, :, 1].reshape(M, F)
-            assert rel_err(og, gelu_tanh(gate) * lin) < 8e-3
-            outs.append(og)
-        B, T, H, K = 171, 256, 6, 512                                    # 171 tall tiles x 6 columns = 1026 >= 1024
-        A = torch.randn(B * T, K, device="cuda", generator=g).to(torch.bfloat16)
-        W2 = (torch.randn(2 * H * 64, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
-        o2 = torch.zeros(2, B, H, T, 64, device="cuda", dtype=torch.bfloat16)
-        run_gemm_ex(A, 0, W2, o2, B * T, 2 * H * 64, K, _lib.EPI_HEADS, seq_len=T)
-        r2 = (A.double() @ W2.double().T).view(B, T, 2, H, 64).permute(2, 0, 3, 1, 4)
-        assert rel_err(o2, r2) < 6e-3
-        outs.append(o2)
-        test_gemm_glds_256_row_tile_store_geglu_heads.results = getattr(
-            test_gemm_glds_256_row_tile_store_geglu_heads, "results", {})
-        test_gemm_glds_256_row_tile_store_geglu_heads.results[tall] = [o.clone() for o in outs]
-        both = test_gemm_glds_256_row_tile_store_geglu_heads.results
-        if True in both and False in both:
-            for a, b in zip(both[True], both[False]):
-                assert torch.equal(a, b), "the 256-row and the 128-row tile must produce identical outputs"
-    finally:
-        _lib.check(lib().mt3_debug_set_knob(_lib.DEBUG_KNOB_NO_GLDS_256, 0))
+    sums in 16 registers).  The same product launched in row slices small enough to fall back to the 128 x 128 tile
+    must agree with the reference AND with the tall-tile launch bit for bit (same per-element summation order)."""
+    g = torch.Generator(device="cuda").manual_seed(77)
+    for (M, N, K, piece) in ((256 * 120 + 37, 1152, 512, 256 * 56), (256 * 64 + 5, 2048, 1024, 256 * 24)):
+        assert ((M + 255) // 256) * (N // 128) >= 1024 > ((piece + 255) // 256) * (N // 128)
+        x = torch.randn(M, K, device="cuda", generator=g) * torch.rand(M, 1, device="cuda", generator=g) * 4
+        Wt = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+        ct, ss = _split(x)
+        rs = torch.rsqrt((x.double() ** 2).mean(-1, keepdim=True) + 1e-6)
+        full = (ct.double() @ Wt.double().T) * rs
+        F = N // 2
+        gate = full.view(M, F // 16, 2, 16)[:, :, 0].reshape(M, F)
+        lin = full.view(M, F // 16, 2, 16)[:, :, 1].reshape(M, F)
+        for epi, ref, width, tol in ((_lib.EPI_STORE, full, N, 6e-3), (_lib.EPI_GEGLU, gelu_tanh(gate) * lin, F, 8e-3)):
+            tall = torch.zeros(M, width, device="cuda", dtype=torch.bfloat16)
+            run_gemm_ex(ct, 2, Wt, tall, M, N, K, epi, a_ss=ss)
+            assert rel_err(tall, ref) < tol, (M, N, K, epi, rel_err(tall, ref))
+            worst = ((tall.double() - ref).abs().amax(1) / ref.abs().amax(1)).max()
+            assert float(worst) < 3e-2, float(worst)                     # no row is garbage (ragged tail, tile seams)
+            short = torch.zeros(M, width, device="cuda", dtype=torch.bfloat16)
+            for r0 in range(0, M, piece):
+                m = min(piece, M - r0)
+                run_gemm_ex(ct[r0:r0 + m], 2, Wt, short[r0:r0 + m], m, N, K, epi, a_ss=ss[r0:r0 + m])
+            assert torch.equal(tall, short), "the 256-row and the 128-row tile must produce identical outputs"
+    B, T, H, K = 171, 256, 6, 512                                    # 171 tall tiles x 6 columns = 1026 >= 1024
+    A = torch.randn(B * T, K, device="cuda", generator=g).to(torch.bfloat16)
+    W2 = (torch.randn(2 * H * 64, K, device="cuda", generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    o2 = torch.zeros(2, B, H, T, 64, device="cuda", dtype=torch.bfloat16)
+    run_gemm_ex(A, 0, W2, o2, B * T, 2 * H * 64, K, _lib.EPI_HEADS, seq_len=T)
+    r2 = (A.double() @ W2.double().T).view(B, T, 2, H, 64).permute(2, 0, 3, 1, 4)
+    assert rel_err(o2, r2) < 6e-3
+    Bs = 60                                                          # 60 x 6 = 360 tall tiles: the 128-row tile
+    o3 = torch.zeros(2, Bs, H, T, 64, device="cuda", dtype=torch.bfloat16)
+    run_gemm_ex(A[: Bs * T], 0, W2, o3, Bs * T, 2 * H * 64, K, _lib.EPI_HEADS, seq_len=T)
+    assert torch.equal(o3, o2[:, :Bs])
 
 
 # ------------------------------------------------------------------------ attention

@@ -270,9 +270,8 @@ def test_wide_bf16_engine_encodes_at_batch_one():
 def test_f32_engine_variants_agree_at_f32_round_off():
     """Round 3 moved the f32 decode loop onto the split residual form (f32 rows + per-16-column sums of squares), folded
     the cross-attention q-projection AND every layer's q / k / v projection into the neighbouring launches (layer 0:
-    two table rows), and gave the decode-sized f32 tiles eight waves with the K-groups split two ways and two K slices
-    in flight.  Every variant is the same function with different summation orders: against the r2 path
-    (options = SINGLE_RESIDUAL_STREAM | SEPARATE_PROJECTIONS, four-wave tiles) teacher-forced logits at 96 positions
+    two table rows).  Every variant is the same function with different summation orders: against the r2 path
+    (options = SINGLE_RESIDUAL_STREAM | SEPARATE_PROJECTIONS) teacher-forced logits at 96 positions
     agree to 2e-5 rel-L2 per (step, row), and each variant stays inside 1e-4 of the f32 oracle."""
     cfg = network.T5Config(dtype="float32")
     params = network.init_random_params(cfg, seed=0, norm_scale_jitter=0.2)
@@ -281,15 +280,11 @@ def test_f32_engine_variants_agree_at_f32_round_off():
     x[4, 50:] = 0.0
     forced = _forced(B, S, 3)
     _, ref = _teacher_forced_ref(_oracle(cfg, params), x, forced)
-    lib = _lib.load()
     outs = {}
-    try:
-        for name, opt, split_k in (("r3", 0, 0), ("r3 eight-wave tiles", 0, 1),
-                                      ("q-fold only", _lib.OPT_SEPARATE_QKV_PROJECTION, 0),
-                                      ("separate projections", _lib.OPT_SEPARATE_PROJECTIONS, 0),
-                                      ("r2 path", _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_SEPARATE_PROJECTIONS, 0)):
-            _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_F32_SPLIT_K, split_k))
-            _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_PREFETCH2, split_k))
+    if True:
+        for name, opt in (("r3", 0), ("q-fold only", _lib.OPT_SEPARATE_QKV_PROJECTION),
+                          ("separate projections", _lib.OPT_SEPARATE_PROJECTIONS),
+                          ("r2 path", _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_SEPARATE_PROJECTIONS)):
             eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=opt)
             eng.load_params(params)
             assert eng.status(_lib.STATUS_Q_FOLD) == (0 if opt & (_lib.OPT_SEPARATE_PROJECTIONS | _lib.OPT_SINGLE_RESIDUAL_STREAM) else 1)
@@ -304,10 +299,7 @@ def test_f32_engine_variants_agree_at_f32_round_off():
             g = eng.decode(num_steps=24).cpu().numpy()
             outs[name + " ids"] = g
             del eng
-    finally:
-        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_F32_SPLIT_K, 0))
-        _lib.check(lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_PREFETCH2, 0))
-    for name in ("r3", "r3 eight-wave tiles", "q-fold only", "separate projections"):
+    for name in ("r3", "q-fold only", "separate projections"):
         d = _rel_rows(outs[name], outs["r2 path"])
         print(f"f32 engine [{name}] vs the r2 path: max rel-L2 {d.max():.3e}")
         assert d.max() < 2e-5, (name, d.max())
@@ -365,8 +357,8 @@ def test_folded_qkv_projection_bf16_and_fp8_caches_against_the_separate_launches
 def test_row_group_decode_schedule_is_bit_identical():
     """Batches of >= 128 rows decode as row groups on streams with hardware queues of their own, one host thread each
     (include/mt3_hip.h, "Schedule").  Rows are independent, so the ids must equal the single-stream graph-replayed schedule bit for bit:
-    greedy, beam-1, with early exit (every group stops on its own rows), odd batch sizes; the experiment entry
-    (mt3_debug_engine_decode_split) as well."""
+    greedy, beam-1, with early exit (every group stops on its own rows, finished rows are retired), odd batch sizes;
+    graph replay per group and direct launches."""
     cfg = network.T5Config(dtype="bfloat16", num_encoder_layers=2, num_decoder_layers=3)
     params = network.init_random_params(cfg, seed=5, norm_scale_jitter=0.1)
     k = params["decoder/logits_dense/kernel"].copy()
@@ -389,8 +381,9 @@ def test_row_group_decode_schedule_is_bit_identical():
     ee = eng.decode(num_steps=L, early_exit=True)
     assert eng.steps_run <= L and torch.equal(ee, full)
     assert bool((full == 1).any()), "the case should contain rows that emit EOS"
-    ids, ms = eng.debug_decode_split(num_steps=96, groups=2, mask_mode=1)
-    assert torch.equal(ids[:, :96], eng.decode(num_steps=96, single_stream=True)[:, :96])
+    direct = eng.decode(num_steps=96, use_graph=False)
+    assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 2 and eng.status(_lib.STATUS_LAST_DECODE_USED_GRAPH) == 0
+    assert torch.equal(direct[:, :96], full[:, :96])
     # a small batch stays on the caller's stream, and the option switches the schedule off for good
     eng.encode(lm[:64])
     eng.decode(num_steps=8)
@@ -470,42 +463,3 @@ def test_bench_batch_256_bf16_against_the_f32_engine_at_all_1024_positions():
     assert float(r[-64:].mean()) < 1.5 * float(r[:64].mean()) + 1e-3
     assert bool(agree[safe].all()) and float(safe.double().mean()) > 0.5
     assert float(agree.double().mean()) > 0.97
-
-
-def test_launch_shape_knobs_do_not_change_results():
-    """`mt3_debug_set_knob` knobs choose launch shapes, not arithmetic: with the summation order of every output element
-    untouched (tile dealing to XCDs, K = 768 in one or two slices, 128- or 256-row encoder tiles, four or eight waves per
-    encoder-attention workgroup, waves per decode-attention workgroup) the encoder output, the teacher-forced logits and
-    the greedy ids of a base-shape engine with e4m3 caches are BIT-identical to the default build."""
-    cfg = dataclasses.replace(network.MT3_BASE, dtype="bfloat16", kv_dtype="fp8_e4m3", num_encoder_layers=2,
-                              num_decoder_layers=2)
-    params = network.init_random_params(cfg, seed=9, norm_scale_jitter=0.1)
-    from mt3_amd import spectrograms, synthetic
-    B = 40                                                      # 40 x 256 rows: 128-row tiles by default, ragged decode tiles
-    lm = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(B, seed=4), None)
-    forced = _forced(B, 20, 2)
-    lib = _lib.load()
-
-    def run():
-        eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B)
-        eng.load_params(params)
-        enc = eng.encode(lm, return_encoded=True).clone()
-        _, logits = eng.decode_forced(forced, num_steps=20)
-        ids = eng.decode(num_steps=24).clone()
-        return enc, logits.clone(), ids
-
-    base = run()
-    knobs = ((_lib.DEBUG_KNOB_XCD_N_MAJOR, 2), (_lib.DEBUG_KNOB_XCD_N_MAJOR, 1), (_lib.DEBUG_KNOB_NO_K768_SPLIT, 1),
-             (_lib.DEBUG_KNOB_NO_GLDS_256, 1), (_lib.DEBUG_KNOB_ENC_ATTN_4_WAVES, 1), (_lib.DEBUG_KNOB_GLDS_FRAG_DB, 1),
-             (_lib.DEBUG_KNOB_DEC_ATTN_FP8_WAVES, 2), (_lib.DEBUG_KNOB_NO_LDS_DMA_GEMM, 1))
-    for knob, value in knobs:
-        _lib.check(lib.mt3_debug_set_knob(knob, value))
-        try:
-            got = run()
-        finally:
-            _lib.check(lib.mt3_debug_set_knob(knob, 0))
-        if knob in (_lib.DEBUG_KNOB_NO_LDS_DMA_GEMM, _lib.DEBUG_KNOB_DEC_ATTN_FP8_WAVES):
-            # a different tile / merge tree: same function, different f32 summation order -> bf16-noise distance
-            assert float((got[0] - base[0]).norm() / base[0].norm()) < 6e-3, knob
-            continue
-        assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]) and torch.equal(got[2], base[2]), (knob, value)

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_typed():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in mt3_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.mt3_abi_version() == 2
+    assert lib.mt3_abi_version() == 3
 
 
 def test_argument_errors_are_reported_not_swallowed():
@@ -37,17 +37,20 @@ def test_argument_errors_are_reported_not_swallowed():
     assert lib.mt3_engine_create(C.byref(cfg), C.byref(h)) == _lib.MT3_ERR_INVALID
     cfg = _lib.EngineConfig(1536, 512, 6, 64, 1024, 8, 8, 512, 256, 1024, 8, _lib.MT3_BF16, 1, 0, 0, 1 << 7)      # unknown option
     assert lib.mt3_engine_create(C.byref(cfg), C.byref(h)) == _lib.MT3_ERR_INVALID
-    assert lib.mt3_debug_set_knob(99, 1) == _lib.MT3_ERR_INVALID
-    assert lib.mt3_debug_set_knob(_lib.DEBUG_KNOB_DEC_ATTN_WAVES, 7) == _lib.MT3_ERR_INVALID
+    assert not hasattr(lib, "mt3_debug_set_knob") and not hasattr(lib, "mt3_debug_engine_decode_split")   # pruned in r4
+    assert lib.mt3_engine_decode_wait(None, None) == _lib.MT3_ERR_INVALID
+    assert lib.mt3_debug_engine_set_eos_schedule(None, None, 0) == _lib.MT3_ERR_INVALID
     with pytest.raises(_lib.Mt3Error):
         _lib.check(lib.mt3_ids_to_tokens(None, 1, 1, 1, None, None))
 
 
 def test_the_product_reads_no_environment_variable():
-    """Tuning switches are config fields (mt3_engine_config.options) or debug knobs (mt3_hip_debug.h), never getenv."""
+    """Tuning switches are config fields (mt3_engine_config.options) or decode flags, never getenv; and since round 4
+    there is no process-global knob left in the library either."""
     csrc = os.path.join(ROOT, "mt3_amd", "csrc")
     for f in os.listdir(csrc):
-        assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+        src = open(os.path.join(csrc, f)).read()
+        assert "getenv" not in src and "g_knobs" not in src, f
 
 
 @pytest.mark.skipif(__import__("torch").cuda.is_available(), reason="checks the no-GPU failure mode")
