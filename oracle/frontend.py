@@ -81,6 +81,65 @@ def compute_logmel(samples: np.ndarray, dtype=np.float64) -> np.ndarray:
     return np.log(safe).astype(dtype)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Second variant: the same leaves in FLOAT32 with TensorFlow's own op order (round 4).  tf.signal builds its window and
+# its mel matrix in `dtype=tf.float32` by default and the reference passes no dtype (mt3/spectral_ops.py:42-47 `tf.signal
+# .stft(... pad_end=True)`, :69-71 `tf.signal.linear_to_mel_weight_matrix(...)`), so what the reference multiplies by is
+# the f32-ROUNDED-AT-EVERY-OP version of the tables above.  Restated [from memory of tensorflow/python/ops/signal/
+# {window_ops,mel_ops}.py and math_ops.linspace_nd; still PARITY UNPINNED against TF itself] to BOUND what that rounding
+# moves in the log domain (tests/test_oracle_frontend_tf32.py; the figure is quoted in DESIGN.md section 4):
+#   linspace(start, stop, n)   = concat(start, start + delta * [1 .. n-2], stop), delta = (stop - start) / (n - 1), all f32
+#   _hertz_to_mel(f)           = 1127.0 * log(1.0 + f / 700.0)                   (plain log, not log1p; f32)
+#   hann_window(N, periodic)   = 0.5 - 0.5 * cos(2 pi * k / N)                   (2 pi as an f32 constant, f32 cos)
+#   mel = tensordot(|rfft|, W) , log                                              (f32; the FFT itself in f32: scipy.fft keeps
+#                                                                                 single precision, numpy.fft would not)
+def _f32(x):
+    return np.asarray(x, np.float32)
+
+
+def linspace_tf32(start, stop, n) -> np.ndarray:
+    start, stop = np.float32(start), np.float32(stop)
+    delta = np.float32((stop - start) / np.float32(n - 1))
+    mid = start + delta * np.arange(1, n - 1, dtype=np.float32)
+    return np.concatenate([[start], mid.astype(np.float32), [stop]]).astype(np.float32)
+
+
+def hertz_to_mel_tf32(f):
+    return (np.float32(1127.0) * np.log(np.float32(1.0) + _f32(f) / np.float32(700.0))).astype(np.float32)
+
+
+def mel_weight_matrix_tf32(num_mel_bins=NUM_MEL_BINS, num_spectrogram_bins=FFT_SIZE // 2 + 1,
+                           sample_rate=SAMPLE_RATE, lo_hz=MEL_LO_HZ, hi_hz=MEL_HI_HZ) -> np.ndarray:
+    nyquist = np.float32(sample_rate) / np.float32(2.0)
+    lin = linspace_tf32(0.0, nyquist, num_spectrogram_bins)[1:]
+    spec_mel = hertz_to_mel_tf32(lin)[:, None]
+    edges = linspace_tf32(hertz_to_mel_tf32(lo_hz), hertz_to_mel_tf32(hi_hz), num_mel_bins + 2)
+    lower, center, upper = edges[:-2][None, :], edges[1:-1][None, :], edges[2:][None, :]
+    lower_slopes = ((spec_mel - lower) / (center - lower)).astype(np.float32)
+    upper_slopes = ((upper - spec_mel) / (upper - center)).astype(np.float32)
+    w = np.maximum(np.float32(0.0), np.minimum(lower_slopes, upper_slopes))
+    return np.pad(w, [[1, 0], [0, 0]]).astype(np.float32)
+
+
+def hann_periodic_tf32(n=FFT_SIZE) -> np.ndarray:
+    count = np.arange(n, dtype=np.float32)
+    arg = (np.float32(2.0 * np.pi) * count / np.float32(n)).astype(np.float32)      # periodic, even n: divisor n
+    return (np.float32(0.5) - np.float32(0.5) * np.cos(arg)).astype(np.float32)
+
+
+def compute_logmel_tf32(samples: np.ndarray) -> np.ndarray:
+    """compute_logmel with every leaf as a float32 TensorFlow graph would evaluate it (see above)."""
+    import scipy.fft
+    x = _f32(samples)
+    frames = (frame_signal(x) * hann_periodic_tf32()[None, :]).astype(np.float32)
+    spec = scipy.fft.rfft(frames, axis=-1)
+    assert spec.dtype == np.complex64
+    mag = np.abs(spec).astype(np.float32)
+    mel = (mag @ mel_weight_matrix_tf32()).astype(np.float32)
+    safe = np.where(mel <= 0.0, np.float32(LOG_EPS), mel)
+    return np.log(safe).astype(np.float32)
+
+
 def segment_logmel_padded(seg_frames: np.ndarray, inputs_length: int, dtype=np.float32) -> np.ndarray:
     """What reaches the encoder for one segment: log-mel of its n<=T frames, rows
     n..T-1 literal zeros (feature converter pads AFTER the log: models.py:48-98)."""
