@@ -432,8 +432,9 @@ def main():
             ach = self_bytes / launches / (self_us * 1e-6) / 1e9
             kname = ("fp8" if ecfg.kv_dtype else ("bf16" if esz == 2 else "f32"))
             traffic, traffic_src = None, "no PMC summary for these kernel sources / this shape (run tools/gpu_pmc.sh)"
-            if args.decode_steps == 1024 and ecfg.num_heads == 6:
-                ratio, fname, khash = pmc_ratio("dec_attn_self_append_" + kname, "n_keys_513")
+            if args.decode_steps == 1024 and (ecfg.num_heads == 6 or (ecfg.num_heads == 12 and ecfg.kv_dtype)):
+                ratio, fname, khash = pmc_ratio("dec_attn_self_append_" + kname + ("_h12" if ecfg.num_heads == 12 else ""),
+                                                "n_keys_513")
                 if ratio is not None:
                     traffic = ratio * self_bytes / launches
                     traffic_src = "profiles/%s (kernel sources %s; measured traffic/algorithmic = %.4f at the mean " \
@@ -507,19 +508,24 @@ def main():
 
             free_running = {}          # key -> the token rows [Br, L] of that engine's free-running decode of a256
 
-            def other_engine(key, ecfg, label, n_steps, with_roofline):
+            def other_engine(key, ecfg, label, n_steps, with_roofline, inputs=None):
                 """the SAME pipeline as the headline on another engine configuration: one warm-up step, then `n_steps`
-                timed steps (wall clock, synchronised both sides, host note decoding inside)"""
+                timed steps (wall clock, synchronised both sides, host note decoding inside).  inputs: (audio, true
+                frame counts, [(first, count) per file]) instead of the headline's fixed-length segments"""
                 try:
                     e2 = network.Transformer(ecfg, input_length=256, max_decode_length=L, max_batch=Br)
                     e2.load_params(network.init_random_params(ecfg, seed=0))
+                    aud, nfr, file_list = inputs if inputs is not None else (a256, None, None)
+                    lm_in = spectrograms.compute_spectrogram_batch(aud, nfr)
 
                     def one_step():
                         with torch.cuda.stream(stream):
-                            e2.encode(spectrograms.compute_spectrogram_batch(a256, None))
+                            e2.encode(spectrograms.compute_spectrogram_batch(aud, nfr))
                             ids = e2.decode(num_steps=args.decode_steps)
                             host = vocab.decode_tf(ids).cpu().numpy()
                         free_running[key] = host
+                        if file_list is not None:     # one host-stage job per FILE of the ragged corpus
+                            return [job._pool.submit(notes_of_file, host[a:a + n], a) for a, n in file_list]
                         return host_stage(host)
                     for f in one_step():
                         f.result()
@@ -532,7 +538,7 @@ def main():
                         f.result()
                     torch.cuda.synchronize()
                     d = (time.perf_counter() - t1) / n_steps
-                    e_ms = min(timed(lambda: e2.encode(lm256), reps=5) for _ in range(2))
+                    e_ms = min(timed(lambda: e2.encode(lm_in), reps=5) for _ in range(2))
                     rec = {"value": Br * SEG_SECONDS / d, "unit": "audio-s/s", "ms_per_step": d * 1e3, "steps": n_steps,
                            "warmup": 1, "dtype": ("bf16" if ecfg.dtype == "bfloat16" else "f32") +
                            (" compute + fp8 (e4m3) K/V caches" if ecfg.kv_dtype else "") +
@@ -568,12 +574,16 @@ def main():
             #   fp8_kv    : this workload with e4m3 K/V caches (half the bytes of the HBM-bound decode stream)
             #   fp8_kv_mx8: the same plus the encoder's dense layers / cross-K/V projections as MXFP8 on the scaled MFMA
             #   configs4  : the ismir2022/base.gin shape (emb 768, 12 heads, 12+12 layers, mlp 2048) with both
-            for key, shp, dense, label, wr in (
-                    ("fp8_kv", network.MT3_SMALL, "", "MT3 (model.gin) shape", True),
-                    ("fp8_kv_mx8", network.MT3_SMALL, "fp8_e4m3", "MT3 (model.gin) shape", False),
-                    ("configs4", network.MT3_BASE, "fp8_e4m3", "BASELINE configs[4]: ismir2022/base.gin shape", True)):
+            # configs[4] runs on "Slakh-shaped" audio: six tones in every segment, files of 1 .. 8 segments
+            # whose last segment is ragged (true frame counts go to the frontend, one host-stage job per file)
+            slakh = synthetic.synth_slakh_shaped(Br, seed=4)
+            for key, shp, dense, label, wr, inp in (
+                    ("fp8_kv", network.MT3_SMALL, "", "MT3 (model.gin) shape", True, None),
+                    ("fp8_kv_mx8", network.MT3_SMALL, "fp8_e4m3", "MT3 (model.gin) shape", False, None),
+                    ("configs4", network.MT3_BASE, "fp8_e4m3", "BASELINE configs[4]: ismir2022/base.gin shape, Slakh-shaped "
+                     "synthetic audio (6 tones, %d files of 1-8 segments, ragged last segments)" % len(slakh[2]), True, slakh)):
                 c8 = dataclasses.replace(shp, dtype="bfloat16", kv_dtype="fp8_e4m3", dense_dtype=dense)
-                rec = other_engine(key, c8, label, 3, wr)
+                rec = other_engine(key, c8, label, 3, wr, inp)
                 if key == "fp8_kv_mx8" and rec.get("value"):
                     tf8 = ENC_GFLOP_PER_SEGMENT * Br / (rec["encoder_ms"] * 1e-3) / 1e3
                     extras["encoder_mx8"] = {"segments": Br, "ms": rec["encoder_ms"], "bound": "mfma", "achieved": tf8,

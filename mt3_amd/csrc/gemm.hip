@@ -832,6 +832,15 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
         }
       }
     }
+    if constexpr (KG == 16 && !NORM && !A_F32 && (EPI == MT3_EPI_GEGLU || EPI == kEpiResidS)) {
+      // f32 operands, experiment (GemmArgs::tall): 64-row tiles for the two weight-heavy launches of a decoder layer --
+      // one weight fetch serves a whole 64-row group; K slices of 256 keep (64 + BN) x 264 floats inside the LDS; four
+      // waves stacked along M (GEGLU: 16 x 32 per wave, the gate | linear fragment pair; fold: 16 x 16)
+      if (g.tall && g.K % (16 * KG) == 0) {
+        if constexpr (EPI == MT3_EPI_GEGLU) return launch_cfg<CT, 64, 32, 16 * KG, 4, 1, A_F32, NORM, EPI>(g, s);
+        else return launch_cfg<CT, 64, 16, 16 * KG, 4, 1, A_F32, NORM, EPI>(g, s);
+      }
+    }
     if constexpr (EPI == MT3_EPI_GEGLU) {
       if (deep) return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 64, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);

@@ -12,13 +12,16 @@ import math
 
 
 def synth_audio(n_segments: int, seed: int = 0, seg_samples: int = 32768, sample_rate: int = 16000,
-                device: str = "cuda"):
+                device: str = "cuda", tones: int = 0):
+    """tones = 0: 1-6 tones per segment (the MT3 recipe); tones = n: exactly n in every segment."""
     import torch
     g = torch.Generator(device=device).manual_seed(seed)
     S, N = n_segments, seg_samples
     t = torch.arange(N, device=device, dtype=torch.float32) / sample_rate           # [N]
     dur = N / sample_rate
     n_tones = torch.randint(1, 7, (S,), device=device, generator=g)
+    if tones:
+        n_tones = torch.full_like(n_tones, tones)
     x = torch.zeros(S, N, device=device)
     for tone in range(6):
         on = (n_tones > tone).float()[:, None]
@@ -40,3 +43,24 @@ def synth_audio(n_segments: int, seed: int = 0, seg_samples: int = 32768, sample
     x.scatter_add_(1, idx.reshape(S, -1), noise.reshape(S, -1))
     x *= 0.9 / x.abs().amax(1, keepdim=True).clamp_min(1e-9)
     return x
+
+
+def synth_slakh_shaped(n_segments: int, seed: int = 0, seg_frames: int = 256, hop: int = 128, max_file_segments: int = 8):
+    """"Slakh-shaped" synthetic audio (BASELINE configs[4]): mixed-instrument tracks = SIX tones in every
+    segment plus the noise bursts, cut into FILES of any length >= 1 segment (the reference resamples Slakh `mix` files to
+    16 kHz and splits them into input-length segments, mt3/preprocessors.py:500-503, NB:331): the segments of a file are
+    consecutive, the last one is ragged (1 .. seg_frames frames of audio, zeros after).  Returns (CUDA f32
+    [n_segments, seg_frames * hop], numpy int32 true frame counts [n_segments], list of (first, count) per file)."""
+    import numpy as np
+    audio = synth_audio(n_segments, seed=seed, seg_samples=seg_frames * hop, tones=6)
+    rng = np.random.default_rng(seed)
+    n_frames = np.full(n_segments, seg_frames, np.int32)
+    files, first = [], 0
+    while first < n_segments:
+        count = int(min(rng.integers(1, max_file_segments + 1), n_segments - first))
+        last = first + count - 1
+        n_frames[last] = int(rng.integers(1, seg_frames + 1))
+        audio[last, int(n_frames[last]) * hop:] = 0.0
+        files.append((first, count))
+        first += count
+    return audio, n_frames, files

@@ -27,7 +27,7 @@ del a, b
 KEYS = (1024, 513, 129, 1024, 513, 129)
 
 
-def self_and_cross(kind):
+def self_and_cross(kind, H=H):
     tdt = torch.float32 if kind == "f32" else torch.bfloat16
     es = 4 if kind == "f32" else 2
     dt = _lib.MT3_F32 if kind == "f32" else _lib.MT3_BF16
@@ -74,6 +74,9 @@ def self_and_cross(kind):
 for kind in ("bf16", "f32", "fp8"):
     self_and_cross(kind)
     torch.cuda.empty_cache()
+# BASELINE configs[4] (ismir2022/base.gin shape): 12 heads, e4m3 caches (the summary tells the two fp8 passes apart by grid size)
+self_and_cross("fp8", H=12)
+torch.cuda.empty_cache()
 # log-mel frontend at the bench shape (256 full segments), 3 launches on fresh inputs (north_star: rocprof counters
 # report the frontend's HBM traffic; algorithmic = 655,360 B per segment)
 from mt3_amd import spectrograms, synthetic  # noqa: E402

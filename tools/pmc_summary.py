@@ -12,7 +12,7 @@ import shutil
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-RND = sys.argv[3] if len(sys.argv) > 3 else "r3"
+RND = sys.argv[3] if len(sys.argv) > 3 else "r4"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import FRONTEND_SOURCES, kernel_source_hash  # noqa: E402
 B, H, D, CAP = 256, 6, 64, 1024
@@ -55,7 +55,7 @@ summary = {
 }
 
 
-def entry(f_kib, w_kib, n_keys, append, kind):
+def entry(f_kib, w_kib, n_keys, append, kind, H=H):
     # algorithmic: K and V rows of every cached key, the query, the output (+ the new K/V row read and written);
     # fp8: 64 e4m3 bytes per K / V row + the 8-byte scale pair of the position; q / out / new rows bf16
     es = 4 if kind == "f32" else 2
@@ -72,10 +72,14 @@ def entry(f_kib, w_kib, n_keys, append, kind):
 # launch order of pmc_attn.py per cache format: (1024, 513, 129) x 2 rounds x 4 layers of self/append, then 8 cross
 # (rocprofv3 prints the __bf16 instantiations either mangled -- ...dec_attn_kernelIDF16b... -- or mis-demangled as
 # "dec_attn_kernel<bool _Accum, ...>")
+H12 = (B * 12 * 192, B * 12 * 256)             # work-items of the 12-head fp8 launches (self: 3 waves, cross: 4)
 KIND = {"bf16": lambda n, g: "dec_attn_kernel" in n and "dec_attn_kernel<float" not in n,
         "f32": lambda n, g: "dec_attn_kernel<float" in n,
-        "fp8": lambda n, g: "dec_attn_fp8_kernel" in n}
+        "fp8": lambda n, g: "dec_attn_fp8_kernel" in n and g not in H12,
+        "fp8_h12": lambda n, g: "dec_attn_fp8_kernel" in n and g in H12}
 for kind, pred in KIND.items():
+    heads = 12 if kind.endswith("_h12") else H
+    fmt = kind.split("_")[0]
     af, aw = pick(fetch, pred), pick(write, pred)
     if len(af) != 32 or len(aw) != 32:
         print("skipping %s: %d / %d dispatches (expected 32)" % (kind, len(af), len(aw)))
@@ -83,9 +87,9 @@ for kind, pred in KIND.items():
     sec = {}
     for i, n_keys in enumerate((1024, 513, 129)):
         sel = list(range(12 + i * 4, 12 + i * 4 + 4))        # second round: caches hold nothing of these layers
-        sec["n_keys_%d" % n_keys] = entry(sum(af[j] for j in sel) / 4, sum(aw[j] for j in sel) / 4, n_keys, True, kind)
+        sec["n_keys_%d" % n_keys] = entry(sum(af[j] for j in sel) / 4, sum(aw[j] for j in sel) / 4, n_keys, True, fmt, heads)
     summary["dec_attn_self_append_" + kind] = sec
-    summary["dec_attn_cross_256_keys_" + kind] = entry(sum(af[24:]) / 8, sum(aw[24:]) / 8, 256, False, kind)
+    summary["dec_attn_cross_256_keys_" + kind] = entry(sum(af[24:]) / 8, sum(aw[24:]) / 8, 256, False, fmt, heads)
 # log-mel frontend: 3 launches of 256 full segments
 is_fe = lambda n, g: "logmel_kernel" in n
 ff, fw = pick(fetch, is_fe), pick(write, is_fe)
