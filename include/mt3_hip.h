@@ -145,16 +145,13 @@ enum {
   MT3_OPT_SEPARATE_QKV_PROJECTION = 8,
   /* never use the row-group decode schedule (see mt3_engine_decode): every decode stays on the caller's stream */
   MT3_OPT_NO_ROW_GROUPS = 16,
-  /* ---- round-4 experiment bits (measured in tools/ab_r4.py; the winners become the default, the rest go) ----
-   * f32 engine, row groups of more than 32 rows: the two weight-heavy launches of a decoder layer (GEGLU: 4 MB of f32
-   * weights; the two-source fold launch: 12.6 MB) on 64-ROW tiles, so that a 64-row group fetches every weight byte
-   * once instead of once per 32-row tile (same per-element summation order: bit-identical results) */
-  MT3_OPT_X_F32_TALL_TILES = 32,
-  /* at most two row groups whatever the batch (the f32 engine otherwise takes four from 256 rows) */
-  MT3_OPT_X_TWO_ROW_GROUPS = 64,
-  /* the group threads wait for their stream on a blocking-sync event (the thread sleeps) instead of spinning in
-   * hipStreamSynchronize */
-  MT3_OPT_X_BLOCKING_WAIT = 128
+  /* ---- round-4 experiment bits (measured in tools/ab_r4.py; the winner becomes the default, the rest goes) ----
+   * decoder: the latency-bound RESID-family and GEGLU launches of a step on the split-K tile (16 x 16 outputs per
+   * workgroup, four waves splitting K, operands straight from L2: csrc/gemm.hip, gemm_sk_kernel); summation order per
+   * output element changes (four K quarters), i.e. f32 round-off */
+  MT3_OPT_X_SPLIT_K_TILES = 32,
+  /* with it: the two-source fold launch on 16 x 32 tiles */
+  MT3_OPT_X_SK_WIDE_FOLD = 64
 };
 
 typedef struct mt3_engine mt3_engine;

@@ -283,12 +283,15 @@ def test_f32_engine_variants_agree_at_f32_round_off():
     outs = {}
     if True:
         for name, opt in (("r3", 0), ("q-fold only", _lib.OPT_SEPARATE_QKV_PROJECTION),
+                          ("split-K tiles", _lib.OPT_X_SPLIT_K_TILES),
+                          ("split-K tiles, wide fold", _lib.OPT_X_SPLIT_K_TILES | _lib.OPT_X_SK_WIDE_FOLD),
+                          ("split-K tiles, separate qkv", _lib.OPT_X_SPLIT_K_TILES | _lib.OPT_SEPARATE_QKV_PROJECTION),
                           ("separate projections", _lib.OPT_SEPARATE_PROJECTIONS),
                           ("r2 path", _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_SEPARATE_PROJECTIONS)):
             eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=opt)
             eng.load_params(params)
             assert eng.status(_lib.STATUS_Q_FOLD) == (0 if opt & (_lib.OPT_SEPARATE_PROJECTIONS | _lib.OPT_SINGLE_RESIDUAL_STREAM) else 1)
-            assert eng.status(_lib.STATUS_QKV_FOLD) == (1 if opt == 0 else 0)
+            assert eng.status(_lib.STATUS_QKV_FOLD) == (1 if opt & ~(_lib.OPT_X_SPLIT_K_TILES | _lib.OPT_X_SK_WIDE_FOLD) == 0 else 0)
             assert eng.status(_lib.STATUS_RESIDUAL_SPLIT) == (0 if opt & _lib.OPT_SINGLE_RESIDUAL_STREAM else 1)
             eng.encode(torch.from_numpy(x).cuda())
             ids, logits = eng.decode_forced(forced, num_steps=S)
@@ -299,7 +302,8 @@ def test_f32_engine_variants_agree_at_f32_round_off():
             g = eng.decode(num_steps=24).cpu().numpy()
             outs[name + " ids"] = g
             del eng
-    for name in ("r3", "q-fold only", "separate projections"):
+    for name in ("r3", "q-fold only", "split-K tiles", "split-K tiles, wide fold", "split-K tiles, separate qkv",
+                 "separate projections"):
         d = _rel_rows(outs[name], outs["r2 path"])
         print(f"f32 engine [{name}] vs the r2 path: max rel-L2 {d.max():.3e}")
         assert d.max() < 2e-5, (name, d.max())
@@ -326,17 +330,19 @@ def test_folded_qkv_projection_bf16_and_fp8_caches_against_the_separate_launches
         cfg = dataclasses.replace(network.T5Config(), dtype="bfloat16", kv_dtype=kv)
         outs = {}
         for name, opt in (("folded", 0), ("q-fold only", _lib.OPT_SEPARATE_QKV_PROJECTION),
+                          ("folded, split-K tiles", _lib.OPT_X_SPLIT_K_TILES),
+                          ("folded, split-K tiles, wide fold", _lib.OPT_X_SPLIT_K_TILES | _lib.OPT_X_SK_WIDE_FOLD),
                           ("separate", _lib.OPT_SEPARATE_PROJECTIONS)):
             eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=opt)
             eng.load_params(params)
-            assert eng.status(_lib.STATUS_QKV_FOLD) == (1 if opt == 0 else 0)
+            assert eng.status(_lib.STATUS_QKV_FOLD) == (0 if opt & (_lib.OPT_SEPARATE_QKV_PROJECTION | _lib.OPT_SEPARATE_PROJECTIONS) else 1)
             eng.encode(torch.from_numpy(x).cuda())
             _, logits = eng.decode_forced(forced, num_steps=S)
             outs[name] = logits.cpu().numpy()
             r = _rel_rows(outs[name], ref)
             print(f"kv {kv or 'bf16'} [{name}]: teacher-forced logits vs f32 oracle max {r.max():.3e} mean {r.mean():.3e}")
             assert r.max() < bound, (kv, name, r.max())
-            if opt == 0:
+            if not opt & (_lib.OPT_SEPARATE_QKV_PROJECTION | _lib.OPT_SEPARATE_PROJECTIONS):
                 _, l2 = eng.decode_forced(forced, num_steps=40, use_graph=False)
                 assert torch.equal(l2.cpu(), torch.from_numpy(outs[name][:40]))
                 a = eng.decode(num_steps=48, chains=1).cpu().numpy()
@@ -348,7 +354,7 @@ def test_folded_qkv_projection_bf16_and_fp8_caches_against_the_separate_launches
                 assert np.array_equal(d1, d2)
                 assert eng.status(_lib.STATUS_GRAPH_FALLBACKS) == 0
             del eng
-        for name in ("folded", "q-fold only"):
+        for name in ("folded", "q-fold only", "folded, split-K tiles", "folded, split-K tiles, wide fold"):
             d = _rel_rows(outs[name], outs["separate"])
             print(f"kv {kv or 'bf16'} [{name}] vs separate launches: max {d.max():.3e} median {np.median(d):.3e}")
             assert d.max() < (2e-2 if not kv else 5e-2) and np.median(d) < 8e-3, (kv, name, d.max(), np.median(d))

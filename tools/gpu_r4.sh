@@ -8,6 +8,7 @@
 #          frontend) -> gpurun_out/pmc/r4_pmc_summary.json (+ the two counter csv files)
 #   pmcenc tools/gpu_pmc_enc.sh: SQ / MFMA counter passes over the encoder -> gpurun_out/pmc_enc/summary.json
 #   ab     python tools/ab_r4.py $AB_ARGS -> gpurun_out/ab_r4.log
+#   eosprof rocprofv3 --kernel-trace --stats of tools/eos_profile.py (the decode loop under the synthetic EOS schedule)
 #   smoke  __graft_entry__.smoke()
 #   corpus bench.py --corpus 10000 (BASELINE configs[3] at N = 1)
 # Everything lands under gpurun_out/; copy what should be judged into profiles/.
@@ -67,6 +68,18 @@ for st in $STAGES; do
     ab)
       timeout ${AB_TIMEOUT:-600} python tools/ab_r4.py $AB_ARGS > gpurun_out/ab_r4.log 2>&1
       echo "exit $? : ab_r4 $AB_ARGS"; grep -v "^/opt\|Warning" gpurun_out/ab_r4.log | tail -40
+      ;;
+    eosprof)
+      rm -rf gpurun_out/prof_eos; mkdir -p gpurun_out/prof_eos
+      for dt in ${EOS_DTYPES:-float32 bfloat16}; do
+        cd /tmp
+        timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_eos" -o eos_$dt -- python "$R/tools/eos_profile.py" $dt 2 > "$R/gpurun_out/eos_profile_$dt.log" 2>&1
+        echo "exit $? : rocprof eos_profile $dt"; grep "eos-schedule" "$R/gpurun_out/eos_profile_$dt.log"
+        cd "$R"
+        f=$(find gpurun_out/prof_eos -name "eos_${dt}_kernel_stats.csv" | head -1)
+        [ -n "$f" ] && cp "$f" gpurun_out/r4_eos_${dt}_kernel_stats.csv && head -16 "$f" | cut -c1-220
+      done
+      find gpurun_out/prof_eos -name "*kernel_trace.csv" -delete; find gpurun_out/prof_eos -name "*.db" -delete
       ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_r4.log 2>&1
