@@ -145,13 +145,9 @@ enum {
   MT3_OPT_SEPARATE_QKV_PROJECTION = 8,
   /* never use the row-group decode schedule (see mt3_engine_decode): every decode stays on the caller's stream */
   MT3_OPT_NO_ROW_GROUPS = 16,
-  /* ---- round-4 experiment bits (measured in tools/ab_r4.py; the winner becomes the default, the rest goes) ----
-   * decoder: the latency-bound RESID-family and GEGLU launches of a step on the split-K tile (16 x 16 outputs per
-   * workgroup, four waves splitting K, operands straight from L2: csrc/gemm.hip, gemm_sk_kernel); summation order per
-   * output element changes (four K quarters), i.e. f32 round-off */
-  MT3_OPT_X_SPLIT_K_TILES = 32,
-  /* with it: the two-source fold launch on 16 x 32 tiles */
-  MT3_OPT_X_SK_WIDE_FOLD = 64
+  /* ---- round-4 experiment bit (measured in tools/ab_r4.py; becomes the default or goes) ----
+   * f32 engine, batches of >= 256 rows: EIGHT row groups of >= 32 rows instead of four */
+  MT3_OPT_X_EIGHT_ROW_GROUPS = 32
 };
 
 typedef struct mt3_engine mt3_engine;

@@ -92,7 +92,7 @@ struct LayerDev {
 // 4 = beam-1 token selection, 8 = teacher forcing, 16 = row retirement (finished slots cost nothing, the slot map is
 // in use), 32 = the synthetic EOS schedule (mt3_debug_engine_set_eos_schedule)
 constexpr int kVarBeam = 4, kVarForced = 8, kVarRetire = 16, kVarEos = 32, kNumVariants = 64;
-constexpr int kMaxGroups = 4;
+constexpr int kMaxGroups = 8;
 
 // One persistent host thread per row group (created with the first decode that needs it, joined at destroy): a
 // decode call hands each group's loop to one of them instead of spawning threads per call, and with
@@ -236,7 +236,7 @@ struct mt3_engine {
   // hipExtStreamCreateWithCUMask and a mask of ALL compute units: measured at B = 256 (bf16), two PLAIN streams take
   // 818 ms per 1024-step decode (HIP multiplexes them onto its queue pool and the groups serialise), two masked ones
   // 588 ms whether the masks are disjoint halves, overlap, or cover every CU (one graph-replayed chain: 626 ms).
-  hipStream_t part_stream[4] = {};
+  hipStream_t part_stream[kMaxGroups] = {};
   hipEvent_t part_begin = nullptr;
   int part_failed = 0;           // partitioned decodes that fell back to the single-stream schedule (stream creation failed)
   int last_groups = 1;           // row groups of the most recent decode
@@ -593,13 +593,10 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     g.a_ss = y_ss;
     return g;
   };
-  // experiment (MT3_OPT_X_SPLIT_K_TILES): the latency-bound RESID-family / GEGLU launches on the split-K tile
-  const int sk = (c.options & MT3_OPT_X_SPLIT_K_TILES) ? ((c.options & MT3_OPT_X_SK_WIDE_FOLD) ? 3 : 1) : 0;
   auto resid = [&](const void* A, const void* Wt, int K) {
     mt3k::GemmArgs g = gemm_args(A, Wt, y, rows, emb, K, emb);
     g.out_ct = y_copy;
     g.out_ss = y_ss;
-    g.sk = sk;
     return g;
   };
   const int nrm = split ? 2 : 1;
@@ -711,11 +708,8 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     }
     case 5:
       return mt3k::launch_gemm(dt, resid(attn_d, L.wo_x, hd), false, 0, MT3_EPI_RESID, small, s);
-    case 6: {
-      mt3k::GemmArgs g = normed(L.wi, h_d, 2 * c.mlp_dim, c.mlp_dim);
-      g.sk = split ? sk : 0;
-      return mt3k::launch_gemm(dt, g, !split, nrm, MT3_EPI_GEGLU, small, s);
-    }
+    case 6:
+      return mt3k::launch_gemm(dt, normed(L.wi, h_d, 2 * c.mlp_dim, c.mlp_dim), !split, nrm, MT3_EPI_GEGLU, small, s);
     default:
       if (fold) {
         // MLP out-projection + residual, and -- as extra output columns with a two-source K = mlp + emb -- what consumes
@@ -734,7 +728,6 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
         g.A2 = y_ct;
         g.lda2 = emb;
         g.k_split = c.mlp_dim;
-        g.sk = sk;
         return mt3k::launch_gemm(dt, g, false, 0, mt3k::kEpiResidS, small, s);
       }
       return mt3k::launch_gemm(dt, resid(h_d, L.wo_mlp, c.mlp_dim), false, 0, MT3_EPI_RESID, small, s);
@@ -855,8 +848,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
   if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM |
-                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_X_SPLIT_K_TILES |
-                       MT3_OPT_X_SK_WIDE_FOLD))
+                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_X_EIGHT_ROW_GROUPS))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -882,7 +874,7 @@ void mt3_engine_destroy(mt3_engine* e) {
     if (e->cap_stream[k]) (void)hipStreamDestroy(e->cap_stream[k]);
     if (e->cap_event[k]) (void)hipEventDestroy(e->cap_event[k]);
   }
-  for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < kMaxGroups; ++g)
     if (e->part_stream[g]) (void)hipStreamDestroy(e->part_stream[g]);
   if (e->part_begin) (void)hipEventDestroy(e->part_begin);
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
@@ -1209,6 +1201,7 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
 // (Three groups are never better than two or four.)
 static int row_groups_for(const mt3_engine_config& c, int batch) {
   const bool f32 = c.compute_dtype != MT3_BF16;
+  if (f32 && batch >= 256 && (c.options & MT3_OPT_X_EIGHT_ROW_GROUPS)) return 8;
   if (batch >= (f32 ? 256 : 512)) return 4;
   return batch >= 128 ? 2 : 1;
 }

@@ -487,137 +487,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   MT3_PROF_MARK(4);
 }
 
-// ------------------------------------------------------------------ decode-sized tile, split-K, no LDS staging
-// Round 4.  In the ragged (early-exit) regime and inside the row-group schedule the decode GEMMs are pure LATENCY: a
-// 32 x 32 tile pulls its whole K slice (f32: 128 KB) through ONE CU's 64 B/clk L1, stages it in LDS behind two barriers
-// and then runs a dependent MFMA chain (f32, K = 512: 128 x v_mfma_f32_16x16x4_f32 = 1.7 us on one SIMD) -- and a
-// K = 1536 launch does that three to six times in a row (rocprofv3, f32, EOS schedule: the fold launch 18.3 us, GEGLU
-// 12.1, the out-projections 7.4).  This tile turns the trade around: 16 x BN outputs per workgroup (4x the workgroups:
-// the launches have 28 .. 128 of the 32 x 32 ones on 256 CUs), the FOUR waves split K four ways, and every wave loads
-// its operand chunks STRAIGHT from L2 in the MFMA lane layout -- a lane's 16-byte chunk of row (lane & 15) at K-group
-// offset (lane >> 4), exactly what the LDS fragment read delivers in the staged tile -- with all loads of a wave in
-// flight at once (U chunks per round), no LDS staging, no barrier before the MFMAs.  The four partial accumulators meet
-// in 1-3 KB of LDS (fixed order: wave 0 + 1 + 2 + 3, so a row's result does not depend on where it sits) and wave 0 runs
-// the same epilogue code as the staged tile.  Per-element summation order differs from the staged tile's (four K
-// quarters instead of one ascending chain): same function, f32 round-off apart.
-template <typename CT, int BN, int EPI, int NPV, int U>
-__global__ __launch_bounds__(256) void gemm_sk_kernel(GemmArgs g) {
-  constexpr int KPL = CTraits<CT>::KPL, KG = CTraits<CT>::KGROUP;
-  constexpr int FN = BN / 16;
-  static_assert(EPI != MT3_EPI_GEGLU || (FN % 2 == 0), "GEGLU pairs fragments");
-  __shared__ float red[3][FN][4][64];
-  __shared__ float rs_x[16];
-
-  const void* const gA = g.A;
-  const void* const gW = g.Wt;
-  void* const gO = g.out;
-  const int gM = g.M, gN = g.N, gK = g.K, gLda = g.lda, gLdo = g.ldo;
-  const float* const gAss = g.a_ss;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_n = gN / BN;
-  const int lid = xcd_remap(blockIdx.x, gridDim.x);
-  int m0 = (lid / tiles_n) * 16, n0 = (lid % tiles_n) * BN;
-  if (g.n_major) {
-    const int tiles_m = gridDim.x / tiles_n;
-    m0 = (lid % tiles_m) * 16;
-    n0 = (lid / tiles_m) * BN;
-  }
-  constexpr bool kSplitEpi = EPI == kEpiStoreQ || EPI == kEpiResidQ || EPI == kEpiResidS;
-  const int ld2 = kSplitEpi ? (g.ld2 ? g.ld2 : gN - g.n_split) : 0;
-  const bool second = kSplitEpi && n0 >= g.n_split;        // (tile-uniform) this tile belongs to the second product
-  const int kend = EPI == kEpiResidS ? (second ? gK : g.k_split) : gK;
-  const void* const gA2 = EPI == kEpiResidS && second ? g.A2 : nullptr;
-  const int gLda2 = g.lda2, k1 = g.k_split;
-
-  // norm 2: the row's K/16 partial sums of squares, requested first, folded after the K loop (lanes 0 .. 15 of wave 0)
-  float4 pv[NPV];
-  const bool scale_rows = gAss != nullptr && tid < 16;
-  {
-    const int prow = m0 + (tid & 15) < gM ? m0 + (tid & 15) : gM - 1;
-    const float4* p4 = reinterpret_cast<const float4*>(gAss + static_cast<size_t>(prow) * (gK >> 4));
-#pragma unroll
-    for (int u = 0; u < NPV; ++u) pv[u] = (scale_rows && u < (gK >> 6)) ? p4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  // RESID family: wave 0's elements of the rows it will update, requested before the K loop
-  constexpr bool kPre = EPI == MT3_EPI_RESID || EPI == kEpiResidQ || EPI == kEpiResidS;
-  float xpre[1][FN][4];
-  const float* const gResidSrc = g.resid_src ? g.resid_src : static_cast<const float*>(gO);
-  if constexpr (kPre) if (wave == 0 && !(EPI == kEpiResidS && second)) {
-    const float* src = gResidSrc;
-    int ld = gLdo, c0 = n0;
-    if constexpr (EPI == kEpiResidQ) {
-      if (second) {
-        src = g.out2;
-        ld = ld2;
-        c0 = n0 - g.n_split;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = m0 + (lane >> 4) * 4 + r;
-        xpre[0][j][r] = src[static_cast<size_t>(row < gM ? row : gM - 1) * ld + c0 + j * 16 + (lane & 15)];
-      }
-  }
-
-  const int frag_row = lane & 15, frag_g = lane >> 4;
-  const int arow = m0 + frag_row < gM ? m0 + frag_row : gM - 1;      // clamp: such rows are never stored
-  const CT* const a1 = static_cast<const CT*>(gA) + static_cast<size_t>(arow) * gLda + frag_g * KPL;
-  const CT* const a2 = gA2 ? static_cast<const CT*>(gA2) + static_cast<size_t>(arow) * gLda2 + frag_g * KPL : nullptr;
-  const CT* wp[FN];
-#pragma unroll
-  for (int j = 0; j < FN; ++j)
-    wp[j] = static_cast<const CT*>(gW) + static_cast<size_t>(n0 + j * 16 + frag_row) * gK + frag_g * KPL;
-
-  f32x4 acc[1][FN];
-#pragma unroll
-  for (int j = 0; j < FN; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nch = kend / KG / 4;               // K-groups of this wave's quarter
-  const int cb = wave * nch;
-  for (int c0 = 0; c0 < nch; c0 += U) {
-    u32x4 af[U], bf[U][FN];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (c0 + u < nch) {                      // (wave-uniform)
-        const int k = (cb + c0 + u) * KG;
-        af[u] = (a2 != nullptr && k >= k1) ? *reinterpret_cast<const u32x4*>(a2 + (k - k1))
-                                           : *reinterpret_cast<const u32x4*>(a1 + k);
-#pragma unroll
-        for (int j = 0; j < FN; ++j) bf[u][j] = *reinterpret_cast<const u32x4*>(wp[j] + k);
-      }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (c0 + u < nch) {
-#pragma unroll
-        for (int j = 0; j < FN; ++j) mfma_chunk<CT>(af[u], bf[u][j], acc[0][j]);
-      }
-  }
-  if (scale_rows) {
-    float t = 0.f;
-#pragma unroll
-    for (int u = 0; u < NPV; ++u) t = (((t + pv[u].x) + pv[u].y) + pv[u].z) + pv[u].w;    // fixed order per row
-    rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);
-  }
-  if (wave > 0) {
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave - 1][j][r][lane] = acc[0][j][r];
-  }
-  __syncthreads();
-  if (wave > 0) return;
-#pragma unroll
-  for (int q = 0; q < 3; ++q)
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[0][j][r] += red[q][j][r][lane];
-  auto row_rs = [&](int lrow) -> float { return gAss ? rs_x[lrow] : 1.f; };
-  const EpiCtx ec{gO, g.aux, gM, kSplitEpi ? g.n_split : gN, gLdo, g.seq_len, g.out_ct, g.out_ss, g.out2, g.n_split, ld2, gResidSrc};
-  gemm_epilogue<CT, EPI, 1, FN, kPre>(acc, 0, 0, lane, m0, n0, ec, row_rs, xpre);
-}
+// (Round 4 built and measured a second decode-sized tile -- 16 x 16 / 16 x 32 outputs per workgroup, the four waves
+// splitting K four ways and loading their operand chunks straight from L2 in the MFMA lane layout, no LDS staging, one
+// barrier for the 3 KB reduction -- on the theory that the decode GEMMs are pure latency (rocprofv3, f32, EOS schedule:
+// fold launch 18.3 us, GEGLU 12.1, out-projections 7.4).  Parity-green, and SLOWER everywhere: f32 1100 -> 1362 ms per
+// 1024-step decode (1269 with the fold launch on 16 x 32), EOS-schedule decode 380 -> 467 / 450 ms; bf16 590 -> 764 / 693
+// and 212 -> 264 / 254 (profiles/r4_ab_split_k_tiles.txt).  Four times the workgroups re-read four times the operand
+// bytes through the L1s as 64-byte row pieces, and the wider tile losing LESS says the launches are bound by L1 / L2
+// request throughput, not by the dependent chain inside a workgroup.  64-row f32 tiles (one weight fetch per 64-row
+// group: 64 x 16 x 256 for the fold launch, 64 x 32 x 256 for GEGLU) measured 1 % slower as well
+// (profiles/r4_ab_tall_tiles_groups_wait.txt).  The staged 32 x 32 tile stays; both variants were removed again.)
 
 // ------------------------------------------------------------------ encoder-sized tile, LDS-DMA staged (bf16)
 // 128x128x32 tile, 2x2 waves of 64x64 (4x4 MFMA fragments), both operands bf16 in memory.  The encoder GEMMs have
@@ -939,40 +818,11 @@ static int launch_small(const GemmArgs& g, hipStream_t s) {
   return launch_cfg<CT, BM, BN, BK, 2, 2, A_F32, NORM, EPI, NPV>(g, s);
 }
 
-// the split-K decode tile: 16 x 16 outputs per workgroup (GEGLU: 16 x 32, the gate | linear fragment pair; g.sk & 2: the
-// two-source fold launch on 16 x 32 as well)
-template <typename CT, int EPI>
-static int launch_sk(const GemmArgs& g, hipStream_t s) {
-  constexpr int KG = CTraits<CT>::KGROUP;
-  const bool wide = EPI == MT3_EPI_GEGLU || (EPI == kEpiResidS && (g.sk & 2));
-  const int bn = wide ? 32 : 16;
-  if (g.N % bn || (g.n_split && g.n_split % bn)) return mt3::fail(MT3_ERR_INVALID, "gemm: N / n_split not a multiple of the split-K tile");
-  if (g.a_ss && g.K > 1024) return mt3::fail(MT3_ERR_INVALID, "gemm: K too large for the split-K tile's partial-sum registers");
-  const dim3 grid(((g.M + 15) / 16) * (g.N / bn)), block(256);
-  // U = K-groups in flight per wave: a wave's quarter of K = 1536 is 24 (f32) / 12 (bf16) groups
-  constexpr int U1 = KG == 16 ? 12 : 6, U2 = KG == 16 ? 8 : 4;
-  if constexpr (EPI == MT3_EPI_GEGLU) {
-    hipLaunchKernelGGL((gemm_sk_kernel<CT, 32, EPI, 16, U2>), grid, block, 0, s, g);
-  } else if constexpr (EPI == kEpiResidS) {
-    if (wide) hipLaunchKernelGGL((gemm_sk_kernel<CT, 32, EPI, 1, U2>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_sk_kernel<CT, 16, EPI, 1, U1>), grid, block, 0, s, g);
-  } else {
-    hipLaunchKernelGGL((gemm_sk_kernel<CT, 16, EPI, 1, U1>), grid, block, 0, s, g);
-  }
-  MT3_HIP_CHECK(hipGetLastError());
-  return MT3_OK;
-}
-
 template <typename CT, bool A_F32, bool NORM, int EPI>
 static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
   constexpr int KG = CTraits<CT>::KGROUP;
   if (small) {
     const bool deep = g.K % (16 * KG) == 0;
-    if constexpr (!NORM && !A_F32 && (EPI == MT3_EPI_RESID || EPI == kEpiResidQ || EPI == kEpiResidS || EPI == MT3_EPI_GEGLU)) {
-      if (g.sk && g.K % (4 * KG) == 0 && (EPI != kEpiResidS || g.k_split % (4 * KG) == 0) &&
-          (EPI == MT3_EPI_GEGLU ? g.a_ss != nullptr : g.a_ss == nullptr))
-        return launch_sk<CT, EPI>(g, s);
-    }
     // (measured and removed, DESIGN.md section 3: the two-source fold launch on 32 x 64 tiles -- 25 % fewer operand
     // bytes through a CU's L1 but one workgroup per CU, slower; eight-wave split-K f32 tiles, slower)
     if constexpr (!NORM && !A_F32 && KG == 32 && EPI != MT3_EPI_HEADS && EPI != MT3_EPI_POS) {

@@ -41,9 +41,6 @@ struct GemmArgs {
   // tile -> XCD dealing: 0 = an XCD owns a run of row blocks (all weight columns pass through its L2), 1 = an XCD
   // owns a run of weight-column tiles for ALL row blocks (its L2 sees 1/8 of the weights; set by launch_gemm)
   int n_major;
-  // decode-sized RESID-family / GEGLU launches on the split-K tile (gemm_sk_kernel): 1 = 16 x 16 (GEGLU 16 x 32),
-  // 3 = the two-source fold launch on 16 x 32 as well
-  int sk;
 };
 // internal epilogues (not part of the C ABI): STORE / RESID with a second f32 output region, see GemmArgs::out2
 constexpr int kEpiStoreQ = 6, kEpiResidQ = 7, kEpiResidS = 8;

@@ -283,15 +283,12 @@ def test_f32_engine_variants_agree_at_f32_round_off():
     outs = {}
     if True:
         for name, opt in (("r3", 0), ("q-fold only", _lib.OPT_SEPARATE_QKV_PROJECTION),
-                          ("split-K tiles", _lib.OPT_X_SPLIT_K_TILES),
-                          ("split-K tiles, wide fold", _lib.OPT_X_SPLIT_K_TILES | _lib.OPT_X_SK_WIDE_FOLD),
-                          ("split-K tiles, separate qkv", _lib.OPT_X_SPLIT_K_TILES | _lib.OPT_SEPARATE_QKV_PROJECTION),
                           ("separate projections", _lib.OPT_SEPARATE_PROJECTIONS),
                           ("r2 path", _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_SEPARATE_PROJECTIONS)):
             eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=opt)
             eng.load_params(params)
             assert eng.status(_lib.STATUS_Q_FOLD) == (0 if opt & (_lib.OPT_SEPARATE_PROJECTIONS | _lib.OPT_SINGLE_RESIDUAL_STREAM) else 1)
-            assert eng.status(_lib.STATUS_QKV_FOLD) == (1 if opt & ~(_lib.OPT_X_SPLIT_K_TILES | _lib.OPT_X_SK_WIDE_FOLD) == 0 else 0)
+            assert eng.status(_lib.STATUS_QKV_FOLD) == (1 if opt == 0 else 0)
             assert eng.status(_lib.STATUS_RESIDUAL_SPLIT) == (0 if opt & _lib.OPT_SINGLE_RESIDUAL_STREAM else 1)
             eng.encode(torch.from_numpy(x).cuda())
             ids, logits = eng.decode_forced(forced, num_steps=S)
@@ -302,8 +299,7 @@ def test_f32_engine_variants_agree_at_f32_round_off():
             g = eng.decode(num_steps=24).cpu().numpy()
             outs[name + " ids"] = g
             del eng
-    for name in ("r3", "q-fold only", "split-K tiles", "split-K tiles, wide fold", "split-K tiles, separate qkv",
-                 "separate projections"):
+    for name in ("r3", "q-fold only", "separate projections"):
         d = _rel_rows(outs[name], outs["r2 path"])
         print(f"f32 engine [{name}] vs the r2 path: max rel-L2 {d.max():.3e}")
         assert d.max() < 2e-5, (name, d.max())
@@ -330,8 +326,6 @@ def test_folded_qkv_projection_bf16_and_fp8_caches_against_the_separate_launches
         cfg = dataclasses.replace(network.T5Config(), dtype="bfloat16", kv_dtype=kv)
         outs = {}
         for name, opt in (("folded", 0), ("q-fold only", _lib.OPT_SEPARATE_QKV_PROJECTION),
-                          ("folded, split-K tiles", _lib.OPT_X_SPLIT_K_TILES),
-                          ("folded, split-K tiles, wide fold", _lib.OPT_X_SPLIT_K_TILES | _lib.OPT_X_SK_WIDE_FOLD),
                           ("separate", _lib.OPT_SEPARATE_PROJECTIONS)):
             eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, options=opt)
             eng.load_params(params)
@@ -354,7 +348,7 @@ def test_folded_qkv_projection_bf16_and_fp8_caches_against_the_separate_launches
                 assert np.array_equal(d1, d2)
                 assert eng.status(_lib.STATUS_GRAPH_FALLBACKS) == 0
             del eng
-        for name in ("folded", "q-fold only", "folded, split-K tiles", "folded, split-K tiles, wide fold"):
+        for name in ("folded", "q-fold only"):
             d = _rel_rows(outs[name], outs["separate"])
             print(f"kv {kv or 'bf16'} [{name}] vs separate launches: max {d.max():.3e} median {np.median(d):.3e}")
             assert d.max() < (2e-2 if not kv else 5e-2) and np.median(d) < 8e-3, (kv, name, d.max(), np.median(d))
@@ -402,7 +396,7 @@ def test_row_group_decode_schedule_is_bit_identical():
 
 
 @pytest.mark.parametrize("dtype,B,groups,options", [
-    ("float32", 259, 4, 0), ("float32", 130, 2, 0), ("bfloat16", 515, 4, 0),
+    ("float32", 259, 4, 0), ("float32", 130, 2, 0), ("bfloat16", 515, 4, 0), ("float32", 261, 8, _lib.OPT_X_EIGHT_ROW_GROUPS),
     ("float32", 257, 4, _lib.OPT_SINGLE_RESIDUAL_STREAM | _lib.OPT_SEPARATE_PROJECTIONS)])
 def test_row_group_counts_follow_operand_type_and_batch(dtype, B, groups, options):
     """The group count of the schedule (engine.hip: row_groups_for -- bf16 operands: 2 groups from 128 rows, 4 from

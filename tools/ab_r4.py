@@ -20,12 +20,8 @@ B = int(os.environ.get("AB_B", "256"))
 REPS = int(os.environ.get("AB_REPS", "2"))
 K = _lib
 VARIANTS = [
-    ("f32 default (staged 32 x 32 tiles)", "float32", 0),
-    ("f32 split-K tiles", "float32", K.OPT_X_SPLIT_K_TILES),
-    ("f32 split-K tiles, wide fold", "float32", K.OPT_X_SPLIT_K_TILES | K.OPT_X_SK_WIDE_FOLD),
-    ("bf16 default (staged 32 x 32 tiles)", "bfloat16", 0),
-    ("bf16 split-K tiles", "bfloat16", K.OPT_X_SPLIT_K_TILES),
-    ("bf16 split-K tiles, wide fold", "bfloat16", K.OPT_X_SPLIT_K_TILES | K.OPT_X_SK_WIDE_FOLD),
+    ("f32 default (4 row groups)", "float32", 0),
+    ("f32 eight row groups", "float32", K.OPT_X_EIGHT_ROW_GROUPS),
 ]
 want = sys.argv[1:]
 stream = torch.cuda.Stream()
