@@ -144,10 +144,7 @@ enum {
    * cross-attention query stays folded */
   MT3_OPT_SEPARATE_QKV_PROJECTION = 8,
   /* never use the row-group decode schedule (see mt3_engine_decode): every decode stays on the caller's stream */
-  MT3_OPT_NO_ROW_GROUPS = 16,
-  /* ---- round-4 experiment bit (measured in tools/ab_r4.py; becomes the default or goes) ----
-   * f32 engine, batches of >= 256 rows: EIGHT row groups of >= 32 rows instead of four */
-  MT3_OPT_X_EIGHT_ROW_GROUPS = 32
+  MT3_OPT_NO_ROW_GROUPS = 16
 };
 
 typedef struct mt3_engine mt3_engine;

@@ -92,7 +92,7 @@ struct LayerDev {
 // 4 = beam-1 token selection, 8 = teacher forcing, 16 = row retirement (finished slots cost nothing, the slot map is
 // in use), 32 = the synthetic EOS schedule (mt3_debug_engine_set_eos_schedule)
 constexpr int kVarBeam = 4, kVarForced = 8, kVarRetire = 16, kVarEos = 32, kNumVariants = 64;
-constexpr int kMaxGroups = 8;
+constexpr int kMaxGroups = 4;
 
 // One persistent host thread per row group (created with the first decode that needs it, joined at destroy): a
 // decode call hands each group's loop to one of them instead of spawning threads per call, and with
@@ -848,7 +848,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
   if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM |
-                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_X_EIGHT_ROW_GROUPS))
+                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -1198,10 +1198,11 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
 // Row groups of the product decode schedule (mt3_engine::part_stream).  Measured on MI355X, ms per 1024-step decode,
 // 1 / 2 / 4 groups (profiles/r3_ab_row_groups_*.txt): bf16 B = 256: 626 / 588 / 608, B = 512: 1113 / 1048 / 1013;
 // f32 B = 128: 747 / 684 / 737, B = 256: 1178 / 1132 / 1098 -- groups of ~128 rows for bf16 operands, ~64 for f32.
-// (Three groups are never better than two or four.)
+// (Three groups are never better than two or four.  EIGHT groups of 32 rows -- round 4, f32, B = 256: 2307 ms against
+// 1098 with four, the EOS-schedule decode 1052 against 380 ms, profiles/r4_ab_eight_row_groups.txt: beyond four streams
+// with queues of their own the hardware queues are oversubscribed and the groups take turns.)
 static int row_groups_for(const mt3_engine_config& c, int batch) {
   const bool f32 = c.compute_dtype != MT3_BF16;
-  if (f32 && batch >= 256 && (c.options & MT3_OPT_X_EIGHT_ROW_GROUPS)) return 8;
   if (batch >= (f32 ? 256 : 512)) return 4;
   return batch >= 128 ? 2 : 1;
 }

@@ -21,7 +21,7 @@ REPS = int(os.environ.get("AB_REPS", "2"))
 K = _lib
 VARIANTS = [
     ("f32 default (4 row groups)", "float32", 0),
-    ("f32 eight row groups", "float32", K.OPT_X_EIGHT_ROW_GROUPS),
+    ("bf16 default (2 row groups)", "bfloat16", 0),
 ]
 want = sys.argv[1:]
 stream = torch.cuda.Stream()
