@@ -174,7 +174,7 @@ def test_engine_mx8_encoder_within_bounds(setup, kv):
     """Encoder on MXFP8 vs the f32 oracle.  e4m3 keeps 3 mantissa bits (rounding noise ~2.6 % rms per operand), so
     every GEMM output carries ~3.7 % relative noise whatever its K, and 16 of them feed the residual stream: measured
     on the random-init MT3 shape rel-L2 5.6-9.2e-2 per segment, cosine 0.9958-0.9984 (bf16 path: 6-8e-3).
-    Bounds: rel-L2 < 1.3e-1, cosine > 0.992; step-0 logits rel-L2 < 2e-1 (bf16 path: 3e-2)."""
+    Bounds: rel-L2 < 1.3e-1, cosine > 0.992; step-0 logits rel-L2 < 1e-1 (bf16 path: 3e-2)."""
     cfg = dataclasses.replace(network.T5Config(), dtype="bfloat16", dense_dtype="fp8_e4m3", kv_dtype=kv)
     eng = network.Transformer(cfg, input_length=T, max_decode_length=L, max_batch=3)
     eng.load_params(setup["params"])
@@ -190,7 +190,7 @@ def test_engine_mx8_encoder_within_bounds(setup, kv):
     ids, logits0 = eng.decode(num_steps=8, return_first_logits=True)
     r = rel(logits0.cpu().numpy(), setup["logits_ref"][:, 0])
     print(f"mx8 encoder (kv {kv or 'bf16'}): step-0 logits rel-L2 {r:.3e}")
-    assert r < 2e-1, f"step-0 logits rel-L2 {r}"
+    assert r < 1e-1, f"step-0 logits rel-L2 {r}"          # measured 5.1e-2 (round 4: bound tightened from 2e-1)
     # the bf16 engine on the same weights is the nearer neighbour: both engines agree on every comfortable argmax
     ref_eng = network.Transformer(dataclasses.replace(cfg, dense_dtype=""), input_length=T, max_decode_length=L, max_batch=3)
     ref_eng.load_params(setup["params"])

@@ -56,10 +56,12 @@ def _teacher_forced_ref(orc, x, forced):
 
 
 def test_configs4_as_benched_base_shape_mxfp8_and_fp8_caches_together():
-    """What `bench.py`'s `extra.configs4` line times: base.gin shape + dense_dtype fp8 + kv_dtype fp8.  Bounds (stated
-    before measuring, from the two halves' own tests: MXFP8 encoder 1.3e-1, fp8 caches 8e-2 at this shape):
-    encoder rel-L2 < 1.5e-1 per segment, teacher-forced logits rel-L2 < 2.5e-1 at every one of 160 positions, no
-    drift with depth; the bf16 engine of the same shape is the nearer neighbour (printed)."""
+    """What `bench.py`'s `extra.configs4` line times: base.gin shape + dense_dtype fp8 + kv_dtype fp8.  Bounds: round 3
+    stated them before measuring (encoder 1.5e-1, logits 2.5e-1) and measured encoder 6.5-9.6e-2, logits max 7.6e-2 / mean
+    6.4e-2; round 4 holds the test to what is measured plus a margin for other seeds -- encoder rel-L2
+    < 1.2e-1 per segment, teacher-forced logits rel-L2 < 1e-1 at every one of 160 positions, mean < 8e-2 -- so that a
+    regression of the MXFP8 / e4m3 path fails it; no drift with depth; the bf16 engine of the same shape is the nearer
+    neighbour (printed)."""
     base = dataclasses.replace(network.MT3_BASE, dtype="bfloat16")
     params = network.init_random_params(base, seed=2, norm_scale_jitter=0.1)
     B, S = 4, 160
@@ -87,8 +89,8 @@ def test_configs4_as_benched_base_shape_mxfp8_and_fp8_caches_together():
     print(f"configs[4] as benched (base.gin + MXFP8 dense + e4m3 caches), B={B}, {S} positions: encoder rel-L2 "
           f"{np.round(re, 4)}; teacher-forced logits vs f32 oracle max {r.max():.3e} mean {r.mean():.3e} "
           f"(bf16 engine of the same shape: max {r16.max():.3e} mean {r16.mean():.3e})")
-    assert max(re) < 1.5e-1, re
-    assert r.max() < 2.5e-1, r.max()
+    assert max(re) < 1.2e-1, re
+    assert r.max() < 1e-1 and r.mean() < 8e-2, (r.max(), r.mean())
     assert r[-32:].mean() < 1.5 * r[:32].mean() + 1e-2, (r[:32].mean(), r[-32:].mean())
     top2 = np.partition(ref, -2, axis=-1)[..., -2:]
     safe = (top2[..., 1] - top2[..., 0]) > 0.6 * ref.std(-1)
@@ -99,8 +101,8 @@ def test_configs4_as_benched_base_shape_mxfp8_and_fp8_caches_together():
 def test_mxfp8_engine_teacher_forced_all_1024_positions():
     """MT3 shape, dense_dtype fp8 (MXFP8 encoder + MXFP8 cross-K/V projections), bf16 and e4m3 caches: logits at ALL
     1024 cache positions vs the f32 oracle.  The decoder's own dense layers are bf16; what this checks at depth is
-    that the MXFP8-made `encoded` and cross-K/V do not make the error grow with the cache position.  Bounds: 2e-1 at
-    every (step, row) (the step-0 bound of tests/test_gpu_mx8.py), last 64 positions no worse than 1.5x the first 64."""
+    that the MXFP8-made `encoded` and cross-K/V do not make the error grow with the cache position.  Bounds: 1.4e-1 at
+    every (step, row), mean 9e-2 (round 4: what is measured plus a margin -- the stated-in-advance 2e-1 could not fail), last 64 positions no worse than 1.5x the first 64."""
     cfg32 = network.T5Config(dtype="float32")
     params = network.init_random_params(cfg32, seed=0, norm_scale_jitter=0.2)
     B = 4
@@ -120,7 +122,7 @@ def test_mxfp8_engine_teacher_forced_all_1024_positions():
         agree = float((logits.argmax(-1) == ref.argmax(-1)).mean())
         print(f"MXFP8 engine (kv {kv or 'bf16'}), teacher-forced, {B} x 1024 positions: rel-L2 max {r.max():.3e} mean "
               f"{r.mean():.3e}; first/last 64: {r[:64].mean():.3e} / {r[-64:].mean():.3e}; arg-max agreement {agree:.4f}")
-        assert r.max() < 2e-1, r.max()
+        assert r.max() < 1.4e-1 and r.mean() < 9e-2, (r.max(), r.mean())     # measured (r3): max 1.04e-1, mean 6.7e-2
         assert r[-64:].mean() < 1.5 * r[:64].mean() + 5e-3
         del eng
 
