@@ -133,6 +133,47 @@ def transcription_scores(ref_ns: NoteSequence, est_ns: NoteSequence, pitch_unit:
     return out
 
 
+def program_aware_note_scores(ref_ns: NoteSequence, est_ns: NoteSequence, granularity_type: str = "full") -> Dict[str, float]:
+    """mt3/metrics.py:35-147 `_program_aware_note_scores`: non-drum programs mapped by the granularity's `program_map_fn`,
+    then per (program, is_drum) track (`note_sequences.extract_track`) one `precision_recall_f1_overlap` call -- onsets +
+    offsets for non-drum tracks, onsets only for drum tracks (`offset_ratio=None`) -- and precision / recall averaged over
+    tracks weighted by their numbers of estimated / reference notes; F from the averaged pair.  Pitches go to the 50-cent
+    rule as note NUMBERS, as everywhere in the reference (module docstring).  A track that one side lacks scores 0 there
+    (mir_eval returns zeros for an empty side)."""
+    from . import vocabularies
+    pmap = vocabularies.PROGRAM_MAP_FNS[granularity_type]
+
+    def tracks(ns):
+        out = {}
+        for n in ns.notes:
+            key = (n.program if n.is_drum else pmap(n.program), bool(n.is_drum))
+            out.setdefault(key, []).append(n)
+        return out
+    ref_t, est_t = tracks(ref_ns), tracks(est_ns)
+    sums = {True: [0.0, 0, 0.0, 0], False: [0.0, 0, 0.0, 0]}          # is_drum -> [P sum, P count, R sum, R count]
+    for key in set(ref_t) | set(est_t):
+        is_drum = key[1]
+        ri, rp, _ = sequence_to_valued_intervals(NoteSequence(notes=ref_t.get(key, [])))
+        ei, ep, _ = sequence_to_valued_intervals(NoteSequence(notes=est_t.get(key, [])))
+        p, r, _ = precision_recall_f1_overlap(ri, rp, ei, ep, **({"offset_ratio": None} if is_drum else {}))
+        acc = sums[is_drum]
+        acc[0] += p * len(ei)
+        acc[1] += len(ei)
+        acc[2] += r * len(ri)
+        acc[3] += len(ri)
+
+    def prf(ps, pc, rs, rc):
+        p, r = (ps / pc) if pc else 0, (rs / rc) if rc else 0
+        return p, r, f_measure(p, r)
+    d, nd = sums[True], sums[False]
+    g = granularity_type
+    out = {}
+    for name, (p, r, f) in (("Onset + offset + program", prf(d[0] + nd[0], d[1] + nd[1], d[2] + nd[2], d[3] + nd[3])),
+                            ("Drum onset", prf(*d)), ("Nondrum onset + offset + program", prf(*nd))):
+        out[f"{name} precision ({g})"], out[f"{name} recall ({g})"], out[f"{name} F1 ({g})"] = p, r, f
+    return out
+
+
 # ------------------------------------------------------------------------------- precision-mode divergence report
 def token_stream_divergence(ref_tokens: np.ndarray, est_tokens: np.ndarray, codec=None, encoding_spec=None,
                             segment_seconds: float = 2.048) -> Dict[str, float]:

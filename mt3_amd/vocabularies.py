@@ -124,3 +124,13 @@ def vocabulary_from_codec(codec: event_codec.Codec) -> GenericTokenVocabulary:
 
 def num_embeddings(vocabulary: GenericTokenVocabulary) -> int:
     return 128 * math.ceil(vocabulary.vocab_size / 128)
+
+
+# mt3/vocabularies.py:94-117: the NoteSequence side of a program granularity (`program_map_fn`, idempotent); the token
+# side (`tokens_map_fn`: drop_programs / programs_to_midi_classes) belongs to the training data pipeline, which is out of
+# this path's scope.
+PROGRAM_MAP_FNS = {
+    "flat": lambda program: 0,                             # programs ignored
+    "midi_class": lambda program: 8 * (program // 8),      # first program of the MIDI class
+    "full": lambda program: program,
+}

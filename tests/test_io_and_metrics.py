@@ -2,6 +2,7 @@
 import itertools
 
 import numpy as np
+import pytest
 
 from mt3_amd import audio_io, metrics, midi_io
 from mt3_amd.note_sequences import Note, NoteSequence
@@ -127,6 +128,34 @@ def test_the_reference_passes_note_numbers_to_the_cents_rule():
     assert metrics.transcription_scores(ref, est, pitch_unit="hz")["Onset F1"] == 0.0
     iv, pitches, vel = metrics.sequence_to_valued_intervals(ref, drums=False)
     assert list(pitches) == [60.0, 34.0] and iv.shape == (2, 2)
+
+
+def test_program_aware_note_scores_follow_the_reference_weighting():
+    """mt3/metrics.py:35-147: per (mapped program, is_drum) track one overlap score -- offsets ignored for drums --,
+    precision weighted by estimated notes, recall by reference notes; the granularity maps programs first."""
+    ref = NoteSequence(notes=[Note(0.0, 1.0, 60, 100, 0), Note(1.0, 2.0, 62, 100, 0),          # piano (program 0): 2 notes
+                              Note(0.0, 1.0, 50, 100, 41),                                     # viola (41)
+                              Note(0.5, 0.6, 38, 100, 0, True, 9), Note(1.5, 1.6, 42, 100, 0, True, 9)])
+    est = NoteSequence(notes=[Note(0.0, 1.0, 60, 100, 0),                                      # piano: 1 of 2 found
+                              Note(0.0, 1.0, 50, 100, 40),                                     # violin (40) instead of viola
+                              Note(0.5, 0.9, 38, 100, 0, True, 9)])                            # drum onset right, offset ignored
+    full = metrics.program_aware_note_scores(ref, est, "full")
+    # non-drum tracks: program 0 (P 1/1, R 1/2), 40 (P 0/1), 41 (R 0/1) -> P = 1/2, R = 1/3; drums P 1/1, R 1/2
+    assert abs(full["Nondrum onset + offset + program precision (full)"] - 0.5) < 1e-12
+    assert abs(full["Nondrum onset + offset + program recall (full)"] - 1 / 3) < 1e-12
+    assert full["Drum onset precision (full)"] == 1.0 and full["Drum onset recall (full)"] == 0.5
+    assert abs(full["Onset + offset + program precision (full)"] - 2 / 3) < 1e-12          # (1 + 0 + 1) / 3 estimated notes
+    assert abs(full["Onset + offset + program recall (full)"] - 2 / 5) < 1e-12             # (1 + 0 + 1) / 5 reference notes
+    # midi_class: 40 and 41 both map to 40 -> the string note matches
+    mc = metrics.program_aware_note_scores(ref, est, "midi_class")
+    assert mc["Nondrum onset + offset + program precision (midi_class)"] == 1.0
+    assert abs(mc["Nondrum onset + offset + program recall (midi_class)"] - 2 / 3) < 1e-12
+    flat = metrics.program_aware_note_scores(ref, est, "flat")
+    assert flat["Nondrum onset + offset + program F1 (flat)"] == mc["Nondrum onset + offset + program F1 (midi_class)"]
+    empty = metrics.program_aware_note_scores(NoteSequence(notes=[]), NoteSequence(notes=[]), "full")
+    assert all(v == 0 for v in empty.values())
+    with pytest.raises(ValueError):
+        metrics.precision_recall_f1_overlap([[0.0, 1.0]], [0.0], [[0.0, 1.0]], [60.0])         # mir_eval.validate: pitch > 0
 
 
 def test_token_stream_divergence_report():
