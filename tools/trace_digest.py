@@ -42,3 +42,45 @@ for (kind, wgs), d in sorted(groups.items()):
         line += "; last pass by step t=0,15,63,127,255,511,767,1023: %s" % [round(per[i], 1) for i in
                                                                             (0, 15, 63, 127, 255, 511, 767, 1023)]
     print(line)
+
+# ---- concurrency inside the row-group schedule: the decode-attention launches of the row groups have a smaller grid than
+# the full-batch roofline passes; bursts of them (gaps < 5 ms) are the product-schedule decodes.  Inside those bursts: how
+# much of the wall time has k attention kernels in flight (k = 0: the HBM stream is idle), and how much has no kernel at all.
+attn = [(s, e, grid // max(wg, 1)) for s, e, n, grid, wg in rows if "dec_attn" in n]
+if attn:
+    full = max(w for _, _, w in attn)
+    small = sorted((s, e) for s, e, w in attn if w < full)
+    if small:
+        bursts, cur = [], [small[0][0], small[0][1]]
+        for s, e in small[1:]:
+            if s - cur[1] > 5_000_000:
+                bursts.append(cur)
+                cur = [s, e]
+            cur[1] = max(cur[1], e)
+        bursts.append(cur)
+        bursts = [b for b in bursts if b[1] - b[0] > 50_000_000]            # whole decodes only (> 50 ms)
+        hist, idle, span = defaultdict(float), 0.0, 0.0
+        for b0, b1 in bursts:
+            ev = []
+            for s, e, n, grid, wg in rows:
+                if e <= b0 or s >= b1:
+                    continue
+                is_attn = 1 if "dec_attn" in n else 0
+                ev.append((max(s, b0), 1, is_attn))
+                ev.append((min(e, b1), -1, is_attn))
+            ev.sort()
+            k_all = k_attn = 0
+            last = b0
+            for t, d, a in ev:
+                dt = t - last
+                hist[k_attn] += dt
+                if k_all == 0:
+                    idle += dt
+                last = t
+                k_all += d
+                k_attn += d * a
+            span += b1 - b0
+        if span:
+            print("row-group decodes: %d bursts, %.1f ms; share of wall time with k decode-attention kernels in flight: %s; "
+                  "no kernel at all in flight: %.3f" % (len(bursts), span / 1e6,
+                                                         {k: round(v / span, 3) for k, v in sorted(hist.items())}, idle / span))
