@@ -42,9 +42,6 @@ int mt3_debug_engine_set_eos_schedule(mt3_engine* e, const int32_t* h_lengths, i
  * return exactly the ids it returns over zero-filled caches. */
 int mt3_debug_engine_poison_caches(mt3_engine* e, int32_t pattern, int32_t cross, void* stream);
 
-/* EXPERIMENT (round 4, to be removed): waves per (row, head) workgroup of the bf16 / f32 decode attention (3 default) */
-int mt3_debug_set_attn_waves(int32_t n);
-
 /* (Rounds 2-3 had thirteen process-wide launch-shape knobs here -- mt3_debug_set_knob -- and a row-group experiment
  * entry, mt3_debug_engine_decode_split.  What they measured is recorded in DESIGN.md sections 3 and 5 and under
  * profiles/r3_ab_*; the variants that lost are no longer compiled into the library, the ones that won are the code.) */

@@ -84,7 +84,6 @@ SIGNATURES = {
     "mt3_debug_engine_decode": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mt3_debug_engine_poison_caches": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "mt3_debug_engine_set_eos_schedule": (C.c_int, [_P, _P, C.c_int32]),
-    "mt3_debug_set_attn_waves": (C.c_int, [C.c_int32]),
     "mt3_ids_to_tokens": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     "mt3_op_gemm": (C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32,
                               C.c_int32, _P, C.c_int32, C.c_int32, _P]),

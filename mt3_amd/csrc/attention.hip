@@ -902,9 +902,6 @@ int launch_kv_quantize_fp8(const void* src_bf16, void* dst_fp8, void* scales, in
   return MT3_OK;
 }
 
-static int g_attn_waves = 0;       // EXPERIMENT (round 4), see below
-void set_attn_waves(int n) { g_attn_waves = n; }
-
 int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
   if ((!a.q && !a.q_f32) || !a.kcache || !a.vcache || !a.out || a.B <= 0 || a.H <= 0 || a.cap <= 0)
     return mt3::fail(MT3_ERR_INVALID, "decode_attention: bad arguments");
@@ -929,18 +926,9 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
     MT3_HIP_CHECK(hipGetLastError());
     return MT3_OK;
   }
-  // EXPERIMENT (round 4): waves per (row, head) workgroup for the non-fp8 kernels: g_attn_waves (mt3_debug_set_attn_waves)
-  const int nw = g_attn_waves ? g_attn_waves : 3;
-  const dim3 grid(a.B * a.H), block(nw * 64);
-#define MT3_LAUNCH_NW(CT, AP, Q)                                                              \
-  do {                                                                                        \
-    if (nw == 3) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 3, Q>), grid, block, 0, s, a);        \
-    else if (nw == 4) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 4, Q>), grid, block, 0, s, a);   \
-    else if (nw == 6) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 6, Q>), grid, block, 0, s, a);   \
-    else hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 8, Q>), grid, block, 0, s, a);                \
-  } while (0)
-#define MT3_LAUNCH_DEC(CT, AP) MT3_LAUNCH_NW(CT, AP, false)
-#define MT3_LAUNCH_DEC_Q(CT, AP) MT3_LAUNCH_NW(CT, AP, true)
+  const dim3 grid(a.B * a.H), block(3 * 64);
+#define MT3_LAUNCH_DEC(CT, AP) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 3>), grid, block, 0, s, a)
+#define MT3_LAUNCH_DEC_Q(CT, AP) hipLaunchKernelGGL((dec_attn_kernel<CT, AP, 3, true>), grid, block, 0, s, a)
   if (dtype == MT3_BF16 && a.q_f32) {
     if (append) MT3_LAUNCH_DEC_Q(__bf16, true);
     else MT3_LAUNCH_DEC_Q(__bf16, false);
@@ -957,7 +945,6 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
     return mt3::fail(MT3_ERR_INVALID, "decode_attention: unknown dtype");
   }
 #undef MT3_LAUNCH_DEC
-#undef MT3_LAUNCH_NW
 #undef MT3_LAUNCH_DEC_Q
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
@@ -1013,12 +1000,6 @@ int mt3_op_decode_attention_fp8(const void* d_q, int32_t q_stride, void* d_kcach
   a.B = B;
   a.H = H;
   return mt3k::launch_decode_attention(MT3_BF16, a, static_cast<hipStream_t>(stream));
-}
-
-int mt3_debug_set_attn_waves(int32_t n) {       // EXPERIMENT (round 4): 0 = default
-  if (n != 0 && n != 3 && n != 4 && n != 6 && n != 8) return mt3::fail(MT3_ERR_INVALID, "attn waves: 0, 3, 4, 6 or 8");
-  mt3k::set_attn_waves(n);
-  return MT3_OK;
 }
 
 int mt3_op_kv_quantize_fp8(const void* d_src, void* d_dst, void* d_scales, int32_t rows, void* stream) {
