@@ -221,7 +221,6 @@ def main():
     ap.add_argument("--cpu-small-segments", type=int, default=32, help="batch of the CPU batch-scaling probe (0: skip)")
     ap.add_argument("--cpu-enc-segments", type=int, default=64)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--engine-options", type=int, default=0, help=argparse.SUPPRESS)      # mt3_engine_config.options (A/B)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print("CPU_BASELINE " + json.dumps(cpu_baseline(args.cpu_segments, args.decode_steps, args.cpu_enc_segments,
@@ -261,8 +260,7 @@ def main():
     import dataclasses
     shape = network.MT3_BASE if args.model == "base" else network.MT3_SMALL
     cfg = dataclasses.replace(shape, dtype=args.dtype, kv_dtype=args.kv_dtype, dense_dtype=args.dense_dtype)
-    eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, decode_chains=args.chains,
-                              options=args.engine_options)
+    eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, decode_chains=args.chains)
     eng.load_params(network.init_random_params(cfg, seed=0))
     codec = vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1))
     vocab = vocabularies.vocabulary_from_codec(codec)

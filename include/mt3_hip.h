@@ -144,11 +144,7 @@ enum {
    * cross-attention query stays folded */
   MT3_OPT_SEPARATE_QKV_PROJECTION = 8,
   /* never use the row-group decode schedule (see mt3_engine_decode): every decode stays on the caller's stream */
-  MT3_OPT_NO_ROW_GROUPS = 16,
-  /* ---- round-4 experiment bits (tools/ab_r4.py): an encode beside a decode in flight runs on a stream restricted to
-   * every FOURTH compute unit; ..._ON_HALF: every second one; ..._UNMASKED: on the caller's stream, all CUs */
-  MT3_OPT_X_ENCODE_ON_HALF = 32,
-  MT3_OPT_X_ENCODE_UNMASKED = 64
+  MT3_OPT_NO_ROW_GROUPS = 16
 };
 
 typedef struct mt3_engine mt3_engine;

@@ -249,13 +249,6 @@ struct mt3_engine {
   int enc_slot = 0;              // cross-K/V slot of the most recent encode
   int slot_batch[2] = {0, 0};    // batch of the encode that filled each slot
   hipEvent_t enc_done[2] = {};   // recorded on the encode's stream: a decode orders itself after the encode of its slot
-  // An encode that arrives while a decode is in flight runs on an engine-owned stream restricted to a QUARTER of the
-  // compute units (every fourth one): left on all of them, the encoder's thousands of workgroups hold enough LDS on every
-  // CU that the decode's 133 KB GEMM tiles never find room and the decode stalls for the length of the encode (measured:
-  // the unrestricted overlap gained nothing, 1131.5 against 1133.8 ms per step); the decode is HBM- / latency-bound and
-  // does not miss the CUs, the encoder takes 4x as long and still ends long before the decode does.
-  hipStream_t enc_stream = nullptr;
-  hipEvent_t enc_begin = nullptr;
   int cur_batch = 0;             // batch of the most recent encode (= slot_batch[enc_slot])
   hipStream_t cap_stream[8] = {};     // one capture stream per chain (kMaxChains)
   hipEvent_t cap_event[8] = {};
@@ -864,7 +857,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
   if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM |
-                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_X_ENCODE_ON_HALF | MT3_OPT_X_ENCODE_UNMASKED))
+                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -895,8 +888,6 @@ void mt3_engine_destroy(mt3_engine* e) {
   if (e->part_begin) (void)hipEventDestroy(e->part_begin);
   for (int xs = 0; xs < 2; ++xs)
     if (e->enc_done[xs]) (void)hipEventDestroy(e->enc_done[xs]);
-  if (e->enc_stream) (void)hipStreamDestroy(e->enc_stream);
-  if (e->enc_begin) (void)hipEventDestroy(e->enc_begin);
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
@@ -1112,30 +1103,6 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
   // decode; otherwise the slot of the previous encode again.
   const int slot = e->pending.active ? 1 - e->pending.slot : e->enc_slot;
   if (!e->enc_done[slot]) MT3_HIP_CHECK(hipEventCreateWithFlags(&e->enc_done[slot], hipEventDisableTiming));
-  hipStream_t const caller = s;
-  if (e->pending.active) {         // beside a decode: on the CU-restricted stream (see mt3_engine::enc_stream)
-    if (!e->enc_stream) {
-      int n_cu = 0;
-      if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, e->device) == hipSuccess && n_cu >= 8) {
-        const int every = (c.options & MT3_OPT_X_ENCODE_ON_HALF) ? 2 : 4;
-        std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
-        for (int i = 0; i < n_cu; i += every) mask[i >> 5] |= 1u << (i & 31);
-        if (hipExtStreamCreateWithCUMask(&e->enc_stream, static_cast<uint32_t>(mask.size()), mask.data()) != hipSuccess) {
-          e->enc_stream = nullptr;
-          (void)hipGetLastError();
-        }
-      }
-      if (e->enc_stream && hipEventCreateWithFlags(&e->enc_begin, hipEventDisableTiming) != hipSuccess) {
-        (void)hipStreamDestroy(e->enc_stream);
-        e->enc_stream = nullptr;
-      }
-    }
-    if (e->enc_stream && !(c.options & MT3_OPT_X_ENCODE_UNMASKED)) {
-      MT3_HIP_CHECK(hipEventRecord(e->enc_begin, caller));
-      MT3_HIP_CHECK(hipStreamWaitEvent(e->enc_stream, e->enc_begin, 0));
-      s = e->enc_stream;
-    }
-  }
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), T = c.input_length;
   const int M = batch * T;
   const bool small = M < 2048;
@@ -1202,7 +1169,6 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
                                              batch * c.num_heads * T, s));
     }
     MT3_HIP_CHECK(hipEventRecord(e->enc_done[slot], s));
-    if (s != caller) MT3_HIP_CHECK(hipStreamWaitEvent(caller, e->enc_done[slot], 0));
     e->enc_slot = slot;
     e->slot_batch[slot] = e->cur_batch = batch;
     return MT3_OK;
@@ -1243,7 +1209,6 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
                                            batch * c.num_heads * T, s));
   }
   MT3_HIP_CHECK(hipEventRecord(e->enc_done[slot], s));
-  if (s != caller) MT3_HIP_CHECK(hipStreamWaitEvent(caller, e->enc_done[slot], 0));
   e->enc_slot = slot;
   e->slot_batch[slot] = e->cur_batch = batch;
   return MT3_OK;

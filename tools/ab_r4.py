@@ -1,8 +1,12 @@
-"""Round-4 A/B on one box, one process: the two-deep pipeline (frontend + encoder of step i + 1 beside the decode of step i)
-against one call at a time, with the pipelined encoder on a quarter / half / all of the compute units -- whole steps
-(frontend, encode, decode, ids -> tokens, device -> host copy) in the canonical full-length schedule and under the synthetic
-EOS schedule (lengths ~ clipped N(300, 100), early exit + row retirement).  Usage: python tools/ab_r4.py [name-substring ...]"""
+"""Round-4 A/B of decode-loop variants on one box, one process: for each named variant (dtype, engine options) build an
+engine, encode the same 256 segments, and time (a) the canonical 1024-step greedy decode in the product schedule, (b) the
+same decode under the synthetic EOS schedule (lengths ~ clipped N(300, 100), early exit + row retirement).  HIP events on
+the launch stream for the device side, getrusage for the host CPU seconds of the whole process (group workers included).
+Variants that only change schedules give the first variant's ids bit for bit; the split-K tiles change the summation
+order of a GEMM output (f32 round-off), so their free-running ids are compared row by row (identical rows, first
+divergence) instead.  Usage: python tools/ab_r4.py [variant-name-substring ...]"""
 import os
+import resource
 import sys
 import time
 
@@ -10,63 +14,68 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mt3_amd import _lib, network, spectrograms, synthetic, vocabularies  # noqa: E402
+from mt3_amd import _lib, network, spectrograms, synthetic  # noqa: E402
 
 B = int(os.environ.get("AB_B", "256"))
-N = int(os.environ.get("AB_STEPS", "4"))
+REPS = int(os.environ.get("AB_REPS", "2"))
 K = _lib
 VARIANTS = [
-    ("one call at a time", False, 0),
-    ("two-deep, encoder on every 4th CU", True, 0),
-    ("two-deep, encoder on every 2nd CU", True, K.OPT_X_ENCODE_ON_HALF),
-    ("two-deep, encoder on all CUs", True, K.OPT_X_ENCODE_UNMASKED),
+    ("f32 default (4 row groups)", "float32", 0),
+    ("bf16 default (2 row groups)", "bfloat16", 0),
 ]
 want = sys.argv[1:]
 stream = torch.cuda.Stream()
 audio = synthetic.synth_audio(B, seed=1000)
 lens = np.clip(np.rint(np.random.default_rng(0).normal(300, 100, B)), 1, 1024).astype(np.int32)
-vocab = vocabularies.vocabulary_from_codec(vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1)))
+first = {}
 
 
-def run(eng, n, pipelined, **kw):
-    out, in_flight = None, False
-    with torch.cuda.stream(stream):
-        for _ in range(n):
-            eng.encode(spectrograms.compute_spectrogram_batch(audio, None))
-            if in_flight:
-                out = vocab.decode_tf(eng.decode_wait()).cpu()
-            eng.decode(num_steps=1024, wait=False, **kw)
-            in_flight = True
-            if not pipelined:
-                out, in_flight = vocab.decode_tf(eng.decode_wait()).cpu(), False
-        if in_flight:
-            out = vocab.decode_tf(eng.decode_wait()).cpu()
+def timed(fn):
     torch.cuda.synchronize()
-    return out
+    r0 = resource.getrusage(resource.RUSAGE_SELF)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        out = fn()
+        e1.record(stream)
+    e1.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3
+    r1 = resource.getrusage(resource.RUSAGE_SELF)
+    return e0.elapsed_time(e1), wall, (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime), out
 
 
-for dtype in ("float32", "bfloat16"):
-    first = None
-    for name, pipelined, opt in VARIANTS:
-        if want and not any(w in name for w in want):
-            continue
-        cfg = network.T5Config(dtype=dtype)
-        eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=B, options=opt)
-        eng.load_params(network.init_random_params(cfg, seed=0))
-        res = []
-        for eos in (False, True):
-            eng.debug_set_eos_schedule(lens if eos else None)
-            kw = dict(early_exit=True) if eos else {}
-            run(eng, 2, pipelined, **kw)
-            t0 = time.perf_counter()
-            out = run(eng, N, pipelined, **kw)
-            res.append(((time.perf_counter() - t0) * 1e3 / N, out))
-        eng.debug_set_eos_schedule(None)
-        same = ""
-        if first is None:
-            first = [r[1] for r in res]
-        else:
-            same = " | tokens equal to the first variant: %s / %s" % (torch.equal(res[0][1], first[0]), torch.equal(res[1][1], first[1]))
-        print("%-8s %-36s full-length step %.1f ms (%.1f audio-s/s) | EOS-schedule step %.1f ms (%.1f audio-s/s)%s" % (
-            dtype, name, res[0][0], B * 2.048 / res[0][0] * 1e3, res[1][0], B * 2.048 / res[1][0] * 1e3, same), flush=True)
-        del eng
+for name, dtype, opt in VARIANTS:
+    if want and not any(w in name for w in want):
+        continue
+    cfg = network.T5Config(dtype=dtype)
+    eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=B, options=opt)
+    eng.load_params(network.init_random_params(cfg, seed=0))
+    with torch.cuda.stream(stream):
+        eng.encode(spectrograms.compute_spectrogram_batch(audio, None))
+        eng.decode(num_steps=2)
+    full = min((timed(lambda: eng.decode(num_steps=1024)) for _ in range(REPS)), key=lambda t: t[0])
+    groups = eng.status(K.STATUS_LAST_DECODE_GROUPS)
+    eng.debug_set_eos_schedule(lens)
+    with torch.cuda.stream(stream):
+        eng.decode(num_steps=1024, early_exit=True)
+    eos = min((timed(lambda: eng.decode(num_steps=1024, early_exit=True)) for _ in range(REPS)), key=lambda t: t[1])
+    steps, comp = eng.steps_run, eng.status(K.STATUS_LAST_DECODE_COMPACTIONS)
+    eos1 = min((timed(lambda: eng.decode(num_steps=1024, early_exit=True, single_stream=True)) for _ in range(REPS)),
+               key=lambda t: t[1])
+    eng.debug_set_eos_schedule(None)
+    key = (dtype, "full"), (dtype, "eos")
+    same = ""
+    if key[0] in first:
+        a, b = full[3].cpu().numpy(), first[key[0]].cpu().numpy()
+        neq = a != b
+        rows_same = float((~neq.any(1)).mean())
+        fd = np.where(neq.any(1), neq.argmax(1), a.shape[1])
+        same = " ids vs first: %.3f of rows identical, median first divergence %s; eos ids equal: %s" % (
+            rows_same, int(np.median(fd[neq.any(1)])) if neq.any() else None, torch.equal(eos[3], first[key[1]]))
+    else:
+        first[key[0]], first[key[1]] = full[3].clone(), eos[3].clone()
+    print("%-44s groups %d | full decode %.1f ms (host cpu %.2f s) | eos schedule %.1f ms wall (cpu %.2f s, %d steps, %d "
+          "compactions) single stream %.1f ms |%s" % (name, groups, full[0], full[2], eos[1], eos[2], steps, comp, eos1[1], same),
+          flush=True)
+    del eng
