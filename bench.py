@@ -210,9 +210,6 @@ def main():
     ap.add_argument("--file-segments", type=int, default=256,
                     help="the corpus is a list of files of this many consecutive segments (256 x 2.048 s = 8.7 min of "
                          "audio); host note decoding is sequential inside a file and parallel across files")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="one call at a time (frontend, encode, decode, tokens) instead of the two-deep pipeline in which "
-                         "the frontend + encoder of call i + 1 run beside the decode of call i")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other-precision blocks and the stage (frontend/encoder) extras")
     ap.add_argument("--eos-mean", type=float, default=300.0, help="synthetic EOS schedule: mean output length (SURVEY 8d)")
@@ -292,26 +289,6 @@ def main():
         e.encode(spectrograms.compute_spectrogram_batch(chunk, None))
         return vocab.decode_tf(e.decode(num_steps=args.decode_steps, beam1=args.decoding == "beam1"))
 
-    class Pipe:
-        """the two-deep schedule of distributed.ShardedTranscriber: `prepare` = frontend + encode of the NEXT call (into
-        the engine's other cross-K/V slot, MFMA-bound) while the previous call's decode (HBM- / latency-bound, on the
-        engine's group streams) is still in flight; `launch` = its MT3_DECODE_ASYNC decode; `collect` = join + ids -> tokens"""
-        def __init__(self, engine, **decode_kw):
-            self.e, self.kw = engine, decode_kw
-
-        def prepare(self, first, count):
-            chunk = audio[first - lo: first - lo + count]
-            with torch.cuda.stream(stream):
-                self.e.encode(spectrograms.compute_spectrogram_batch(chunk, None))
-
-        def launch(self):
-            with torch.cuda.stream(stream):
-                self.e.decode(num_steps=args.decode_steps, beam1=args.decoding == "beam1", wait=False, **self.kw)
-
-        def collect(self):
-            with torch.cuda.stream(stream):
-                return vocab.decode_tf(self.e.decode_wait())
-
     def on_gather(phase):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(stream)
@@ -321,8 +298,7 @@ def main():
             gather_events[-1][1] = ev
 
     job = distributed.ShardedTranscriber(n_global, rank, world, transcribe, notes_of_file, call_segments=B,
-                                         file_segments=args.file_segments, host_threads=8, on_gather=on_gather,
-                                         pipeline=None if args.no_pipeline else Pipe(eng))
+                                         file_segments=args.file_segments, host_threads=8, on_gather=on_gather)
 
     def host_stage(host):
         """one step's token rows of THIS rank's shard alone (the single-GPU extras): futures, one per file"""
@@ -532,32 +508,6 @@ def main():
 
             free_running = {}          # key -> the token rows [Br, L] of that engine's free-running decode of a256
 
-            def run_steps(engine, n, inputs, stage, **decode_kw):
-                """`n` steps of the headline pipeline on `engine` over the same inputs, scheduled as the headline is: two-deep
-                (step i + 1's frontend + encode beside step i's decode) unless --no-pipeline.  inputs() -> log-mel rows;
-                stage(host tokens) -> futures.  Returns (the last step's host tokens, all futures)."""
-                futs, host, in_flight = [], None, False
-
-                def collect():
-                    with torch.cuda.stream(stream):
-                        return vocab.decode_tf(engine.decode_wait()).cpu().numpy()
-                for _ in range(n):
-                    with torch.cuda.stream(stream):
-                        engine.encode(inputs())
-                    if in_flight:
-                        host = collect()
-                        futs += stage(host)
-                    with torch.cuda.stream(stream):
-                        engine.decode(num_steps=args.decode_steps, wait=False, **decode_kw)
-                    in_flight = True
-                    if args.no_pipeline:
-                        host, in_flight = collect(), False
-                        futs += stage(host)
-                if in_flight:
-                    host = collect()
-                    futs += stage(host)
-                return host, futs
-
             def other_engine(key, ecfg, label, n_steps, with_roofline, inputs=None):
                 """the SAME pipeline as the headline on another engine configuration: one warm-up step, then `n_steps`
                 timed steps (wall clock, synchronised both sides, host note decoding inside).  inputs: (audio, true
@@ -568,20 +518,25 @@ def main():
                     aud, nfr, file_list = inputs if inputs is not None else (a256, None, None)
                     lm_in = spectrograms.compute_spectrogram_batch(aud, nfr)
 
-                    def stage(host):
+                    def one_step():
+                        with torch.cuda.stream(stream):
+                            e2.encode(spectrograms.compute_spectrogram_batch(aud, nfr))
+                            ids = e2.decode(num_steps=args.decode_steps)
+                            host = vocab.decode_tf(ids).cpu().numpy()
+                        free_running[key] = host
                         if file_list is not None:     # one host-stage job per FILE of the ragged corpus
                             return [job._pool.submit(notes_of_file, host[a:a + n], a) for a, n in file_list]
                         return host_stage(host)
-
-                    def steps(n):
-                        host, futs = run_steps(e2, n, lambda: spectrograms.compute_spectrogram_batch(aud, nfr), stage)
-                        for f in futs:
-                            f.result()
-                        torch.cuda.synchronize()
-                        return host
-                    free_running[key] = steps(1)
+                    for f in one_step():
+                        f.result()
+                    torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    free_running[key] = steps(n_steps)
+                    futs = []
+                    for _ in range(n_steps):
+                        futs += one_step()
+                    for f in futs:
+                        f.result()
+                    torch.cuda.synchronize()
                     d = (time.perf_counter() - t1) / n_steps
                     e_ms = min(timed(lambda: e2.encode(lm_in), reps=5) for _ in range(2))
                     rec = {"value": Br * SEG_SECONDS / d, "unit": "audio-s/s", "ms_per_step": d * 1e3, "steps": n_steps,
@@ -666,22 +621,29 @@ def main():
                     engine.debug_set_eos_schedule(lens)
                     stats = {}
 
+                    def one_step(**kw):
+                        with torch.cuda.stream(stream):
+                            engine.encode(spectrograms.compute_spectrogram_batch(a256, None))
+                            ids = engine.decode(num_steps=args.decode_steps, early_exit=True, **kw)
+                            stats["steps_run"] = engine.steps_run
+                            stats["compactions"] = engine.status(_lib.STATUS_LAST_DECODE_COMPACTIONS)
+                            stats["groups"] = engine.status(_lib.STATUS_LAST_DECODE_GROUPS)
+                            host = vocab.decode_tf(ids).cpu().numpy()
+                        return host, host_stage(host)
+
                     def timed_steps(**kw):
-                        def steps(n):
-                            host, futs = run_steps(engine, n, lambda: spectrograms.compute_spectrogram_batch(a256, None),
-                                                   host_stage, early_exit=True, **kw)
-                            for f in futs:
-                                f.result()
-                            torch.cuda.synchronize()
-                            return host
-                        steps(1)
+                        host, futs = one_step(**kw)
+                        for f in futs:
+                            f.result()
+                        torch.cuda.synchronize()
                         t1 = time.perf_counter()
-                        host = steps(n_steps)
-                        d1 = (time.perf_counter() - t1) / n_steps
-                        stats["steps_run"] = engine.steps_run
-                        stats["compactions"] = engine.status(_lib.STATUS_LAST_DECODE_COMPACTIONS)
-                        stats["groups"] = engine.status(_lib.STATUS_LAST_DECODE_GROUPS)
-                        return d1, host
+                        futs = []
+                        for _ in range(n_steps):
+                            futs += one_step(**kw)[1]
+                        for f in futs:
+                            f.result()
+                        torch.cuda.synchronize()
+                        return (time.perf_counter() - t1) / n_steps, host
 
                     def decode_only(**kw):
                         with torch.cuda.stream(stream):
@@ -753,16 +715,23 @@ def main():
                 gen = torch.Generator(device="cuda").manual_seed(0)
                 noise = (torch.rand((Br, a256.shape[1]), device="cuda", generator=gen) * 2.0 - 1.0).to(torch.float32)
 
-                def noise_steps(n):
-                    _, futs = run_steps(eng, n, lambda: spectrograms.compute_spectrogram_batch(noise, None), host_stage)
-                    for f in futs:
-                        f.result()
-                    torch.cuda.synchronize()
-                noise_steps(1)
-                with torch.cuda.stream(stream):
-                    lmn = spectrograms.compute_spectrogram_batch(noise, None)
+                def noise_step():
+                    with torch.cuda.stream(stream):
+                        lmn = spectrograms.compute_spectrogram_batch(noise, None)
+                        eng.encode(lmn)
+                        host = vocab.decode_tf(eng.decode(num_steps=args.decode_steps)).cpu().numpy()
+                    return lmn, host_stage(host)
+                lmn, futs = noise_step()
+                for f in futs:
+                    f.result()
+                torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                noise_steps(3)
+                futs = []
+                for _ in range(3):
+                    futs += noise_step()[1]
+                for f in futs:
+                    f.result()
+                torch.cuda.synchronize()
                 dn = (time.perf_counter() - t1) / 3
                 extras["uniform_noise"] = {
                     "value": Br * SEG_SECONDS / dn, "unit": "audio-s/s", "ms_per_step": dn * 1e3, "steps": 3, "warmup": 1,
@@ -809,9 +778,6 @@ def main():
                                            "replayed per step" if used_graph else "direct launches")) if decode_groups > 1 else
                        ("one stream, hipGraph replay per step" if used_graph else
                         "one stream, DIRECT LAUNCHES (graph capture failed)"),
-                       "pipeline": "one call at a time" if args.no_pipeline else
-                       "two-deep: the frontend + encoder of call i + 1 (other cross-K/V slot, caller's stream) run beside the "
-                       "decode of call i (MT3_DECODE_ASYNC, the engine's group streams); every call is joined before the clock stops",
                        "graph_fallbacks": graph_fallbacks, "partition_fallbacks": partition_fallbacks,
                        "notes_decoded_last_step": n_notes},
             "segments_per_s": segs / dt,

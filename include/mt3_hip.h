@@ -162,10 +162,7 @@ int64_t mt3_engine_device_bytes(const mt3_engine* e);
 
 /* Transformer.encode (network.py:275-301) + cross-attention K/V of every decoder
  * layer (layers.py:239-240, hoisted out of the decode loop).
- * d_inputs [batch, T, input_depth] f32.  d_encoded_f32 [batch, T, emb] f32 or NULL.
- * The engine keeps TWO cross-K/V slots: an encode issued while an MT3_DECODE_ASYNC decode is in flight writes the slot that
- * decode does not read; the next mt3_engine_decode works on the most recent encode and orders itself after it (the encode
- * may be on another stream than the decode). */
+ * d_inputs [batch, T, input_depth] f32.  d_encoded_f32 [batch, T, emb] f32 or NULL. */
 int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch,
                       float* d_encoded_f32, void* stream);
 
@@ -208,11 +205,9 @@ enum {
   /* keep the whole decode on the caller's stream (no helper streams): see "Schedule" above */
   MT3_DECODE_SINGLE_STREAM = 8,
   /* return as soon as the decode has been handed to the engine's worker threads; the caller MUST call
-   * mt3_engine_decode_wait before it reads d_ids or starts another decode.  The ONE engine call allowed while a decode is
-   * in flight is mt3_engine_encode: it fills the cross-K/V slot the decode is not reading, so the next batch's frontend
-   * and encoder (MFMA-bound) run beside this batch's decode (HBM- and latency-bound) -- the two-deep pipeline bench.py
-   * and InferenceModel run.  Every other call fails with MT3_ERR_INVALID until the wait.  h_steps_run is not written by
-   * the asynchronous call (mt3_engine_decode_wait reports it). */
+   * mt3_engine_decode_wait before it reads d_ids, enqueues anything else on `stream`, or calls any other function of
+   * this engine (they fail with MT3_ERR_INVALID while a decode is in flight).  h_steps_run is not written by the
+   * asynchronous call (mt3_engine_decode_wait reports it). */
   MT3_DECODE_ASYNC = 16
   /* bits 8..11: number of decode chains for this call (1..8); 0 = the engine's configured default.
    * Any other bit is rejected with MT3_ERR_INVALID (profiling variants live in mt3_hip_debug.h). */

@@ -79,23 +79,19 @@ struct LayerDev {
   void* wo_mlp = nullptr;    // [emb][mlp]
   void* self_k = nullptr;    // decoder [Bm][H][L][64]
   void* self_v = nullptr;
-  // decoder cross-attention K | V, [2][B][H][T][64] -- TWO slots (round 4): an encode that arrives while a decode is in flight
-  // (MT3_DECODE_ASYNC) fills the slot that decode is not reading, so batch i + 1's frontend + encoder (MFMA-bound) run
-  // beside batch i's decode (HBM- and latency-bound)
-  void* cross_kv[2] = {nullptr, nullptr};
+  void* cross_kv = nullptr;  // decoder [2][B][H][T][64]
   // MXFP8 dense path (dense_dtype MT3_FP8_E4M3): the same matrices as e4m3 bytes + E8M0 block scales [rows][K / 32]
   uint8_t *wqkv_q = nullptr, *wqkv_sc = nullptr, *wo_q = nullptr, *wo_sc = nullptr, *wi_q = nullptr, *wi_sc = nullptr,
           *wo_mlp_q = nullptr, *wo_mlp_sc = nullptr, *wkv_x_q = nullptr, *wkv_x_sc = nullptr;
   // fp8 (e4m3) K/V caches only: {k_scale, v_scale} per cached row
   float2* self_scale = nullptr;    // [Bm][H][L]
-  float2* cross_scale[2] = {nullptr, nullptr};   // [B][H][T] per slot
+  float2* cross_scale = nullptr;   // [B][H][T]
 };
 
 // Variant bits of one decode step (index of a captured step graph): 1 / 2 = mt3_debug_engine_decode's skipped kernels,
 // 4 = beam-1 token selection, 8 = teacher forcing, 16 = row retirement (finished slots cost nothing, the slot map is
 // in use), 32 = the synthetic EOS schedule (mt3_debug_engine_set_eos_schedule)
-// 64 = the decode reads cross-K/V slot 1
-constexpr int kVarBeam = 4, kVarForced = 8, kVarRetire = 16, kVarEos = 32, kVarSlot1 = 64, kNumVariants = 128;
+constexpr int kVarBeam = 4, kVarForced = 8, kVarRetire = 16, kVarEos = 32, kNumVariants = 64;
 constexpr int kMaxGroups = 4;
 
 // One persistent host thread per row group (created with the first decode that needs it, joined at destroy): a
@@ -119,7 +115,6 @@ struct GroupGraph {
 // what mt3_engine_decode left for mt3_engine_decode_wait
 struct PendingDecode {
   bool active = false;
-  int slot = 0;                 // cross-K/V slot this decode reads
   int posted = 0;               // workers that hold a job of this decode
   int groups = 1;
   bool beam1 = false;
@@ -246,10 +241,7 @@ struct mt3_engine {
   int part_failed = 0;           // partitioned decodes that fell back to the single-stream schedule (stream creation failed)
   int last_groups = 1;           // row groups of the most recent decode
 
-  int enc_slot = 0;              // cross-K/V slot of the most recent encode
-  int slot_batch[2] = {0, 0};    // batch of the encode that filled each slot
-  hipEvent_t enc_done[2] = {};   // recorded on the encode's stream: a decode orders itself after the encode of its slot
-  int cur_batch = 0;             // batch of the most recent encode (= slot_batch[enc_slot])
+  int cur_batch = 0;             // batch of the last encode
   hipStream_t cap_stream[8] = {};     // one capture stream per chain (kMaxChains)
   hipEvent_t cap_event[8] = {};
   // one captured decode step per (batch, variant); variant bits: 1 = no self-attention, 2 = no
@@ -700,10 +692,9 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
         x.q_ss = y_ss;
         x.q_ss_n = emb / 16;
       }
-      const int xs = (skip & kVarSlot1) ? 1 : 0;
-      x.kcache = static_cast<char*>(L.cross_kv[xs]) + crow0 * H * T * 64 * kes;
-      x.vcache = static_cast<char*>(L.cross_kv[xs]) + (static_cast<size_t>(B_total) + crow0) * H * T * 64 * kes;
-      x.kv_scale = e->kv_fp8 ? L.cross_scale[xs] + crow0 * H * T : nullptr;
+      x.kcache = static_cast<char*>(L.cross_kv) + crow0 * H * T * 64 * kes;
+      x.vcache = static_cast<char*>(L.cross_kv) + (static_cast<size_t>(B_total) + crow0) * H * T * 64 * kes;
+      x.kv_scale = e->kv_fp8 ? L.cross_scale + crow0 * H * T : nullptr;
       if (retire) {
         x.done = e->done + row0;
         x.cache_row = e->slot_row + row0;
@@ -886,8 +877,6 @@ void mt3_engine_destroy(mt3_engine* e) {
   for (int g = 0; g < kMaxGroups; ++g)
     if (e->part_stream[g]) (void)hipStreamDestroy(e->part_stream[g]);
   if (e->part_begin) (void)hipEventDestroy(e->part_begin);
-  for (int xs = 0; xs < 2; ++xs)
-    if (e->enc_done[xs]) (void)hipEventDestroy(e->enc_done[xs]);
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
@@ -968,18 +957,16 @@ int mt3_engine_finalize(mt3_engine* e) {
     // length and mask what lies past it -- those bytes must be finite (0 x NaN would poison the accumulators)
     MT3_HIP_CHECK(hipMemset(e->dec[l].self_k, 0, kvb));
     MT3_HIP_CHECK(hipMemset(e->dec[l].self_v, 0, kvb));
-    for (int xs = 0; xs < 2; ++xs)
-      if ((rc = dmalloc(e, &e->dec[l].cross_kv[xs], static_cast<size_t>(2) * Bm * c.num_heads * T * 64 * e->kv_esize)))
-        return rc;
+    if ((rc = dmalloc(e, &e->dec[l].cross_kv, static_cast<size_t>(2) * Bm * c.num_heads * T * 64 * e->kv_esize)))
+      return rc;
     if (e->kv_fp8) {
       if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->dec[l].self_scale),
                         static_cast<size_t>(Bm) * c.num_heads * L * sizeof(float2))))
         return rc;
       MT3_HIP_CHECK(hipMemset(e->dec[l].self_scale, 0, static_cast<size_t>(Bm) * c.num_heads * L * sizeof(float2)));
-      for (int xs = 0; xs < 2; ++xs)
-        if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->dec[l].cross_scale[xs]),
-                          static_cast<size_t>(Bm) * c.num_heads * T * sizeof(float2))))
-          return rc;
+      if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->dec[l].cross_scale),
+                        static_cast<size_t>(Bm) * c.num_heads * T * sizeof(float2))))
+        return rc;
     }
   }
   if (e->kv_fp8 && (rc = dmalloc(e, &e->cross_stage, static_cast<size_t>(2) * Bm * c.num_heads * T * 64 * 2))) return rc;
@@ -1096,13 +1083,10 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
   if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: engine not finalized");
   if (!d_inputs || batch <= 0 || batch > e->cfg.max_batch)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: batch out of range");
+  if (e->pending.active)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: a decode is in flight (MT3_DECODE_ASYNC): call mt3_engine_decode_wait first");
   const mt3_engine_config& c = e->cfg;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // Which cross-K/V slot this encode fills: while a decode is in flight (MT3_DECODE_ASYNC), the one it does NOT read --
-  // the encoder's own workspaces are touched by nothing else -- so that batch i + 1 can be encoded beside batch i's
-  // decode; otherwise the slot of the previous encode again.
-  const int slot = e->pending.active ? 1 - e->pending.slot : e->enc_slot;
-  if (!e->enc_done[slot]) MT3_HIP_CHECK(hipEventCreateWithFlags(&e->enc_done[slot], hipEventDisableTiming));
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), T = c.input_length;
   const int M = batch * T;
   const bool small = M < 2048;
@@ -1161,16 +1145,14 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
     MT3_TRY(mt3k::launch_mx8_quantize(e->enc_out, false, M, emb, e->enc_q, e->enc_sc, nullptr, s));
     for (int l = 0; l < c.num_decoder_layers; ++l) {
       mt3k::Mx8Args g = mx(e->enc_q, e->enc_sc, e->dec[l].wkv_x_q, e->dec[l].wkv_x_sc, 2 * hd, emb);
-      g.out = e->kv_fp8 ? e->cross_stage : e->dec[l].cross_kv[slot];
+      g.out = e->kv_fp8 ? e->cross_stage : e->dec[l].cross_kv;
       g.seq_len = T;
       MT3_TRY(mt3k::launch_gemm_mx8(g, MT3_EPI_HEADS, s));
       if (e->kv_fp8)
-        MT3_TRY(mt3k::launch_kv_quantize_fp8(e->cross_stage, e->dec[l].cross_kv[slot], e->dec[l].cross_scale[slot],
+        MT3_TRY(mt3k::launch_kv_quantize_fp8(e->cross_stage, e->dec[l].cross_kv, e->dec[l].cross_scale,
                                              batch * c.num_heads * T, s));
     }
-    MT3_HIP_CHECK(hipEventRecord(e->enc_done[slot], s));
-    e->enc_slot = slot;
-    e->slot_batch[slot] = e->cur_batch = batch;
+    e->cur_batch = batch;
     return MT3_OK;
   }
   // the split residual form feeds the LDS-DMA tile (K <= 1024); the decode-sized tile a small batch selects holds the
@@ -1200,17 +1182,15 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
   }
   MT3_TRY(mt3k::launch_rmsnorm(dt, e->x, e->enc_norm, e->enc_out, d_encoded_f32, M, emb, s));
   for (int l = 0; l < c.num_decoder_layers; ++l) {
-    mt3k::GemmArgs g = gemm_args(e->enc_out, e->dec[l].wkv_x, e->kv_fp8 ? e->cross_stage : e->dec[l].cross_kv[slot], M,
+    mt3k::GemmArgs g = gemm_args(e->enc_out, e->dec[l].wkv_x, e->kv_fp8 ? e->cross_stage : e->dec[l].cross_kv, M,
                                  2 * hd, emb, 2 * hd);
     g.seq_len = T;
     MT3_TRY(mt3k::launch_gemm(dt, g, false, false, MT3_EPI_HEADS, small, s));
     if (e->kv_fp8)     // bf16 [2][B][H][T][64] -> e4m3 rows + one power-of-two scale per (row, head, position)
-      MT3_TRY(mt3k::launch_kv_quantize_fp8(e->cross_stage, e->dec[l].cross_kv[slot], e->dec[l].cross_scale[slot],
+      MT3_TRY(mt3k::launch_kv_quantize_fp8(e->cross_stage, e->dec[l].cross_kv, e->dec[l].cross_scale,
                                            batch * c.num_heads * T, s));
   }
-  MT3_HIP_CHECK(hipEventRecord(e->enc_done[slot], s));
-  e->enc_slot = slot;
-  e->slot_batch[slot] = e->cur_batch = batch;
+  e->cur_batch = batch;
   return MT3_OK;
 }
 
@@ -1492,8 +1472,6 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_decode_forced: not combinable with BEAM1 / EARLY_EXIT / ASYNC");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int L = c.max_decode_len;
-  const int xs = e->enc_slot;                   // the decode works on the most recent encode's cross-K/V
-  if (e->enc_done[xs]) MT3_HIP_CHECK(hipStreamWaitEvent(s, e->enc_done[xs], 0));     // (the encode may have used another stream)
   MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, static_cast<size_t>(batch) * 4, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->n_done, 0, 4 * kMaxChains, s));
   MT3_HIP_CHECK(hipMemsetAsync(e->done, 0, static_cast<size_t>(batch) * 4, s));
@@ -1515,7 +1493,7 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
   // step variant: bits 1 / 2 = mt3_debug_engine_decode's skipped kernels (mt3_hip_debug.h; never set by the product
   // entry points), then kVar*
   const int variant = (debug_skip & 3) | (beam1 ? kVarBeam : 0) | (d_forced ? kVarForced : 0) | (retire ? kVarRetire : 0) |
-                      (e->eos_on && !d_forced ? kVarEos : 0) | (xs ? kVarSlot1 : 0);
+                      (e->eos_on && !d_forced ? kVarEos : 0);
   if (beam1) {
     // t5x beam_search(alpha = 0.6): live log-prob 0, nothing finished; the loop bound uses the brevity
     // penalty of max_decode_len + 1 (the dummy start token extends the length by one).  The value travels as a
@@ -1528,7 +1506,6 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
   if (e->group_graphs.size() > 96) drop_group_graphs(e);      // (no worker is running here)
   PendingDecode& p = e->pending;
   p = PendingDecode();
-  p.slot = xs;
   p.beam1 = beam1;
   p.batch = batch;
   p.d_ids = d_ids;
@@ -1700,11 +1677,8 @@ int mt3_debug_engine_poison_caches(mt3_engine* e, int32_t pattern, int32_t cross
     MT3_HIP_CHECK(hipMemsetAsync(L.self_v, pattern, kvb, s));
     if (L.self_scale) MT3_HIP_CHECK(hipMemsetAsync(L.self_scale, pattern, heads * c.max_decode_len * sizeof(float2), s));
     if (cross) {
-      for (int xs = 0; xs < 2; ++xs) {
-        MT3_HIP_CHECK(hipMemsetAsync(L.cross_kv[xs], pattern, 2 * heads * c.input_length * 64 * e->kv_esize, s));
-        if (L.cross_scale[xs])
-          MT3_HIP_CHECK(hipMemsetAsync(L.cross_scale[xs], pattern, heads * c.input_length * sizeof(float2), s));
-      }
+      MT3_HIP_CHECK(hipMemsetAsync(L.cross_kv, pattern, 2 * heads * c.input_length * 64 * e->kv_esize, s));
+      if (L.cross_scale) MT3_HIP_CHECK(hipMemsetAsync(L.cross_scale, pattern, heads * c.input_length * sizeof(float2), s));
     }
   }
   return MT3_OK;

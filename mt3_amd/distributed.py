@@ -78,16 +78,12 @@ class ShardedTranscriber:
 
     def __init__(self, n_items: int, rank: int, world: int, transcribe: Callable, notes: Callable, call_segments: int,
                  file_segments: int, host_threads: int = 8, on_gather: Optional[Callable] = None,
-                 row_length: Optional[int] = None, device=None, pipeline=None):
+                 row_length: Optional[int] = None, device=None):
         """row_length / device: shape and placement of the token rows `transcribe` returns.  Only needed when a rank
         can end up with an EMPTY shard (n_items < world): that rank has no `transcribe` result to take them from and
         still has to enter the gather with a [0, row_length] tensor, or the other ranks wait for it forever.  Without
         them a corpus smaller than the world is refused here -- on EVERY rank (all of them see the same n_items and
-        world), so the job fails loudly instead of hanging.
-        pipeline: instead of `transcribe`, an object with `prepare(first, count)` (frontend + encode of the next call),
-        `launch()` (start ITS decode asynchronously) and `collect()` (join the decode in flight -> its token rows): the
-        job then runs two-deep -- call i + 1 is prepared while call i decodes, across call AND pass boundaries; a pass's
-        gather and host stage are issued when its last call has been collected (at the latest by `drain`)."""
+        world), so the job fails loudly instead of hanging."""
         from concurrent.futures import ThreadPoolExecutor
         if n_items <= 0:
             raise ValueError("ShardedTranscriber: empty corpus")
@@ -102,39 +98,12 @@ class ShardedTranscriber:
         self._transcribe, self._notes, self._on_gather = transcribe, notes, on_gather
         self._pool = ThreadPoolExecutor(max_workers=max(1, host_threads)) if rank == 0 else None
         self._pending: List[list] = []
-        self._pipe, self._in_flight, self._parts = pipeline, None, []
 
     def step(self):
         """one pass over this rank's shard; rank 0 also queues the host stage of the gathered rows"""
-        if self._pipe is not None:
-            calls = [(s, min(self.call_segments, self.hi - s)) for s in range(self.lo, self.hi, self.call_segments)]
-            if not calls:                       # an empty shard still enters every pass's collective
-                self._finish_pass([])
-            for i, (s, n) in enumerate(calls):
-                self._pipe.prepare(s, n)        # overlaps the decode in flight (the previous call's, maybe the previous pass's)
-                done = self._collect()
-                self._pipe.launch()
-                self._in_flight = i + 1 == len(calls)        # is it the last call of its pass?
-                if done is not None:            # the previous pass is complete: its gather / host stage AFTER the launch,
-                    self._finish_pass(done)     # so that the device-to-host copy does not sit in front of the next decode
-            return
+        import torch
         parts = [self._transcribe(s, min(self.call_segments, self.hi - s))
                  for s in range(self.lo, self.hi, self.call_segments)]
-        self._finish_pass(parts)
-
-    def _collect(self):
-        """join the decode in flight (pipeline mode); returns the parts of a pass whose last call this was, else None"""
-        if self._in_flight is None:
-            return None
-        last, self._in_flight = self._in_flight, None
-        self._parts.append(self._pipe.collect())
-        if not last:
-            return None
-        parts, self._parts = self._parts, []
-        return parts
-
-    def _finish_pass(self, parts):
-        import torch
         if not parts:       # an empty shard (n_items < world): this rank still enters the collective
             tokens = torch.zeros((0, self.row_length), dtype=torch.int32, device=self.device or "cpu")
         else:
@@ -151,9 +120,6 @@ class ShardedTranscriber:
 
     def drain(self) -> Sequence:
         """join every queued host stage; returns the per-file results of the LAST pass (rank 0; [] elsewhere)"""
-        done = self._collect()
-        if done is not None:
-            self._finish_pass(done)
         last: list = []
         while self._pending:
             last = [f.result() for f in self._pending.pop(0)]

@@ -125,17 +125,11 @@ class InferenceModel(object):
         import torch
         x = batch["encoder_input_tokens"]
         x = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x, np.float32))
-        out, in_flight = [], False
-        # two-deep pipeline over the batches of a long input: batch i + 1 is encoded (MFMA-bound) while batch i decodes
-        # (HBM- and latency-bound) -- the engine keeps two cross-K/V slots for exactly this (include/mt3_hip.h)
+        out = []
         for s in range(0, x.shape[0], self.batch_size):
             self.model.encode(x[s:s + self.batch_size].cuda())
-            if in_flight:
-                out.append(self.vocabulary.decode_tf(self.model.decode_wait()))
-            self.model.decode(early_exit=self.early_exit, beam1=self.decoding == "beam1", wait=False)
-            in_flight = True
-        if in_flight:
-            out.append(self.vocabulary.decode_tf(self.model.decode_wait()))
+            ids = self.model.decode(early_exit=self.early_exit, beam1=self.decoding == "beam1")
+            out.append(self.vocabulary.decode_tf(ids))
         return torch.cat(out, 0).cpu().numpy()
 
     def __call__(self, audio):

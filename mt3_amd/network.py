@@ -199,7 +199,6 @@ class Transformer:
         _lib.check(self._lib.mt3_engine_encode(self._h, x.data_ptr(), x.shape[0], enc.data_ptr() if enc is not None
                                                else None, torch.cuda.current_stream().cuda_stream))
         self._batch = x.shape[0]
-        self._enc_input = x                     # the launch reads it asynchronously: keep it alive until the next encode
         return enc
 
     def decode(self, num_steps: Optional[int] = None, use_graph: bool = True, early_exit: bool = False,

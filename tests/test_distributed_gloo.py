@@ -219,86 +219,3 @@ def test_a_corpus_smaller_than_the_world_neither_hangs_nor_loses_rows():
         p.join(60)
         assert p.exitcode == 0
     assert got == [(0, True, want), (1, True, [])]
-
-
-# ------------------------------------------------------------------------------------------------------------
-# The two-deep pipeline (round 4): call i + 1 is prepared (frontend + encode) while call i decodes, across call and pass
-# boundaries; results, collectives per pass and call order must not change.
-class _StubPipe:
-    def __init__(self):
-        self.log, self._prepared, self._running = [], None, None
-
-    def prepare(self, first, count):
-        self.log.append(("prepare", first, count))
-        self._prepared = (first, count)
-
-    def launch(self):
-        assert self._running is None, "a decode was launched while another was in flight"
-        self.log.append(("launch",) + self._prepared)
-        self._running, self._prepared = self._prepared, None
-
-    def collect(self):
-        first, count = self._running
-        self._running = None
-        self.log.append(("collect", first, count))
-        return torch.from_numpy(_stub_rows(first, count))
-
-
-def _pipe_job_worker(rank, world, port, n_items, q):
-    sys.path.insert(0, ROOT)
-    import torch.distributed as dist
-    from mt3_amd import distributed
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    pipe, collectives = _StubPipe(), []
-    job = distributed.ShardedTranscriber(n_items, rank, world, None, _notes_of_file_factory(), call_segments=1250,
-                                         file_segments=256, host_threads=4, on_gather=lambda ph: collectives.append(ph),
-                                         pipeline=pipe)
-    job.step()
-    assert collectives == []                               # pass 1's last decode is still in flight: nothing gathered yet
-    job.step()
-    assert collectives == [0, 1]                           # pass 1 was gathered once pass 2's first call had been launched
-    res = job.drain()
-    assert collectives == [0, 1, 0, 1]
-    q.put((rank, res if rank == 0 else None, pipe.log))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_pipelined_job_prepares_the_next_call_under_the_decode_in_flight():
-    from mt3_amd import distributed
-    n_items = 3000
-    plain = distributed.ShardedTranscriber(n_items, 0, 1, lambda f, c: torch.from_numpy(_stub_rows(f, c)),
-                                           _notes_of_file_factory(), call_segments=1250, file_segments=256, host_threads=4)
-    plain.step()
-    want = plain.drain()
-    pipe = _StubPipe()
-    job = distributed.ShardedTranscriber(n_items, 0, 1, None, _notes_of_file_factory(), call_segments=1250,
-                                         file_segments=256, host_threads=4, pipeline=pipe)
-    job.step()
-    job.step()
-    assert job.drain() == want
-    calls = [(0, 1250), (1250, 1250), (2500, 500)] * 2
-    # every call: prepared BEFORE the previous one is collected, launched right after
-    expect = []
-    for i, c in enumerate(calls):
-        expect.append(("prepare",) + c)
-        if i:
-            expect.append(("collect",) + calls[i - 1])
-        expect.append(("launch",) + c)
-    expect.append(("collect",) + calls[-1])
-    assert pipe.log == expect
-    # two ranks: rank 0's notes equal the single-rank run, one collective per pass
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_pipe_job_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = sorted((q.get(timeout=240) for _ in range(2)), key=lambda t: t[0])
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    assert got[0][1] == want
-    assert [e for e in got[1][2] if e[0] == "launch"] == [("launch", 1500, 1250), ("launch", 2750, 250)] * 2
