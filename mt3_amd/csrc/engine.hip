@@ -83,6 +83,8 @@ struct LayerDev {
   // MXFP8 dense path (dense_dtype MT3_FP8_E4M3): the same matrices as e4m3 bytes + E8M0 block scales [rows][K / 32]
   uint8_t *wqkv_q = nullptr, *wqkv_sc = nullptr, *wo_q = nullptr, *wo_sc = nullptr, *wi_q = nullptr, *wi_sc = nullptr,
           *wo_mlp_q = nullptr, *wo_mlp_sc = nullptr, *wkv_x_q = nullptr, *wkv_x_sc = nullptr;
+  // f32 engine, encoder-sized launches (gemm_x6_kernel): the same matrices as three bf16 planes (hi / mid / lo) [N][K]
+  void *wqkv_p[3] = {}, *wo_p[3] = {}, *wi_p[3] = {}, *wo_mlp_p[3] = {}, *wkv_x_p[3] = {};
   // fp8 (e4m3) K/V caches only: {k_scale, v_scale} per cached row
   float2* self_scale = nullptr;    // [Bm][H][L]
   float2* cross_scale = nullptr;   // [B][H][T]
@@ -147,6 +149,8 @@ struct mt3_engine {
   uint8_t *enc_q = nullptr, *enc_sc = nullptr;     // normed encoder output [M][emb] (A of the cross-K/V projections)
 
   void* enc_in = nullptr;        // [emb][input_depth]
+  void* enc_in_p[3] = {};        // f32 engine: its three bf16 planes
+  bool x6 = false;               // f32 engine: the encoder's dense layers multiply on the bf16 pipes (three planes per operand)
   float* enc_norm = nullptr;     // [emb] f32
   float* embedding = nullptr;    // [V][emb] f32
   void* logits_w = nullptr;      // [V][emb] (decoder_norm folded)
@@ -292,6 +296,35 @@ int upload_mx8(mt3_engine* e, const std::vector<float>& h, int64_t rows, int64_t
   return MT3_OK;
 }
 
+// upload a host f32 matrix as its three bf16 planes: hi = rne(w), mid = rne(w - hi), lo = rne(w - hi - mid) (both
+// differences exact); only when the engine multiplies f32 operands that way (mt3_engine::x6)
+int upload_planes(mt3_engine* e, const std::vector<float>& h, void* (&p)[3]) {
+  if (!e->x6) return MT3_OK;
+  std::vector<uint16_t> pl[3];
+  for (auto& v : pl) v.resize(h.size());
+  for (size_t i = 0; i < h.size(); ++i) {
+    auto val = [](uint16_t b) {
+      const uint32_t u = static_cast<uint32_t>(b) << 16;
+      float f;
+      std::memcpy(&f, &u, 4);
+      return f;
+    };
+    const uint16_t hi = f32_to_bf16_bits(h[i]);
+    const float r1 = h[i] - val(hi);
+    const uint16_t mi = f32_to_bf16_bits(r1);
+    const float r2 = r1 - val(mi);
+    pl[0][i] = hi;
+    pl[1][i] = mi;
+    pl[2][i] = f32_to_bf16_bits(r2);
+  }
+  for (int k = 0; k < 3; ++k) {
+    int rc = dmalloc(e, &p[k], h.size() * 2);
+    if (rc) return rc;
+    MT3_HIP_CHECK(hipMemcpy(p[k], pl[k].data(), h.size() * 2, hipMemcpyHostToDevice));
+  }
+  return MT3_OK;
+}
+
 int upload_f32(mt3_engine* e, const std::vector<float>& h, float** d) {
   int rc = dmalloc(e, reinterpret_cast<void**>(d), h.size() * 4);
   if (rc) return rc;
@@ -342,6 +375,8 @@ int build_attention(mt3_engine* e, const std::string& prefix, const float* scale
     if ((rc = upload_ct(e, t, &L->wqkv))) return rc;
     if ((rc = upload_ct(e, ot, &L->wo))) return rc;
     if (encoder) {
+      if ((rc = upload_planes(e, t, L->wqkv_p))) return rc;
+      if ((rc = upload_planes(e, ot, L->wo_p))) return rc;
       if ((rc = upload_mx8(e, t, 3 * hd, emb, &L->wqkv_q, &L->wqkv_sc))) return rc;
       if ((rc = upload_mx8(e, ot, emb, hd, &L->wo_q, &L->wo_sc))) return rc;
     }
@@ -352,6 +387,7 @@ int build_attention(mt3_engine* e, const std::string& prefix, const float* scale
     put_transposed(tkv, emb, hd, *v, nullptr);
     if ((rc = upload_ct(e, tq, &L->wq_x))) return rc;
     if ((rc = upload_ct(e, tkv, &L->wkv_x))) return rc;
+    if ((rc = upload_planes(e, tkv, L->wkv_x_p))) return rc;
     if ((rc = upload_mx8(e, tkv, 2 * hd, emb, &L->wkv_x_q, &L->wkv_x_sc))) return rc;
     if ((rc = upload_ct(e, ot, &L->wo_x))) return rc;
   }
@@ -508,6 +544,8 @@ int build_mlp(mt3_engine* e, const std::string& prefix, const float* scale, Laye
   int rc;
   if ((rc = upload_ct(e, t, &L->wi))) return rc;
   if (encoder) {
+    if ((rc = upload_planes(e, t, L->wi_p))) return rc;
+    if ((rc = upload_planes(e, ot, L->wo_mlp_p))) return rc;
     if ((rc = upload_mx8(e, t, 2 * mlp, emb, &L->wi_q, &L->wi_sc))) return rc;
     if ((rc = upload_mx8(e, ot, emb, mlp, &L->wo_mlp_q, &L->wo_mlp_sc))) return rc;
   }
@@ -848,7 +886,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
   if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM |
-                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS))
+                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_X_F32_ENCODER_ON_F32_MFMA))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -858,6 +896,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
     e->device = 0;                 // no GPU: the failure is reported by the first call that needs one (finalize)
   }
   e->dense_fp8 = cfg->dense_dtype == MT3_FP8_E4M3;
+  e->x6 = cfg->compute_dtype == MT3_F32 && !(cfg->options & MT3_OPT_X_F32_ENCODER_ON_F32_MFMA);
   e->esize = cfg->compute_dtype == MT3_BF16 ? 2 : 4;
   e->kv_fp8 = cfg->kv_cache_dtype == MT3_FP8_E4M3;
   e->kv_esize = e->kv_fp8 ? 1 : e->esize;
@@ -914,6 +953,7 @@ int mt3_engine_finalize(mt3_engine* e) {
     std::vector<float> t(static_cast<size_t>(emb) * c.input_depth);
     put_transposed(t, c.input_depth, 0, *w, nullptr);
     if ((rc = upload_ct(e, t, &e->enc_in))) return rc;
+    if ((rc = upload_planes(e, t, e->enc_in_p))) return rc;
   }
   e->enc.resize(c.num_encoder_layers);
   for (int l = 0; l < c.num_encoder_layers; ++l) {
@@ -1090,6 +1130,30 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), T = c.input_length;
   const int M = batch * T;
   const bool small = M < 2048;
+  if (e->x6 && !small) {
+    // f32 engine, encoder-sized launches: every dense layer on the bf16 pipes with three planes per operand (gemm.hip,
+    // gemm_x6_kernel: at least as exact as the f32 matrix instruction, 2.7x its rate); attention and norms as before
+    auto x6 = [&](const void* A, void* (&W)[3], void* out, int N, int K, int ldo, bool norm, int epi, int seq) {
+      mt3k::GemmArgs g = gemm_args(A, W[0], out, M, N, K, ldo);
+      g.aux = e->pos_table;
+      g.seq_len = seq;
+      return mt3k::launch_gemm_x6(g, W[1], W[2], norm, epi, s);
+    };
+    MT3_TRY(x6(d_inputs, e->enc_in_p, e->x, emb, c.input_depth, emb, false, MT3_EPI_POS, T));
+    for (int l = 0; l < c.num_encoder_layers; ++l) {
+      LayerDev& L = e->enc[l];
+      MT3_TRY(x6(e->x, L.wqkv_p, e->qkv, 3 * hd, emb, 3 * hd, true, MT3_EPI_STORE, 0));
+      MT3_TRY(mt3k::launch_encoder_attention(dt, e->qkv, e->attn, batch, T, c.num_heads, s));
+      MT3_TRY(x6(e->attn, L.wo_p, e->x, emb, hd, emb, false, MT3_EPI_RESID, 0));
+      MT3_TRY(x6(e->x, L.wi_p, e->hbuf, 2 * c.mlp_dim, emb, c.mlp_dim, true, MT3_EPI_GEGLU, 0));
+      MT3_TRY(x6(e->hbuf, L.wo_mlp_p, e->x, emb, c.mlp_dim, emb, false, MT3_EPI_RESID, 0));
+    }
+    MT3_TRY(mt3k::launch_rmsnorm(dt, e->x, e->enc_norm, e->enc_out, d_encoded_f32, M, emb, s));
+    for (int l = 0; l < c.num_decoder_layers; ++l)
+      MT3_TRY(x6(e->enc_out, e->dec[l].wkv_x_p, e->dec[l].cross_kv, 2 * hd, emb, 2 * hd, false, MT3_EPI_HEADS, T));
+    e->cur_batch = batch;
+    return MT3_OK;
+  }
   {
     mt3k::GemmArgs g = gemm_args(d_inputs, e->enc_in, e->x, M, emb, c.input_depth, emb);
     g.aux = e->pos_table;

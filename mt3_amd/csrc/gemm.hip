@@ -498,6 +498,165 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
 // group: 64 x 16 x 256 for the fold launch, 64 x 32 x 256 for GEGLU) measured 1 % slower as well
 // (profiles/r4_ab_tall_tiles_groups_wait.txt).  The staged 32 x 32 tile stays; both variants were removed again.)
 
+// ------------------------------------------------------------------ encoder-sized tile, f32 operands as three bf16 planes
+// Round 4, the f32 engine's encoder.  gfx950 multiplies f32 operands at 1/16 of its bf16 rate
+// (v_mfma_f32_16x16x4_f32: 32 cycles for K = 4; v_mfma_f32_16x16x32_bf16: 16 cycles for K = 32), and the f32 encoder sat at
+// 0.70 of THAT peak -- five times the bf16 encoder's time.  An f32 value is EXACTLY hi + mid + lo + r with three bf16
+// terms (hi = rne(x), mid = rne(x - hi), lo = rne(x - hi - mid); both subtractions are exact) and |r| <= 2^-27 |x|, so
+//   a . w = ah.wh + (ah.wm + am.wh) + (ah.wl + al.wh + am.wm) + [terms <= 2^-26 |a||w|, dropped]
+// -- SIX bf16 matrix instructions per 32 k instead of eight f32 ones of twice the duration: 96 against 256 cycles, with
+// bf16 products exact in f32 and the instruction's adder keeping >= 23 bits (tools/micro/mfma_bf16_accuracy.hip,
+// profiles/r4_mfma_bf16_accuracy.txt: one instruction 1.4e-7 of sum |p| whatever the exponent spread; a K = 512 dot
+// product of unit normals: this scheme 1.3e-7 of sum |p|, the f32 instruction chain 2.1e-7, two terms per operand
+// 8.6e-7).  So this is NOT a reduced-precision mode: it is at least as exact as the f32 instruction it replaces.
+// Weights are split once at finalize (three [N][K] bf16 planes = 1.5x the f32 bytes); activations are split while they
+// are staged (they arrive as f32 from the previous epilogue).  128 x 128 x 32 tile, 2 x 2 waves of 64 x 64, register
+// staged with the next slice in flight under the 96 MFMAs of the current one, six LDS planes of [128][32 + 16] bf16
+// (73.7 KB: two workgroups per CU), fused RMSNorm statistics from the f32 A stream exactly as in gemm_kernel, the same
+// epilogue code (CT = float: outputs are f32).
+__device__ __forceinline__ void split3_bf16(const float (&x)[8], u32x4* h, u32x4* m, u32x4* l) {
+  float hf[8], mf[8], lf[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hi = static_cast<__bf16>(x[i]);
+    const float r1 = x[i] - static_cast<float>(hi);             // exact
+    const __bf16 mi = static_cast<__bf16>(r1);
+    const float r2 = r1 - static_cast<float>(mi);               // exact
+    hf[i] = static_cast<float>(hi);
+    mf[i] = static_cast<float>(mi);
+    lf[i] = r2;
+  }
+  *h = pack_bf16x8(hf);       // (re-rounding an exactly representable value is the identity)
+  *m = pack_bf16x8(mf);
+  *l = pack_bf16x8(lf);
+}
+
+template <bool NORM, int EPI>
+__global__ __launch_bounds__(256) void gemm_x6_kernel(GemmArgs g, const __bf16* __restrict__ Wm,
+                                                       const __bf16* __restrict__ Wl) {
+  constexpr int BM = 128, BN = 128, BK = 32, ROWE = BK + 16, FM = 4, FN = 4, CPR = BK / 8;   // 4 chunks of 8 per tile row
+  __shared__ __attribute__((aligned(16))) __bf16 As[3][BM * ROWE];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[3][BN * ROWE];
+  __shared__ float ss_part[NORM ? BM : 1];
+
+  const float* const gA = static_cast<const float*>(g.A);
+  const __bf16* const gW[3] = {static_cast<const __bf16*>(g.Wt), Wm, Wl};
+  const int gM = g.M, gN = g.N, gK = g.K, gLda = g.lda;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = gN / BN;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+
+  // thread -> (row, chunk) of pass p: row = tid / 4 + 64 p, chunk = tid % 4 (the four lanes of a quad share a row)
+  const int ld_row = tid >> 2, ld_chunk = tid & 3;
+  float4 a_st[2][2];
+  u32x4 w_st[3][2];
+  float ss[2] = {0.f, 0.f};
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      int row = m0 + ld_row + 64 * p;
+      row = row < gM ? row : gM - 1;                       // clamp: such rows are never stored
+      const float4* src = reinterpret_cast<const float4*>(gA + static_cast<size_t>(row) * gLda + k0 + ld_chunk * 8);
+      a_st[p][0] = src[0];
+      a_st[p][1] = src[1];
+      const size_t e = static_cast<size_t>(n0 + ld_row + 64 * p) * gK + k0 + ld_chunk * 8;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) w_st[pl][p] = *reinterpret_cast<const u32x4*>(gW[pl] + e);
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frag_row = lane & 15, frag_g = lane >> 4;
+  const int a_off = (wm * 64 + frag_row) * ROWE + frag_g * 8, b_off = (wn * 64 + frag_row) * ROWE + frag_g * 8;
+
+  load(0);
+  for (int k0 = 0; k0 < gK; k0 += BK) {
+    __syncthreads();                                       // every wave is done reading the previous slice
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float f[8] = {a_st[p][0].x, a_st[p][0].y, a_st[p][0].z, a_st[p][0].w,
+                          a_st[p][1].x, a_st[p][1].y, a_st[p][1].z, a_st[p][1].w};
+      if constexpr (NORM) {
+        // explicit FMA chain in a fixed order: a row's statistics do not depend on where in a tile the row sits
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss[p] = __builtin_fmaf(f[i], f[i], ss[p]);
+      }
+      u32x4 h, m, l;
+      split3_bf16(f, &h, &m, &l);
+      const int at = (ld_row + 64 * p) * ROWE + ld_chunk * 8;
+      *reinterpret_cast<u32x4*>(&As[0][at]) = h;
+      *reinterpret_cast<u32x4*>(&As[1][at]) = m;
+      *reinterpret_cast<u32x4*>(&As[2][at]) = l;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(&Bs[pl][at]) = w_st[pl][p];
+    }
+    __syncthreads();
+    if (k0 + BK < gK) load(k0 + BK);                       // the next slice in flight under the MFMAs below
+    u32x4 bf[3][FN];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bf[pl][j] = *reinterpret_cast<const u32x4*>(&Bs[pl][b_off + j * 16 * ROWE]);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      u32x4 af[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const u32x4*>(&As[pl][a_off + i * 16 * ROWE]);
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {                       // smallest terms first
+        mfma_chunk<__bf16>(af[1], bf[1][j], acc[i][j]);    // mid . mid
+        mfma_chunk<__bf16>(af[0], bf[2][j], acc[i][j]);    // hi  . lo
+        mfma_chunk<__bf16>(af[2], bf[0][j], acc[i][j]);    // lo  . hi
+        mfma_chunk<__bf16>(af[0], bf[1][j], acc[i][j]);    // hi  . mid
+        mfma_chunk<__bf16>(af[1], bf[0][j], acc[i][j]);    // mid . hi
+        mfma_chunk<__bf16>(af[0], bf[0][j], acc[i][j]);    // hi  . hi
+      }
+    }
+  }
+  if constexpr (NORM) {
+    // the four lanes of a quad streamed one tile row: their partial sums of squares meet on the DPP network
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const float v = quad_sum(ss[p]);
+      if (ld_chunk == 0) ss_part[ld_row + 64 * p] = v;
+    }
+    __syncthreads();
+  }
+  auto row_rs = [&](int lrow) -> float {
+    if constexpr (!NORM) return 1.f;
+    return rsqrtf(ss_part[lrow] / static_cast<float>(gK) + 1e-6f);
+  };
+  const EpiCtx ec{g.out, g.aux, gM, gN, g.ldo, g.seq_len, nullptr, nullptr, nullptr, 0, 0, static_cast<const float*>(g.out)};
+  const float nopre[FM][FN][4] = {};
+  gemm_epilogue<float, EPI, FM, FN, false>(acc, wm, wn, lane, m0, n0, ec, row_rs, nopre);
+}
+
+int launch_gemm_x6(const GemmArgs& g, const void* Wm, const void* Wl, bool norm, int epi, hipStream_t s) {
+  if (g.M <= 0 || g.N % 128 || g.K % 32 || !g.A || !g.Wt || !Wm || !Wl || !g.out)
+    return mt3::fail(MT3_ERR_INVALID, "gemm_x6: bad shape or null pointer");
+  if (epi == MT3_EPI_POS && (!g.aux || g.seq_len <= 0)) return mt3::fail(MT3_ERR_INVALID, "gemm_x6: POS needs aux / seq_len");
+  if (epi == MT3_EPI_HEADS && (g.seq_len <= 0 || g.M % g.seq_len)) return mt3::fail(MT3_ERR_INVALID, "gemm_x6: HEADS needs M = B*T");
+  const dim3 grid(((g.M + 127) / 128) * (g.N / 128)), block(256);
+  const __bf16 *m = static_cast<const __bf16*>(Wm), *l = static_cast<const __bf16*>(Wl);
+#define MT3_X6(NORM, EPI) hipLaunchKernelGGL((gemm_x6_kernel<NORM, EPI>), grid, block, 0, s, g, m, l)
+  if (norm && epi == MT3_EPI_STORE) MT3_X6(true, MT3_EPI_STORE);
+  else if (norm && epi == MT3_EPI_GEGLU) MT3_X6(true, MT3_EPI_GEGLU);
+  else if (!norm && epi == MT3_EPI_RESID) MT3_X6(false, MT3_EPI_RESID);
+  else if (!norm && epi == MT3_EPI_POS) MT3_X6(false, MT3_EPI_POS);
+  else if (!norm && epi == MT3_EPI_HEADS) MT3_X6(false, MT3_EPI_HEADS);
+  else return mt3::fail(MT3_ERR_INVALID, "gemm_x6: unsupported (norm, epilogue) combination");
+#undef MT3_X6
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+
 // ------------------------------------------------------------------ encoder-sized tile, LDS-DMA staged (bf16)
 // 128x128x32 tile, 2x2 waves of 64x64 (4x4 MFMA fragments), both operands bf16 in memory.  The encoder GEMMs have
 // SHORT K (384 .. 1024) and operands that come from L2 / MALL at 1-2 us: with one K slice of look-ahead (the

@@ -48,6 +48,10 @@ constexpr int kEpiStoreQ = 6, kEpiResidQ = 7, kEpiResidS = 8;
 // norm: 0 none, 1 fused RMSNorm with statistics from the f32 A stream, 2 fused RMSNorm from g.a_ss (A = compute type)
 int launch_gemm(int dtype, const GemmArgs& g, bool a_f32, int norm, int epi, bool small, hipStream_t s);
 
+// f32 operands as three bf16 planes (gemm_x6_kernel, the f32 engine's encoder): A f32 [M][lda]; g.Wt / Wm / Wl = the hi /
+// mid / lo bf16 planes [N][K] of the weight; outputs f32.  (norm, epi): (true, STORE | GEGLU), (false, RESID | POS | HEADS)
+int launch_gemm_x6(const GemmArgs& g, const void* Wm, const void* Wl, bool norm, int epi, hipStream_t s);
+
 // encoder self-attention, qkv [B, T, 3, H, 64] -> out [B, T, H*64]
 int launch_encoder_attention(int dtype, const void* qkv, void* out, int B, int T, int H, hipStream_t s);
 

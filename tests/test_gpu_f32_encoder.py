@@ -1,0 +1,53 @@
+"""The f32 engine's encoder on the bf16 pipes (round 4; gemm.hip: gemm_x6_kernel).  Every f32 operand is split EXACTLY into
+three bf16 terms and the six significant products accumulate in f32: not a reduced-precision mode -- the instruction-level
+check (tools/micro/mfma_bf16_accuracy.hip) puts it at 1.3e-7 of sum |p| where the f32 matrix instruction is at 2.1e-7.
+Here: the engine's encoder output and first-step logits against the f32 oracle at the SAME bounds as before (1e-4), and
+against the engine that keeps the f32 instruction (option bit) to f32 round-off."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from mt3_amd import _lib, network  # noqa: E402
+from oracle import frontend as OF  # noqa: E402
+from oracle import network as ON  # noqa: E402
+
+
+@pytest.mark.parametrize("shape", ["mt3", "base_2_layers"])
+def test_f32_encoder_on_three_bf16_planes_is_as_exact_as_the_f32_instruction(shape):
+    import dataclasses
+    if shape == "mt3":
+        cfg = network.T5Config(dtype="float32")
+    else:     # emb 768, 12 heads, mlp 2048: N = 2304 / 768 / 4096 tiles, K = 768 / 2048
+        cfg = dataclasses.replace(network.MT3_BASE, dtype="float32", num_encoder_layers=2, num_decoder_layers=2)
+    params = network.init_random_params(cfg, seed=3, norm_scale_jitter=0.2)
+    B = 9                                                      # 2304 rows: the encoder-sized tile, a ragged last tile? no: 18 tiles
+    audio = OF.synth_audio(B, seed=12)
+    x = np.stack([OF.compute_logmel(a, np.float32) for a in audio])
+    x[4, 100:] = 0.0                                           # a short segment (zero rows after the log)
+    torch.set_num_threads(16)
+    orc = ON.Oracle(params, ON.T5Config(vocab_size=cfg.vocab_size, emb_dim=cfg.emb_dim, num_heads=cfg.num_heads,
+                                        num_encoder_layers=cfg.num_encoder_layers,
+                                        num_decoder_layers=cfg.num_decoder_layers, mlp_dim=cfg.mlp_dim))
+    with torch.no_grad():
+        enc_ref = orc.encode(x)
+        logits_ref = orc.decode_logits(enc_ref, np.zeros((B, 1), np.int32))[:, 0].numpy()
+    enc_ref = enc_ref.numpy()
+    outs = {}
+    for name, opt in (("three bf16 planes", 0), ("f32 instruction", _lib.OPT_X_F32_ENCODER_ON_F32_MFMA)):
+        eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=B, options=opt)
+        eng.load_params(params)
+        enc = eng.encode(torch.from_numpy(x).cuda(), return_encoded=True).cpu().numpy()
+        ids, logits0 = eng.decode(num_steps=24, return_first_logits=True)
+        outs[name] = (enc, logits0.cpu().numpy(), ids.cpu().numpy())
+        rel = [float(np.linalg.norm(enc[b] - enc_ref[b]) / np.linalg.norm(enc_ref[b])) for b in range(B)]
+        rl = float(np.linalg.norm(outs[name][1] - logits_ref) / np.linalg.norm(logits_ref))
+        print(f"f32 encoder [{shape}, {name}]: rel-L2 vs the f32 oracle max {max(rel):.3e}; step-0 logits {rl:.3e}")
+        assert max(rel) < 1e-4 and rl < 1e-4, (name, max(rel), rl)
+        del eng
+    a, b = outs["three bf16 planes"], outs["f32 instruction"]
+    d = max(float(np.linalg.norm(a[0][i] - b[0][i]) / np.linalg.norm(b[0][i])) for i in range(B))
+    print(f"f32 encoder [{shape}]: three bf16 planes vs the f32 instruction: max rel-L2 {d:.3e}")
+    assert d < 5e-6, d
+    assert np.array_equal(a[2], b[2]), "greedy ids of the two evaluations differ"
