@@ -30,19 +30,23 @@ def test_f32_encoder_on_three_bf16_planes_is_as_exact_as_the_f32_instruction(sha
     orc = ON.Oracle(params, ON.T5Config(vocab_size=cfg.vocab_size, emb_dim=cfg.emb_dim, num_heads=cfg.num_heads,
                                         num_encoder_layers=cfg.num_encoder_layers,
                                         num_decoder_layers=cfg.num_decoder_layers, mlp_dim=cfg.mlp_dim))
+    decode = shape == "mt3"          # (the f32 DECODE loop of the emb-768 shape is not built: its tiles hold K <= 512 partial sums)
     with torch.no_grad():
         enc_ref = orc.encode(x)
-        logits_ref = orc.decode_logits(enc_ref, np.zeros((B, 1), np.int32))[:, 0].numpy()
+        logits_ref = orc.decode_logits(enc_ref, np.zeros((B, 1), np.int32))[:, 0].numpy() if decode else None
     enc_ref = enc_ref.numpy()
     outs = {}
     for name, opt in (("three bf16 planes", 0), ("f32 instruction", _lib.OPT_X_F32_ENCODER_ON_F32_MFMA)):
         eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=B, options=opt)
         eng.load_params(params)
         enc = eng.encode(torch.from_numpy(x).cuda(), return_encoded=True).cpu().numpy()
-        ids, logits0 = eng.decode(num_steps=24, return_first_logits=True)
-        outs[name] = (enc, logits0.cpu().numpy(), ids.cpu().numpy())
         rel = [float(np.linalg.norm(enc[b] - enc_ref[b]) / np.linalg.norm(enc_ref[b])) for b in range(B)]
-        rl = float(np.linalg.norm(outs[name][1] - logits_ref) / np.linalg.norm(logits_ref))
+        outs[name] = [enc]
+        rl = 0.0
+        if decode:
+            ids, logits0 = eng.decode(num_steps=24, return_first_logits=True)
+            outs[name] += [logits0.cpu().numpy(), ids.cpu().numpy()]
+            rl = float(np.linalg.norm(outs[name][1] - logits_ref) / np.linalg.norm(logits_ref))
         print(f"f32 encoder [{shape}, {name}]: rel-L2 vs the f32 oracle max {max(rel):.3e}; step-0 logits {rl:.3e}")
         assert max(rel) < 1e-4 and rl < 1e-4, (name, max(rel), rl)
         del eng
@@ -50,4 +54,19 @@ def test_f32_encoder_on_three_bf16_planes_is_as_exact_as_the_f32_instruction(sha
     d = max(float(np.linalg.norm(a[0][i] - b[0][i]) / np.linalg.norm(b[0][i])) for i in range(B))
     print(f"f32 encoder [{shape}]: three bf16 planes vs the f32 instruction: max rel-L2 {d:.3e}")
     assert d < 5e-6, d
-    assert np.array_equal(a[2], b[2]), "greedy ids of the two evaluations differ"
+    if decode:
+        assert np.array_equal(a[2], b[2]), "greedy ids of the two evaluations differ"
+
+
+def test_f32_encoder_256_row_tile_matches_the_128_row_tile():
+    """A batch of >= 512 of the 256-row tiles takes them (B = 256: 256 x 4 .. 16 tiles), a smaller one the 128-row tile; the
+    per-element summation order is the same, so a segment's encoder output must not depend on the batch it sits in."""
+    cfg = network.T5Config(dtype="float32", num_encoder_layers=2, num_decoder_layers=1)
+    params = network.init_random_params(cfg, seed=4, norm_scale_jitter=0.2)
+    from mt3_amd import spectrograms, synthetic
+    lm = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(256, seed=6), None)
+    eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=256)
+    eng.load_params(params)
+    big = eng.encode(lm, return_encoded=True).clone()          # M = 65536: 256-row tiles (N = 512: 256 x 4 = 1024 tiles)
+    small = eng.encode(lm[:40], return_encoded=True).clone()   # M = 10240: 40 x 4 = 160 tall tiles < 512 -> 128-row tiles
+    assert torch.equal(big[:40], small)
