@@ -531,10 +531,11 @@ __device__ __forceinline__ void split3_bf16(const float (&x)[8], u32x4* h, u32x4
   *l = pack_bf16x8(lf);
 }
 
-// BM_ = 256 (launches of >= 512 such tiles): a wave owns 128 x 64 outputs, so a slice costs 36 fragment reads for 192 MFMAs
-// instead of 24 for 96 -- with six planes the 128-row tile is LDS-bandwidth-bound (288 KB through the LDS per CU and slice
-// against 1536 cycles of MFMA: measured 20.8 ms per encode, 1.37x the f32 instruction instead of 2.7x); 110 KB of LDS, one
-// workgroup per CU.
+// Measured (profiles/r4_ab_f32_encoder_x6.txt): encoder + cross-K/V 28.6 -> 20.8 ms at B = 256 (7.6 -> 5.5 at B = 64): 1.37x, not
+// the 2.7x of the instruction rates -- with six planes the tile is LDS-bandwidth-bound (288 KB through the LDS per CU and
+// slice: ~2250 cycles against 1536 of MFMA).  A 256-row tile (BM_ = 256: 36 fragment reads per 192 MFMAs instead of 24 per
+// 96, but 110 KB of LDS = ONE workgroup per CU) measured 26.1 ms -- the second co-resident workgroup is worth more than
+// the read ratio, as with the bf16 LDS-DMA tile -- and is not instantiated.
 template <bool NORM, int EPI, int BM_ = 128>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmArgs g, const __bf16* __restrict__ Wm,
                                                        const __bf16* __restrict__ Wl) {
@@ -657,15 +658,9 @@ int launch_gemm_x6(const GemmArgs& g, const void* Wm, const void* Wl, bool norm,
     return mt3::fail(MT3_ERR_INVALID, "gemm_x6: bad shape or null pointer");
   if (epi == MT3_EPI_POS && (!g.aux || g.seq_len <= 0)) return mt3::fail(MT3_ERR_INVALID, "gemm_x6: POS needs aux / seq_len");
   if (epi == MT3_EPI_HEADS && (g.seq_len <= 0 || g.M % g.seq_len)) return mt3::fail(MT3_ERR_INVALID, "gemm_x6: HEADS needs M = B*T");
-  const int grid256 = ((g.M + 255) / 256) * (g.N / 128);
-  const bool tall = grid256 >= 512;                      // two full rounds of one 256-row workgroup per CU
-  const dim3 grid(tall ? grid256 : ((g.M + 127) / 128) * (g.N / 128)), block(256);
+  const dim3 grid(((g.M + 127) / 128) * (g.N / 128)), block(256);
   const __bf16 *m = static_cast<const __bf16*>(Wm), *l = static_cast<const __bf16*>(Wl);
-#define MT3_X6(NORM, EPI)                                                                          \
-  do {                                                                                             \
-    if (tall) hipLaunchKernelGGL((gemm_x6_kernel<NORM, EPI, 256>), grid, block, 0, s, g, m, l);    \
-    else hipLaunchKernelGGL((gemm_x6_kernel<NORM, EPI, 128>), grid, block, 0, s, g, m, l);         \
-  } while (0)
+#define MT3_X6(NORM, EPI) hipLaunchKernelGGL((gemm_x6_kernel<NORM, EPI, 128>), grid, block, 0, s, g, m, l)
   if (norm && epi == MT3_EPI_STORE) MT3_X6(true, MT3_EPI_STORE);
   else if (norm && epi == MT3_EPI_GEGLU) MT3_X6(true, MT3_EPI_GEGLU);
   else if (!norm && epi == MT3_EPI_RESID) MT3_X6(false, MT3_EPI_RESID);
