@@ -81,12 +81,11 @@ int mt3_frontend_mel_matrix(const mt3_frontend* fe, float* h_out /*[(fft/2+1)*me
 int mt3_frontend_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segments,
                         int32_t frames_per_segment, const int32_t* h_n_frames /* may be NULL = all full */,
                         float* d_logmel, void* stream);
-/* The same with the per-segment frame counts already in DEVICE memory (caller-owned, must stay valid until the
- * launch has run).  mt3_frontend_logmel copies h_n_frames into a pre-sized ring inside the frontend (65536
- * counts, device + pinned mirror, created with the first call's tables): no allocation on the call path, the
- * caller's host buffer is free when the call returns, and calls never share a slot -- slot assignment is serialised
- * by a mutex (calls may come from several host threads), and when the ring wraps (once per 65536 ragged segments)
- * the call first waits for the device, so that no queued copy or launch still reads the slots it reuses. */
+/* mt3_frontend_logmel passes h_n_frames to the kernel BY VALUE (1024 counts per launch; longer calls are issued in
+ * pieces): the caller's host buffer is free when the call returns, nothing is allocated, copied, locked or waited for on
+ * the call path, any number of host threads and streams may call, and a stream may be under capture.
+ * mt3_frontend_logmel_dev: the same with the counts already in DEVICE memory (caller-owned, must stay valid until the
+ * launch has run). */
 int mt3_frontend_logmel_dev(mt3_frontend* fe, const float* d_audio, int32_t n_segments,
                             int32_t frames_per_segment, const int32_t* d_n_frames /* may be NULL */,
                             float* d_logmel, void* stream);
@@ -149,7 +148,7 @@ enum {
    * multiply on the bf16 pipes with every f32 operand split EXACTLY into three bf16 terms and the six significant
    * products accumulated in f32 -- at least as exact as the f32 instruction (measured 1.3e-7 against 2.1e-7 of sum |p| on
    * a K = 512 dot product) at 2.7x its rate; DESIGN.md section 3 */
-  MT3_OPT_X_F32_ENCODER_ON_F32_MFMA = 32
+  MT3_OPT_ENCODER_F32_MFMA = 32
 };
 
 typedef struct mt3_engine mt3_engine;

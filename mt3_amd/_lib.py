@@ -19,7 +19,7 @@ EPI_STORE, EPI_RESID, EPI_GEGLU, EPI_POS, EPI_F32, EPI_HEADS = range(6)
 DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SINGLE_STREAM, DECODE_ASYNC = 1, 2, 4, 8, 16
 (OPT_SINGLE_RESIDUAL_STREAM, OPT_SEPARATE_PROJECTIONS, OPT_ENCODER_SINGLE_RESIDUAL_STREAM,
  OPT_SEPARATE_QKV_PROJECTION, OPT_NO_ROW_GROUPS) = 1, 2, 4, 8, 16              # mt3_engine_config.options
-OPT_X_F32_ENCODER_ON_F32_MFMA = 32
+OPT_ENCODER_F32_MFMA = 32
 # include/mt3_hip_debug.h (measurement / fault injection; not the product ABI)
 DEBUG_SKIP_SELF_ATTN, DEBUG_SKIP_CROSS_ATTN = 1, 2
 (STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8, STATUS_Q_FOLD,

@@ -886,7 +886,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
   if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM |
-                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_X_F32_ENCODER_ON_F32_MFMA))
+                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_ENCODER_F32_MFMA))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -896,7 +896,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
     e->device = 0;                 // no GPU: the failure is reported by the first call that needs one (finalize)
   }
   e->dense_fp8 = cfg->dense_dtype == MT3_FP8_E4M3;
-  e->x6 = cfg->compute_dtype == MT3_F32 && !(cfg->options & MT3_OPT_X_F32_ENCODER_ON_F32_MFMA);
+  e->x6 = cfg->compute_dtype == MT3_F32 && !(cfg->options & MT3_OPT_ENCODER_F32_MFMA);
   e->esize = cfg->compute_dtype == MT3_BF16 ? 2 : 4;
   e->kv_fp8 = cfg->kv_cache_dtype == MT3_FP8_E4M3;
   e->kv_esize = e->kv_fp8 ? 1 : e->esize;

@@ -85,10 +85,19 @@ struct FrontendDev {
 // workgroup per CU instead of two of 256) -- measured 17-19 % SLOWER (186.9 against 156.0 us per 256 segments): the
 // kernel is latency-bound, not HBM-bound, and a single workgroup per CU has nobody to overlap its staging barrier and
 // its prologue with.  Outputs are bit-identical.
+// Per-segment frame counts that the caller holds in HOST memory travel as a kernel ARGUMENT (round 4): 1024 counts of 16
+// bits per launch, calls with more segments are issued in pieces.  (Rounds 2-3 copied them into a ring of device slots
+// behind a mutex and waited for the whole device when the ring wrapped -- a hidden synchronisation that also broke stream
+// capture; an argument needs no buffer, no lifetime and no lock.)
+constexpr int kCountsPerLaunch = 1024;
+struct FrameCounts {
+  uint16_t n[kCountsPerLaunch];
+};
+
 template <int kWaves>
 __global__ __launch_bounds__(kWaves * 64) void logmel_kernel(FrontendDev t, const float* __restrict__ audio,
                                                              const int* __restrict__ n_frames, int frames_per_segment,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int use_counts, FrameCounts counts) {
   constexpr int kTileFrames = kWaves * kFramesPerWave;                        // G
   constexpr int kTileSamples = kTileFrames * kHop + (mt3fe::kFft - kHop);     // 3968 / 6016
   constexpr int kThreads = kWaves * 64;
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(kWaves * 64) void logmel_kernel(FrontendDev t, cons
   const int seg = blockIdx.x / tiles;
   const int f0 = (blockIdx.x % tiles) * kTileFrames;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n = n_frames ? n_frames[seg] : frames_per_segment;
+  const int n = use_counts ? static_cast<int>(counts.n[seg]) : (n_frames ? n_frames[seg] : frames_per_segment);
   const int valid = n * kHop;                                    // samples of this segment that exist
   const float* seg_audio = audio + static_cast<size_t>(seg) * frames_per_segment * kHop;
 
@@ -174,13 +183,7 @@ struct mt3_frontend {
   void* d_off = nullptr;
   void* d_w = nullptr;           // group-padded transposed band weights (mt3fe::kPaddedWeights floats)
   std::vector<float> wpad;
-  // per-call frame counts travel through a pre-sized ring (device + pinned host mirror): nothing is allocated on
-  // the call path, the copy is stream-ordered from pinned memory, and a later call on another stream takes the
-  // NEXT slot instead of overwriting counts an earlier launch may still be reading
-  int* d_nframes = nullptr;
-  int* h_nframes = nullptr;
-  int ring_pos = 0;
-  std::mutex ring_mutex;         // ring_pos / first-call table upload: calls may come from several host threads
+  std::mutex table_mutex;        // first-call table upload: calls may come from several host threads
   bool on_device = false;
 };
 
@@ -212,10 +215,9 @@ int mt3_frontend_create(const mt3_frontend_config* cfg, mt3_frontend** out) {
 
 void mt3_frontend_destroy(mt3_frontend* fe) {
   if (!fe) return;
-  void* ptrs[] = {fe->d_hann, fe->d_tw1024, fe->d_tw2048, fe->d_k0, fe->d_cnt, fe->d_off, fe->d_w, fe->d_nframes};
+  void* ptrs[] = {fe->d_hann, fe->d_tw1024, fe->d_tw2048, fe->d_k0, fe->d_cnt, fe->d_off, fe->d_w};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  if (fe->h_nframes) (void)hipHostFree(fe->h_nframes);
   delete fe;
 }
 
@@ -226,8 +228,6 @@ int mt3_frontend_mel_matrix(const mt3_frontend* fe, float* h_out, int64_t* nnz) 
   return MT3_OK;
 }
 
-constexpr int kNFramesRing = 1 << 16;   // segments' worth of frame counts that can be in flight at once
-
 static int upload_all(mt3_frontend* fe) {
   int rc;
   if ((rc = upload(fe->host.hann, &fe->d_hann))) return rc;
@@ -237,42 +237,43 @@ static int upload_all(mt3_frontend* fe) {
   if ((rc = upload(fe->host.cnt, &fe->d_cnt))) return rc;
   if ((rc = upload(fe->host.off, &fe->d_off))) return rc;
   if ((rc = upload(fe->wpad, &fe->d_w))) return rc;
-  MT3_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&fe->d_nframes), sizeof(int) * kNFramesRing));
-  MT3_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&fe->h_nframes), sizeof(int) * kNFramesRing, hipHostMallocDefault));
   return MT3_OK;
 }
 
 static int ensure_device_tables(mt3_frontend* fe) {
-  std::lock_guard<std::mutex> lock(fe->ring_mutex);
+  std::lock_guard<std::mutex> lock(fe->table_mutex);
   if (fe->on_device) return MT3_OK;
   const int rc = upload_all(fe);
   if (rc != MT3_OK) {
     // a failed first call leaves nothing behind: the next call starts from scratch instead of leaking the tables
     // that did get uploaded (the error message of the failing step is kept)
-    void** ptrs[] = {&fe->d_hann, &fe->d_tw1024, &fe->d_tw2048, &fe->d_k0, &fe->d_cnt, &fe->d_off, &fe->d_w,
-                     reinterpret_cast<void**>(&fe->d_nframes)};
+    void** ptrs[] = {&fe->d_hann, &fe->d_tw1024, &fe->d_tw2048, &fe->d_k0, &fe->d_cnt, &fe->d_off, &fe->d_w};
     for (void** p : ptrs) {
       if (*p) (void)hipFree(*p);
       *p = nullptr;
     }
-    if (fe->h_nframes) (void)hipHostFree(fe->h_nframes);
-    fe->h_nframes = nullptr;
     return rc;
   }
   fe->on_device = true;
   return MT3_OK;
 }
 
+// h_n != nullptr: host-resident counts of exactly these n_segments (<= kCountsPerLaunch), passed by value
 static int launch_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segments, int32_t frames_per_segment,
-                         const int* d_n, float* d_logmel, hipStream_t s) {
+                         const int* d_n, float* d_logmel, hipStream_t s, const int32_t* h_n = nullptr) {
   FrontendDev t{static_cast<const float*>(fe->d_hann), static_cast<const cpx*>(fe->d_tw1024),
                 static_cast<const cpx*>(fe->d_tw2048), static_cast<const int*>(fe->d_k0),
                 static_cast<const int*>(fe->d_cnt),    static_cast<const int*>(fe->d_off),
                 static_cast<const float*>(fe->d_w), static_cast<int>(fe->host.w.size())};
   // 16-frame tiles, four waves (r3 also measured 32-frame tiles on eight waves: HBM traffic 1.178 -> 1.091 x the
   // algorithmic bytes, but 17-19 % slower -- one 135 KB workgroup per CU)
+  FrameCounts fc;
+  if (h_n)
+    for (int i = 0; i < n_segments; ++i) fc.n[i] = static_cast<uint16_t>(h_n[i]);
+  else
+    fc.n[0] = 0;                       // (unused; the rest of the argument is never read)
   hipLaunchKernelGGL(logmel_kernel<4>, dim3(n_segments * (frames_per_segment / 16)), dim3(256), 0, s, t, d_audio, d_n,
-                     frames_per_segment, d_logmel);
+                     frames_per_segment, d_logmel, h_n ? 1 : 0, fc);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }
@@ -291,32 +292,20 @@ int mt3_frontend_logmel(mt3_frontend* fe, const float* d_audio, int32_t n_segmen
   if (n_segments <= 0) return MT3_OK;
   if ((rc = ensure_device_tables(fe))) return rc;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int* d_n = nullptr;
-  if (h_n_frames) {
-    if (n_segments > kNFramesRing)
-      return mt3::fail(MT3_ERR_CAPACITY, "mt3_frontend_logmel: more than 65536 ragged segments in one call; split "
-                                         "the call or pass device counts to mt3_frontend_logmel_dev");
-    for (int i = 0; i < n_segments; ++i)
-      if (h_n_frames[i] < 0 || h_n_frames[i] > frames_per_segment)
-        return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_logmel: n_frames out of range");
-    int at;
-    {
-      std::lock_guard<std::mutex> lock(fe->ring_mutex);
-      at = fe->ring_pos;
-      if (at + n_segments > kNFramesRing) {
-        // the ring wraps: slots from the previous lap may still be read by copies / launches queued on ANY stream.
-        // Once per 65536 ragged segments the call waits for the device instead of overwriting them.
-        MT3_HIP_CHECK(hipDeviceSynchronize());
-        at = 0;
-      }
-      fe->ring_pos = at + n_segments;
-    }
-    std::memcpy(fe->h_nframes + at, h_n_frames, sizeof(int) * n_segments);      // the caller's buffer is free again
-    MT3_HIP_CHECK(hipMemcpyAsync(fe->d_nframes + at, fe->h_nframes + at, sizeof(int) * n_segments,
-                                 hipMemcpyHostToDevice, s));
-    d_n = fe->d_nframes + at;
+  if (!h_n_frames) return launch_logmel(fe, d_audio, n_segments, frames_per_segment, nullptr, d_logmel, s);
+  if (frames_per_segment > 65535) return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_logmel: frames_per_segment > 65535");
+  for (int i = 0; i < n_segments; ++i)
+    if (h_n_frames[i] < 0 || h_n_frames[i] > frames_per_segment)
+      return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_logmel: n_frames out of range");
+  // the counts ride in the launches themselves, kCountsPerLaunch segments apiece: the caller's buffer is free when the
+  // call returns, nothing is copied, allocated, locked or waited for
+  const size_t seg_in = static_cast<size_t>(frames_per_segment) * kHop, seg_out = static_cast<size_t>(frames_per_segment) * kMelBins;
+  for (int s0 = 0; s0 < n_segments; s0 += kCountsPerLaunch) {
+    const int n = n_segments - s0 < kCountsPerLaunch ? n_segments - s0 : kCountsPerLaunch;
+    rc = launch_logmel(fe, d_audio + s0 * seg_in, n, frames_per_segment, nullptr, d_logmel + s0 * seg_out, s, h_n_frames + s0);
+    if (rc) return rc;
   }
-  return launch_logmel(fe, d_audio, n_segments, frames_per_segment, d_n, d_logmel, s);
+  return MT3_OK;
 }
 
 int mt3_frontend_logmel_dev(mt3_frontend* fe, const float* d_audio, int32_t n_segments, int32_t frames_per_segment,

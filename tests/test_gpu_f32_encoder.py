@@ -36,7 +36,7 @@ def test_f32_encoder_on_three_bf16_planes_is_as_exact_as_the_f32_instruction(sha
         logits_ref = orc.decode_logits(enc_ref, np.zeros((B, 1), np.int32))[:, 0].numpy() if decode else None
     enc_ref = enc_ref.numpy()
     outs = {}
-    for name, opt in (("three bf16 planes", 0), ("f32 instruction", _lib.OPT_X_F32_ENCODER_ON_F32_MFMA)):
+    for name, opt in (("three bf16 planes", 0), ("f32 instruction", _lib.OPT_ENCODER_F32_MFMA)):
         eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=B, options=opt)
         eng.load_params(params)
         enc = eng.encode(torch.from_numpy(x).cuda(), return_encoded=True).cpu().numpy()

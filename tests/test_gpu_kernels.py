@@ -490,3 +490,33 @@ def test_frontend_vs_oracle():
     one = SP.compute_spectrogram(audio[0][: 100 * 128])
     np.testing.assert_array_equal(one, SP.compute_spectrogram_batch(torch.from_numpy(audio[:1]).cuda(), [100])
                                   .cpu().numpy()[0, :100])
+
+
+def test_frontend_host_counts_ride_in_the_launch_and_match_device_counts():
+    """Round 4: `mt3_frontend_logmel` passes the caller's host frame counts to the kernel by value, 1024 per launch (no
+    ring of device slots, no mutex, no device-wide wait): a call with MORE ragged segments than one launch carries is cut
+    into pieces, must equal `mt3_frontend_logmel_dev` with the same counts in device memory bit for bit, and works while
+    other calls are queued on other streams."""
+    from mt3_amd import spectrograms as SP, synthetic
+    S, F = 2500, 64                                              # 64-frame segments: 3 launches (1024 + 1024 + 452)
+    audio = synthetic.synth_audio(S, seed=5, seg_samples=F * 128)
+    rng = np.random.default_rng(2)
+    counts = rng.integers(0, F + 1, S).astype(np.int32)
+    counts[[0, 1023, 1024, 2047, 2048, S - 1]] = (F, 0, 1, F, 3, F - 1)
+    got = SP.compute_spectrogram_batch(audio, counts)
+    dev = torch.empty_like(got)
+    d_counts = torch.from_numpy(counts).cuda()
+    fe = SP._frontend(SP.SpectrogramConfig())
+    _lib.check(lib().mt3_frontend_logmel_dev(fe, audio.data_ptr(), S, F, d_counts.data_ptr(), dev.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(got, dev)
+    rows = torch.arange(F, device="cuda")[None, :] >= d_counts[:, None]
+    assert bool((got[rows] == 0).all()) and bool((got[~rows].abs().sum() > 0))
+    # calls from two streams interleave freely: each launch owns its counts
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s1):
+        a = SP.compute_spectrogram_batch(audio[:1500], counts[:1500])
+    with torch.cuda.stream(s2):
+        b = SP.compute_spectrogram_batch(audio[1500:], counts[1500:])
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([a, b]), got)

@@ -12,7 +12,7 @@ from mt3_amd import _lib, network, spectrograms, synthetic  # noqa: E402
 
 audio = synthetic.synth_audio(256, seed=1000)
 lm = spectrograms.compute_spectrogram_batch(audio, None)
-for name, opt in (("three bf16 planes (default)", 0), ("f32 matrix instruction", _lib.OPT_X_F32_ENCODER_ON_F32_MFMA)):
+for name, opt in (("three bf16 planes (default)", 0), ("f32 matrix instruction", _lib.OPT_ENCODER_F32_MFMA)):
     cfg = network.T5Config(dtype="float32")
     eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=256, options=opt)
     eng.load_params(network.init_random_params(cfg, seed=0))
