@@ -490,6 +490,16 @@ def main():
             extras["encoder"] = {"segments": Br, "ms": enc_ms, "bound": "mfma", "achieved": enc_tf, "peak": peak,
                                  "unit": "TFLOP/s", "frac": enc_tf / peak,
                                  "algorithmic_gflop_per_segment": ENC_GFLOP_PER_SEGMENT}
+            if esize == 4:
+                # the f32 engine's dense layers multiply on the bf16 pipes: every f32 operand as three exact bf16 terms, six
+                # bf16 products per f32 product (csrc/gemm.hip: gemm_x6_kernel) -- `achieved` / `frac` above are f32-EQUIVALENT
+                # flops against the f32 matrix instruction's peak (what the same work would need there), the instruction
+                # work actually issued is 6x that and belongs next to the bf16 peak
+                extras["encoder"].update({
+                    "note": "f32-equivalent flops over the f32 MFMA peak; the dense layers run as 6 bf16 MFMAs per f32 product "
+                            "(three exact bf16 planes per operand), the attention on the f32 instruction",
+                    "bf16_pipe_tflops": 6.0 * enc_tf, "bf16_peak": MFMA_BF16_PEAK_TFLOPS,
+                    "bf16_pipe_frac": 6.0 * enc_tf / MFMA_BF16_PEAK_TFLOPS})
             # BASELINE configs[1]: batch 64, log-mel + encoder (+ cross-K/V), encoder-only throughput
             n1 = min(64, Br)
             a64 = audio[:n1]
