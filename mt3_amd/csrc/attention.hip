@@ -655,16 +655,26 @@ __device__ __forceinline__ u32x4 fp8_quantize_quad(float* v, float* scale_out) {
   return c;
 }
 
-template <bool APPEND, int NW>
+template <bool APPEND, int NW, int UNROLL, int SPEC>
 __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
   constexpr int D = 64, EPL = 16;         // elements (= bytes) per lane
   constexpr int LPK = 4;                  // lanes sharing one key
   constexpr int KPW = 16;                 // keys per wave per load
   constexpr int STRIDE = NW * KPW;
-  constexpr int UNROLL = 4;
+  // UNROLL = keys per lane and iteration of the steady-state loop, SPEC = keys per lane requested before the row's
+  // length is known (self: 3 waves x 16 keys x 2 = 96; round 3's group of 4 x 48 = 192 keys over-read a short cache by
+  // half: traffic 1.49 x algorithmic at 129 keys).
   constexpr float kLog2e = 1.4426950408889634f;
 
   __shared__ float s_m[NW][LPK], s_l[NW][LPK], s_acc[NW][LPK][EPL];
+  // The step's own (dequantised) K / V row waits here for the end of the key loop instead of in 32 VGPRs of every
+  // lane: with UNROLL 3 that is 120 -> 92 VGPRs = five waves per SIMD, all six workgroups a CU gets at B x H = 1536
+  // resident together.  Measured (profiles/r4_ab_fp8_attention_variants.txt): self-attention 23.3 -> 23.0 us at 6 heads,
+  // 43.5 -> 42.2 at 12; the other combinations (4 keys per lane = four waves per SIMD again, 2, four waves per
+  // workgroup; cross: three waves, 3 keys) are equal or slower.  The launch costs what a line through the bf16 and f32
+  // kernels predicts for its bytes (6.2 us + bytes / 7.0 TB/s = 21.5 us): what keeps the e4m3 cache at 0.55-0.56 of the
+  // HBM peak is that fixed part on half the bytes, not residency, the tail merge or the conversions.
+  __shared__ float s_new[APPEND ? 2 : 1][LPK][EPL];
 
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -680,10 +690,10 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
   const float2* sc2 = a.kv_scale + head;
   // first key group requested before the row's position counter is known (see dec_attn_kernel); discarded by
   // position below, so the contents of the cache and of its scale array past the row's length do not matter
-  u32x4 kv0[UNROLL], vv0[UNROLL];
-  float2 ss0[UNROLL];
+  u32x4 kv0[SPEC], vv0[SPEC];
+  float2 ss0[SPEC];
 #pragma unroll
-  for (int u = 0; u < UNROLL; ++u) {
+  for (int u = 0; u < SPEC; ++u) {
     const int key = min(wave * KPW + slot + u * STRIDE, a.cap - 1);
     kv0[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kc + static_cast<size_t>(key) * D + sub * EPL));
     vv0[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vc + static_cast<size_t>(key) * D + sub * EPL));
@@ -694,7 +704,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
   const int n_cache = APPEND ? pos : n_keys;
   // discard by position what the speculative loads fetched from beyond the row's length (see dec_attn_kernel)
 #pragma unroll
-  for (int u = 0; u < UNROLL; ++u)
+  for (int u = 0; u < SPEC; ++u)
     if (wave * KPW + slot + u * STRIDE >= n_cache) {
       vv0[u] = u32x4{0u, 0u, 0u, 0u};
       ss0[u] = make_float2(0.f, 0.f);
@@ -755,6 +765,12 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
       *reinterpret_cast<u32x4*>(static_cast<uint8_t*>(a.kcache) + at) = kq;
       *reinterpret_cast<u32x4*>(static_cast<uint8_t*>(a.vcache) + at) = vq;
       if (tid == 0) const_cast<float2*>(sc2)[pos] = make_float2(ks, vs);
+      // (written and read back by the same four lanes: no barrier)
+#pragma unroll
+      for (int j = 0; j < EPL; j += 4) {
+        *reinterpret_cast<float4*>(&s_new[0][sub][j]) = make_float4(nk[j], nk[j + 1], nk[j + 2], nk[j + 3]);
+        *reinterpret_cast<float4*>(&s_new[APPEND ? 1 : 0][sub][j]) = make_float4(nv[j], nv[j + 1], nv[j + 2], nv[j + 3]);
+      }
     }
   }
 
@@ -762,11 +778,12 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
 #pragma unroll
   for (int j = 0; j < EPL; ++j) acc[j] = 0.f;
 
-  auto fold = [&](const u32x4 (&kv)[UNROLL], const u32x4 (&vv)[UNROLL], const float2 (&ss)[UNROLL], int base) {
-    float sc[UNROLL];
+  auto fold = [&](const auto& kv, const auto& vv, const auto& ss, int base) {
+    constexpr int G = static_cast<int>(sizeof(ss) / sizeof(float2));            // keys per lane in this group
+    float sc[G];
     float mn = m;
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < G; ++u) {
       float kf[EPL];
       fp8x16_to_f32(kv[u], kf);
       float d0 = 0.f, d1 = 0.f;
@@ -786,7 +803,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
 #pragma unroll
     for (int j = 0; j < EPL; ++j) acc[j] *= rs;
 #pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
+    for (int u = 0; u < G; ++u) {
       const float p = base + slot + u * STRIDE < n_cache ? __builtin_amdgcn_exp2f(sc[u] - mn) : 0.f;
       psum += p;
       const float pv = p * ss[u].y;
@@ -799,7 +816,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
     m = mn;
   };
   if (wave * KPW < n_cache) fold(kv0, vv0, ss0, wave * KPW);
-  for (int base = wave * KPW + STRIDE * UNROLL; base < n_cache; base += STRIDE * UNROLL) {
+  for (int base = wave * KPW + STRIDE * SPEC; base < n_cache; base += STRIDE * UNROLL) {
     u32x4 kv[UNROLL], vv[UNROLL];
     float2 ss[UNROLL];
 #pragma unroll
@@ -812,33 +829,44 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
     fold(kv, vv, ss, base);
   }
   if constexpr (APPEND) {
-    float d = 0.f;
+    if (tid < LPK) {                                       // the quad that wrote the new row attends it
+      float nkq[EPL], nvq[EPL];
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) d = __builtin_fmaf(q[j], nk[j], d);
-    d = dpp_add<0xB1>(d);
-    d = dpp_add<0x4E>(d);
-    const bool mine = tid < LPK;
-    const float mn = mine ? fmaxf(m, d) : m;
-    const float rs = __builtin_amdgcn_exp2f(m - mn);
-    const float p = mine ? __builtin_amdgcn_exp2f(d - mn) : 0.f;
+      for (int j = 0; j < EPL; j += 4) {
+        const float4 kx = *reinterpret_cast<const float4*>(&s_new[0][sub][j]);
+        const float4 vx = *reinterpret_cast<const float4*>(&s_new[1][sub][j]);
+        nkq[j] = kx.x, nkq[j + 1] = kx.y, nkq[j + 2] = kx.z, nkq[j + 3] = kx.w;
+        nvq[j] = vx.x, nvq[j + 1] = vx.y, nvq[j + 2] = vx.z, nvq[j + 3] = vx.w;
+      }
+      float d = 0.f;
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) acc[j] = __builtin_fmaf(p, nv[j], acc[j] * rs);
-    l = l * rs + p;
-    m = mn;
+      for (int j = 0; j < EPL; ++j) d = __builtin_fmaf(q[j], nkq[j], d);
+      d = dpp_add<0xB1>(d);
+      d = dpp_add<0x4E>(d);
+      const float mn = fmaxf(m, d);
+      const float rs = __builtin_amdgcn_exp2f(m - mn);
+      const float p = __builtin_amdgcn_exp2f(d - mn);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) acc[j] = __builtin_fmaf(p, nvq[j], acc[j] * rs);
+      l = l * rs + p;
+      m = mn;
+    }
   }
-#pragma unroll
-  for (int o = LPK; o < 64; o <<= 1) {
-    const float mo = __shfl_xor(m, o), lo = __shfl_xor(l, o);
+  // merge the 16 key slots of the wave (lanes of equal `sub`): inside a 16-lane row the partner arrives over the DPP
+  // network (row_ror 4, then 8: every lane ends up with its row's total), across rows through ds_bpermute
+  auto merge = [&](auto fetch) {
+    const float mo = fetch(m), lo = fetch(l);
     const float mn = fmaxf(m, mo);
     const float ca = __builtin_amdgcn_exp2f(m - mn), cb = __builtin_amdgcn_exp2f(mo - mn);
     l = l * ca + lo * cb;
 #pragma unroll
-    for (int j = 0; j < EPL; ++j) {
-      const float ao = __shfl_xor(acc[j], o);
-      acc[j] = acc[j] * ca + ao * cb;
-    }
+    for (int j = 0; j < EPL; ++j) acc[j] = acc[j] * ca + fetch(acc[j]) * cb;
     m = mn;
-  }
+  };
+  merge([](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true)); });
+  merge([](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)); });
+  merge([](float v) { return __shfl_xor(v, 16); });
+  merge([](float v) { return __shfl_xor(v, 32); });
   if (lane < LPK) {
     s_m[wave][lane] = m;
     s_l[wave][lane] = l;
@@ -921,8 +949,9 @@ int launch_decode_attention(int dtype, const DecAttnArgs& a, hipStream_t s) {
     // per wave: 12.4 us against 13.4 with 3)
     // fp8 (e4m3) K/V cache; activations (q, new rows, out) are bf16
     if (dtype != MT3_BF16) return mt3::fail(MT3_ERR_INVALID, "decode_attention: the fp8 K/V cache needs bf16 activations");
-    if (append) hipLaunchKernelGGL((dec_attn_fp8_kernel<true, 3>), dim3(a.B * a.H), dim3(192), 0, s, a);
-    else hipLaunchKernelGGL((dec_attn_fp8_kernel<false, 4>), dim3(a.B * a.H), dim3(256), 0, s, a);
+    // (round 4, profiles/r4_ab_fp8_attention_variants.txt: keys per lane in the loop / in the speculative group, waves)
+    if (append) hipLaunchKernelGGL((dec_attn_fp8_kernel<true, 3, 3, 2>), dim3(a.B * a.H), dim3(192), 0, s, a);
+    else hipLaunchKernelGGL((dec_attn_fp8_kernel<false, 4, 2, 2>), dim3(a.B * a.H), dim3(256), 0, s, a);
     MT3_HIP_CHECK(hipGetLastError());
     return MT3_OK;
   }

@@ -1263,8 +1263,10 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
 // 1 / 2 / 4 groups (profiles/r3_ab_row_groups_*.txt): bf16 B = 256: 626 / 588 / 608, B = 512: 1113 / 1048 / 1013;
 // f32 B = 128: 747 / 684 / 737, B = 256: 1178 / 1132 / 1098 -- groups of ~128 rows for bf16 operands, ~64 for f32.
 // (Three groups are never better than two or four.  EIGHT groups of 32 rows -- round 4, f32, B = 256: 2307 ms against
-// 1098 with four, the EOS-schedule decode 1052 against 380 ms, profiles/r4_ab_eight_row_groups.txt: beyond four streams
-// with queues of their own the hardware queues are oversubscribed and the groups take turns.)
+// 1098 with four, the EOS-schedule decode 1052 against 380 ms, profiles/r4_ab_eight_row_groups.txt.  The cliff is at
+// exactly FIVE: 5 / 6 groups 2421 / 2306 ms against 1106 with four (3: 1144), the same with GPU_MAX_HW_QUEUES=8 in the
+// environment, profiles/r4_ab_five_six_row_groups.txt -- a fifth busy queue shares a compute pipe with another one and
+// the two take turns, so the decode waits for a group running at half speed.  Four is the hardware's number.)
 static int row_groups_for(const mt3_engine_config& c, int batch) {
   const bool f32 = c.compute_dtype != MT3_BF16;
   if (batch >= (f32 ? 256 : 512)) return 4;
