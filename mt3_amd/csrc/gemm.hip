@@ -537,7 +537,7 @@ __device__ __forceinline__ void split3_bf16(const float (&x)[8], u32x4* h, u32x4
 // 96, but 110 KB of LDS = ONE workgroup per CU) measured 26.1 ms -- the second co-resident workgroup is worth more than
 // the read ratio, as with the bf16 LDS-DMA tile -- and is not instantiated.
 template <bool NORM, int EPI, int BM_ = 128>
-__global__ __launch_bounds__(256) void gemm_x6_kernel(GemmArgs g, const __bf16* __restrict__ Wm,
+__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g, const __bf16* __restrict__ Wm,
                                                        const __bf16* __restrict__ Wl) {
   constexpr int BM = BM_, BN = 128, BK = 32, ROWE = BK + 16, FM = BM / 32, FN = 4;   // 4 chunks of 8 per tile row
   constexpr int AP = BM / 64;                          // A passes per thread: 64 tile rows per pass
@@ -557,47 +557,58 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmArgs g, const __bf16* 
 
   // thread -> (row, chunk) of pass p: row = tid / 4 + 64 p, chunk = tid % 4 (the four lanes of a quad share a row)
   const int ld_row = tid >> 2, ld_chunk = tid & 3;
-  float4 a_st[AP][2];
-  u32x4 w_st[3][2];
-  float ss[AP];
+  // TWO K slices in flight in two sets of staging registers (40 VGPRs each): operands arrive from L2 / MALL / HBM in
+  // 2-3 us, a slice's 96 MFMAs take 0.64 us -- with one slice of look-ahead a workgroup spent most of every slice
+  // waiting for its loads (3.5 us per slice, matrix pipes 36 % busy with two workgroups per CU)
+  float4 a_st[2][AP][2];
+  u32x4 w_st[2][3][2];
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 ss2[AP];
 #pragma unroll
-  for (int p = 0; p < AP; ++p) ss[p] = 0.f;
-  auto load = [&](int k0) {
+  for (int p = 0; p < AP; ++p) ss2[p] = f32x2{0.f, 0.f};
+  // uniform base (SGPRs, advanced with k0) + one constant 32-bit byte offset per thread and pass: four address VGPRs for
+  // the twenty loads of the two sets
+  unsigned a_offs[AP], w_offs[2];
+#pragma unroll
+  for (int p = 0; p < AP; ++p) {
+    int row = m0 + ld_row + 64 * p;
+    row = row < gM ? row : gM - 1;                         // clamp: such rows are never stored
+    a_offs[p] = (static_cast<unsigned>(row) * static_cast<unsigned>(gLda) + ld_chunk * 8) * 4u;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) w_offs[p] = (static_cast<unsigned>(n0 + ld_row + 64 * p) * static_cast<unsigned>(gK) + ld_chunk * 8) * 2u;
+  auto load = [&](int k0, auto set) {
+    constexpr int S = decltype(set)::value;
+    const char* const ab = reinterpret_cast<const char*>(gA) + static_cast<size_t>(k0) * 4;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      int row = m0 + ld_row + 64 * p;
-      row = row < gM ? row : gM - 1;                       // clamp: such rows are never stored
-      const float4* src = reinterpret_cast<const float4*>(gA + static_cast<size_t>(row) * gLda + k0 + ld_chunk * 8);
-      a_st[p][0] = src[0];
-      a_st[p][1] = src[1];
+      const float4* src = reinterpret_cast<const float4*>(ab + a_offs[p]);
+      a_st[S][p][0] = src[0];
+      a_st[S][p][1] = src[1];
     }
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const size_t e = static_cast<size_t>(n0 + ld_row + 64 * p) * gK + k0 + ld_chunk * 8;
+    for (int pl = 0; pl < 3; ++pl) {
+      const char* const wb = reinterpret_cast<const char*>(gW[pl]) + static_cast<size_t>(k0) * 2;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) w_st[pl][p] = *reinterpret_cast<const u32x4*>(gW[pl] + e);
+      for (int p = 0; p < 2; ++p) w_st[S][pl][p] = *reinterpret_cast<const u32x4*>(wb + w_offs[p]);
     }
   };
-
-  f32x4 acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int frag_row = lane & 15, frag_g = lane >> 4;
-  const int a_off = (wm * (BM / 2) + frag_row) * ROWE + frag_g * 8, b_off = (wn * 64 + frag_row) * ROWE + frag_g * 8;
-
-  load(0);
-  for (int k0 = 0; k0 < gK; k0 += BK) {
-    __syncthreads();                                       // every wave is done reading the previous slice
+  // registers of one set -> the six LDS planes (A split into its three bf16 terms on the way)
+  auto stage = [&](auto set) {
+    constexpr int S = decltype(set)::value;
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const float f[8] = {a_st[p][0].x, a_st[p][0].y, a_st[p][0].z, a_st[p][0].w,
-                          a_st[p][1].x, a_st[p][1].y, a_st[p][1].z, a_st[p][1].w};
+      const float f[8] = {a_st[S][p][0].x, a_st[S][p][0].y, a_st[S][p][0].z, a_st[S][p][0].w,
+                          a_st[S][p][1].x, a_st[S][p][1].y, a_st[S][p][1].z, a_st[S][p][1].w};
       if constexpr (NORM) {
-        // explicit FMA chain in a fixed order: a row's statistics do not depend on where in a tile the row sits
+        // explicit FMA chains in a fixed order (even and odd elements, as register pairs: v_pk_fma_f32 on the pairs the
+        // loads deliver -- a scalar chain per pass gets paired ACROSS the passes and shuffles freshly loaded registers):
+        // a row's statistics do not depend on where in a tile the row sits
 #pragma unroll
-        for (int i = 0; i < 8; ++i) ss[p] = __builtin_fmaf(f[i], f[i], ss[p]);
+        for (int i = 0; i < 8; i += 2) {
+          const f32x2 v = {f[i], f[i + 1]};
+          ss2[p] = __builtin_elementwise_fma(v, v, ss2[p]);
+        }
       }
       u32x4 h, m, l;
       split3_bf16(f, &h, &m, &l);
@@ -610,36 +621,86 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmArgs g, const __bf16* 
     for (int p = 0; p < 2; ++p) {
       const int at = (ld_row + 64 * p) * ROWE + ld_chunk * 8;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(&Bs[pl][at]) = w_st[pl][p];
+      for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(&Bs[pl][at]) = w_st[S][pl][p];
     }
-    __syncthreads();
-    if (k0 + BK < gK) load(k0 + BK);                       // the next slice in flight under the MFMAs below
-    u32x4 bf[3][FN];
+  };
+
+  f32x4 acc[FM][FN];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bf[pl][j] = *reinterpret_cast<const u32x4*>(&Bs[pl][b_off + j * 16 * ROWE]);
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int frag_row = lane & 15, frag_g = lane >> 4;
+  const int a_off = (wm * (BM / 2) + frag_row) * ROWE + frag_g * 8, b_off = (wn * 64 + frag_row) * ROWE + frag_g * 8;
+  // the 96 MFMAs of the slice in LDS.  The wave's four column fragments go in two halves so that the second set of
+  // staging registers fits (B fragments of two columns live at a time; the A fragments are read once per half)
+  auto mfma_slice = [&]() {
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      u32x4 af[3];
+    for (int jh = 0; jh < FN; jh += 2) {
+      u32x4 bf[3][2];
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const u32x4*>(&As[pl][a_off + i * 16 * ROWE]);
+      for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {                       // smallest terms first
-        mfma_chunk<__bf16>(af[1], bf[1][j], acc[i][j]);    // mid . mid
-        mfma_chunk<__bf16>(af[0], bf[2][j], acc[i][j]);    // hi  . lo
-        mfma_chunk<__bf16>(af[2], bf[0][j], acc[i][j]);    // lo  . hi
-        mfma_chunk<__bf16>(af[0], bf[1][j], acc[i][j]);    // hi  . mid
-        mfma_chunk<__bf16>(af[1], bf[0][j], acc[i][j]);    // mid . hi
-        mfma_chunk<__bf16>(af[0], bf[0][j], acc[i][j]);    // hi  . hi
+        for (int j = 0; j < 2; ++j) bf[pl][j] = *reinterpret_cast<const u32x4*>(&Bs[pl][b_off + (jh + j) * 16 * ROWE]);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        u32x4 af[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) af[pl] = *reinterpret_cast<const u32x4*>(&As[pl][a_off + i * 16 * ROWE]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                      // smallest terms first
+          mfma_chunk<__bf16>(af[1], bf[1][j], acc[i][jh + j]);    // mid . mid
+          mfma_chunk<__bf16>(af[0], bf[2][j], acc[i][jh + j]);    // hi  . lo
+          mfma_chunk<__bf16>(af[2], bf[0][j], acc[i][jh + j]);    // lo  . hi
+          mfma_chunk<__bf16>(af[0], bf[1][j], acc[i][jh + j]);    // hi  . mid
+          mfma_chunk<__bf16>(af[1], bf[0][j], acc[i][jh + j]);    // mid . hi
+          mfma_chunk<__bf16>(af[0], bf[0][j], acc[i][jh + j]);    // hi  . hi
+        }
       }
     }
+  };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+
+  // K is a multiple of 2 BK (launch_gemm_x6): slices go in pairs, and the steady-state loop reloads BOTH sets
+  // unconditionally -- with the reload under an `if` the compiler has to assume the path without newer loads and
+  // waits for every outstanding load (vmcnt 0) before it touches a set, which is one slice of look-ahead again
+  load(0, Set0{});
+  __builtin_amdgcn_sched_barrier(0);                       // set 0's loads are all older than set 1's (counted vmcnt waits)
+  load(BK, Set1{});
+  __builtin_amdgcn_sched_barrier(0);
+  int k0 = 0;
+  // (a fence behind each reload that vector-ALU and vector-memory instructions may not cross: the split of the OTHER set,
+  // hoisted in front of part of this reload, would wait for that part -- a fresh memory round trip in the middle of the
+  // slice; SALU, MFMA and LDS instructions move freely)
+  constexpr int kNoValuNoVmem = 0x4 | 0x8 | 0x80 | 0x100 | 0x200;
+  for (; k0 + 2 * BK < gK; k0 += 2 * BK) {
+    __syncthreads();                                       // every wave is done reading the previous slice
+    stage(Set0{});
+    __syncthreads();
+    load(k0 + 2 * BK, Set0{});                             // two slices ahead, under this slice's and the next one's MFMAs
+    __builtin_amdgcn_sched_barrier(kNoValuNoVmem);
+    mfma_slice();
+    __syncthreads();
+    stage(Set1{});
+    __syncthreads();
+    load(k0 + 3 * BK, Set1{});
+    __builtin_amdgcn_sched_barrier(kNoValuNoVmem);
+    mfma_slice();
   }
+  __syncthreads();
+  stage(Set0{});
+  __syncthreads();
+  mfma_slice();
+  __syncthreads();
+  stage(Set1{});
+  __syncthreads();
+  mfma_slice();
   if constexpr (NORM) {
     // the four lanes of a quad streamed one tile row: their partial sums of squares meet on the DPP network
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const float v = quad_sum(ss[p]);
+      const float v = quad_sum(ss2[p][0] + ss2[p][1]);
       if (ld_chunk == 0) ss_part[ld_row + 64 * p] = v;
     }
     __syncthreads();
@@ -654,8 +715,11 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(GemmArgs g, const __bf16* 
 }
 
 int launch_gemm_x6(const GemmArgs& g, const void* Wm, const void* Wl, bool norm, int epi, hipStream_t s) {
-  if (g.M <= 0 || g.N % 128 || g.K % 32 || !g.A || !g.Wt || !Wm || !Wl || !g.out)
+  if (g.M <= 0 || g.N % 128 || g.K % 64 || g.K < 64 || !g.A || !g.Wt || !Wm || !Wl || !g.out)
     return mt3::fail(MT3_ERR_INVALID, "gemm_x6: bad shape or null pointer");
+  // 32-bit byte offsets from the operand bases (kernel: a_offs / w_offs)
+  if (static_cast<size_t>(g.M) * g.lda * 4 >= (1ull << 32) || static_cast<size_t>(g.N) * g.K * 2 >= (1ull << 32))
+    return mt3::fail(MT3_ERR_INVALID, "gemm_x6: operand larger than 4 GB");
   if (epi == MT3_EPI_POS && (!g.aux || g.seq_len <= 0)) return mt3::fail(MT3_ERR_INVALID, "gemm_x6: POS needs aux / seq_len");
   if (epi == MT3_EPI_HEADS && (g.seq_len <= 0 || g.M % g.seq_len)) return mt3::fail(MT3_ERR_INVALID, "gemm_x6: HEADS needs M = B*T");
   const dim3 grid(((g.M + 127) / 128) * (g.N / 128)), block(256);
