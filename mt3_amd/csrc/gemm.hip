@@ -535,7 +535,10 @@ __device__ __forceinline__ void split3_bf16(const float (&x)[8], u32x4* h, u32x4
 // the 2.7x of the instruction rates -- with six planes the tile is LDS-bandwidth-bound (288 KB through the LDS per CU and
 // slice: ~2250 cycles against 1536 of MFMA).  A 256-row tile (BM_ = 256: 36 fragment reads per 192 MFMAs instead of 24 per
 // 96, but 110 KB of LDS = ONE workgroup per CU) measured 26.1 ms -- the second co-resident workgroup is worth more than
-// the read ratio, as with the bf16 LDS-DMA tile -- and is not instantiated.
+// the read ratio, as with the bf16 LDS-DMA tile -- and is not instantiated.  Two K slices in flight (below): 20.8 -> 19.6 ms.
+// W fragments loaded straight into registers in the MFMA lane layout (16 B per lane from row n: no LDS pass for W, 72
+// instead of 168 KB through the LDS per workgroup and slice), with one or two sets in flight and two or three workgroups
+// per CU: 21.9 - 23.3 ms -- the 64-byte row pieces cost more in the L1 path than the LDS passes they replace; removed.
 template <bool NORM, int EPI, int BM_ = 128>
 __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g, const __bf16* __restrict__ Wm,
                                                        const __bf16* __restrict__ Wl) {
