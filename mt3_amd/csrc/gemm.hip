@@ -496,7 +496,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
 // bytes through the L1s as 64-byte row pieces, and the wider tile losing LESS says the launches are bound by L1 / L2
 // request throughput, not by the dependent chain inside a workgroup.  64-row f32 tiles (one weight fetch per 64-row
 // group: 64 x 16 x 256 for the fold launch, 64 x 32 x 256 for GEGLU) measured 1 % slower as well
-// (profiles/r4_ab_tall_tiles_groups_wait.txt).  The staged 32 x 32 tile stays; both variants were removed again.)
+// (profiles/r4_ab_tall_tiles_groups_wait.txt), and so did the opposite: 16 x 32 / 16 x 64 staged tiles on two waves for
+// the launches of a 64-row group (all of which leave more than half of the CUs idle) -- three quarters of the bytes per
+// workgroup on twice the workgroups: 1101 -> 1155 ms (profiles/r4_ab_16_row_f32_tiles.txt).  Fewer bytes per workgroup,
+// fewer bytes in total, more workgroups, fewer workgroups: each is slower than the staged 32 x 32 tile, which stays.)
 
 // ------------------------------------------------------------------ encoder-sized tile, f32 operands as three bf16 planes
 // Round 4, the f32 engine's encoder.  gfx950 multiplies f32 operands at 1/16 of its bf16 rate
