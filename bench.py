@@ -48,6 +48,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0
 MFMA_F32_PEAK_TFLOPS = 157.3
 MFMA_FP8_PEAK_TFLOPS = 5000.0              # dense MX-scaled fp8 (K = 128 instructions), MI355X_MICROARCH.md
 ENC_GFLOP_PER_SEGMENT = 10.603 + 1.611     # encoder + the one-off cross-K/V projections of 8 layers
+ENC_ATTN_GFLOP_PER_SEGMENT = 8 * 6 * 2 * 2 * 256 * 256 * 64 / 1e9      # of which QK^T and PV: 8 layers x 6 heads (0.805)
 FRONTEND_BYTES_PER_SEGMENT = 655360        # 131072 in + 524288 out
 FRONTEND_SOURCES = ("frontend.hip", "frontend_core.h", "frontend_tables.h")
 
@@ -487,19 +488,24 @@ def main():
                                   "traffic_source": "profiles/%s (frontend sources %s)" % (fe_name, fe_hash)
                                   if fe_ratio else "no PMC summary for these frontend sources"}
             enc_tf = ENC_GFLOP_PER_SEGMENT * Br / (enc_ms * 1e-3) / 1e3
-            extras["encoder"] = {"segments": Br, "ms": enc_ms, "bound": "mfma", "achieved": enc_tf, "peak": peak,
-                                 "unit": "TFLOP/s", "frac": enc_tf / peak,
+
+            def mfma_block(tf):
+                """roofline fields of an encoder figure.  The f32 engine's dense layers multiply on the bf16 pipes: every
+                f32 operand as three exact bf16 terms, six bf16 products per f32 product (csrc/gemm.hip: gemm_x6_kernel),
+                so its matrix-instruction work is 6x the algorithmic flops and is priced against the BF16 peak -- against
+                the f32 instruction's peak the same figure would read above 1"""
+                if esize == 2:
+                    return {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}
+                dense = 1.0 - ENC_ATTN_GFLOP_PER_SEGMENT / ENC_GFLOP_PER_SEGMENT      # share of the flops in the dense layers
+                return {"bound": "mfma", "achieved": 6.0 * dense * tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": 6.0 * dense * tf / MFMA_BF16_PEAK_TFLOPS, "f32_equivalent_tflops": tf,
+                        "f32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
+                        "note": "achieved = bf16 matrix-instruction work of the dense layers (6 bf16 MFMAs per f32 product: "
+                                "three exact bf16 planes per operand) over the WHOLE time, of which the encoder attention -- %.1f %% "
+                                "of the flops, on the f32 instruction -- takes about a fifth; f32_equivalent_tflops = all "
+                                "algorithmic flops / time" % (100.0 * (1.0 - dense))}
+            extras["encoder"] = {"segments": Br, "ms": enc_ms, **mfma_block(enc_tf),
                                  "algorithmic_gflop_per_segment": ENC_GFLOP_PER_SEGMENT}
-            if esize == 4:
-                # the f32 engine's dense layers multiply on the bf16 pipes: every f32 operand as three exact bf16 terms, six
-                # bf16 products per f32 product (csrc/gemm.hip: gemm_x6_kernel) -- `achieved` / `frac` above are f32-EQUIVALENT
-                # flops against the f32 matrix instruction's peak (what the same work would need there), the instruction
-                # work actually issued is 6x that and belongs next to the bf16 peak
-                extras["encoder"].update({
-                    "note": "f32-equivalent flops over the f32 MFMA peak; the dense layers run as 6 bf16 MFMAs per f32 product "
-                            "(three exact bf16 planes per operand), the attention on the f32 instruction",
-                    "bf16_pipe_tflops": 6.0 * enc_tf, "bf16_peak": MFMA_BF16_PEAK_TFLOPS,
-                    "bf16_pipe_frac": 6.0 * enc_tf / MFMA_BF16_PEAK_TFLOPS})
             # BASELINE configs[1]: batch 64, log-mel + encoder (+ cross-K/V), encoder-only throughput
             n1 = min(64, Br)
             a64 = audio[:n1]
@@ -512,7 +518,7 @@ def main():
             extras["configs1"] = {"workload": "BASELINE configs[1]: batch=%d synthetic segments, log-mel + encoder "
                                               "(+ cross-K/V projections), no decode" % n1,
                                   "segments_per_s": n1 / (c1_ms * 1e-3), "audio_s_per_s": n1 * SEG_SECONDS / (c1_ms * 1e-3),
-                                  "ms": c1_ms, "achieved": c1_tf, "peak": peak, "unit": "TFLOP/s", "frac": c1_tf / peak}
+                                  "ms": c1_ms, **mfma_block(c1_tf)}
             with torch.cuda.stream(stream):
                 eng.encode(lm256)                                    # leave the engine at the bench batch
 

@@ -1,6 +1,6 @@
 """Encoder passes (B=256) for a rocprofv3 --pmc run: what are the big GEMM / attention waves waiting on?
-Two engines in one process: the bf16 encoder (gemm_glds_kernel) and the MXFP8 encoder (gemm_mx8_kernel); their GEMM
-kernels have different names, the attention kernel is shared."""
+Three engines in one process: the bf16 encoder (gemm_glds_kernel), the MXFP8 encoder (gemm_mx8_kernel) and the f32
+encoder (gemm_x6_kernel: three bf16 planes per operand; enc_attn_kernel<float>); their GEMM kernels have different names."""
 import dataclasses
 import os
 import sys
@@ -19,4 +19,11 @@ for dense in ("", "fp8_e4m3"):
         eng.encode(x)
     torch.cuda.synchronize()
     del eng
+cfg = network.T5Config(dtype="float32")
+eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=256)
+eng.load_params(network.init_random_params(cfg, seed=0))
+for _ in range(2):
+    eng.encode(x)
+torch.cuda.synchronize()
+del eng
 print("pmc_encoder done")

@@ -24,10 +24,14 @@ def short(name):
         epi = ["STORE", "RESID", "GEGLU", "POS", "F32", "HEADS"][int(m.group(2))]
         bm = m.group(4) or "128"
         return ("gemm LDS-DMA bf16 %sx128x32 " % bm if m.group(1) == "glds" else "gemm MXFP8 128x128x128 ") + epi
+    m = re.search(r"gemm_x6_kernelILb(\d)ELi(\d)", name) or re.search(r"gemm_x6_kernel<(true|false|\d), (\d)", name)
+    if m:
+        epi = ["STORE", "RESID", "GEGLU", "POS", "F32", "HEADS"][int(m.group(2))]
+        return "gemm f32 as 3 bf16 planes 128x128x32 " + ("norm " if m.group(1) in ("1", "true") else "") + epi
     if "mx8_quantize" in name:
         return "mx8_quantize"
     if "enc_attn" in name:
-        return "enc_attn"
+        return "enc_attn f32" if ("IfL" in name or "<float" in name) else "enc_attn"
     if "logmel" in name:
         return "logmel"
     return None
