@@ -561,8 +561,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g, const __bf1
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
 
-  // thread -> (row, chunk) of pass p: row = tid / 4 + 64 p, chunk = tid % 4 (the four lanes of a quad share a row)
-  const int ld_row = tid >> 2, ld_chunk = tid & 3;
+  // thread -> (row, chunk) of pass p (64 tile rows per pass, 4 chunks of 8 elements per row): every 8 consecutive lanes
+  // take 4 rows x 2 chunks -- at the 96-byte row stride (which makes the fragment READS conflict-free) the eight 16-byte
+  // slots of such a group are distinct mod 128 bytes, so a ds_write_b128 pass is conflict-free too; with 2 rows x 4
+  // chunks per 8 lanes (a quad per row) the second row started 96 bytes after the first and overlapped its first 32
+  // bytes' banks: a third of the tile's LDS-active cycles were bank conflicts (counter passes of tools/gpu_pmc_enc.sh:
+  // 0.05 - 0.07 per wave cycle, 0.0000 now, LDS-active cycles down by a third; the TIME did not move -- the tile is not
+  // LDS-bound: matrix pipes busy 0.52 / 0.56 of the cycles in the two big launches, profiles/r4_pmc_encoder_summary.json).
+  // The four lanes of a row are t, t ^ 1, t ^ 8, t ^ 9.
+  const int ld_chunk = (tid & 1) | ((tid >> 2) & 2);
+  const int ld_row = ((tid >> 1) & 3) | ((tid >> 4) << 2);
   // TWO K slices in flight in two sets of staging registers (40 VGPRs each): operands arrive from L2 / MALL / HBM in
   // 2-3 us, a slice's 96 MFMAs take 0.64 us -- with one slice of look-ahead a workgroup spent most of every slice
   // waiting for its loads (3.5 us per slice, matrix pipes 36 % busy with two workgroups per CU)
@@ -703,10 +711,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g, const __bf1
   __syncthreads();
   mfma_slice();
   if constexpr (NORM) {
-    // the four lanes of a quad streamed one tile row: their partial sums of squares meet on the DPP network
+    // the four lanes that streamed one tile row: their partial sums of squares meet on the DPP network (xor 1, then xor 8)
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
-      const float v = quad_sum(ss2[p][0] + ss2[p][1]);
+      float v = ss2[p][0] + ss2[p][1];                     // lanes t, t ^ 1, t ^ 8, t ^ 9 streamed one tile row
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
       if (ld_chunk == 0) ss_part[ld_row + 64 * p] = v;
     }
     __syncthreads();
