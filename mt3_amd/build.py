@@ -17,7 +17,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmt3hip.so")
 OBJ = os.path.join(ROOT, "build", "obj")
 
-HIP_SOURCES = ["frontend.hip", "gemm.hip", "gemm_mx8.hip", "attention.hip", "decode_ops.hip", "engine.hip"]
+HIP_SOURCES = ["frontend.hip", "gemm.hip", "gemm_mx8.hip", "attention.hip", "enc_attention_x6.hip", "decode_ops.hip",
+               "engine.hip"]
 CPP_SOURCES = ["errors.cpp", "symbolic.cpp", "mx8_host.cpp"]
 
 

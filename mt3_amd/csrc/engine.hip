@@ -41,6 +41,11 @@
 
 #include "common.h"
 #include "kernels.h"
+
+namespace mt3k {
+// enc_attention_x6.hip: the f32 engine's encoder attention with Q, K, V and P as three bf16 planes each
+int launch_encoder_attention_x6(const void* qkv, void* out, int B, int T, int H, hipStream_t s);
+}  // namespace mt3k
 #include "mx8.h"
 #include "mt3_hip.h"
 #include "mt3_hip_debug.h"
@@ -1143,7 +1148,7 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
     for (int l = 0; l < c.num_encoder_layers; ++l) {
       LayerDev& L = e->enc[l];
       MT3_TRY(x6(e->x, L.wqkv_p, e->qkv, 3 * hd, emb, 3 * hd, true, MT3_EPI_STORE, 0));
-      MT3_TRY(mt3k::launch_encoder_attention(dt, e->qkv, e->attn, batch, T, c.num_heads, s));
+      MT3_TRY(mt3k::launch_encoder_attention_x6(e->qkv, e->attn, batch, T, c.num_heads, s));
       MT3_TRY(x6(e->attn, L.wo_p, e->x, emb, hd, emb, false, MT3_EPI_RESID, 0));
       MT3_TRY(x6(e->x, L.wi_p, e->hbuf, 2 * c.mlp_dim, emb, c.mlp_dim, true, MT3_EPI_GEGLU, 0));
       MT3_TRY(x6(e->hbuf, L.wo_mlp_p, e->x, emb, c.mlp_dim, emb, false, MT3_EPI_RESID, 0));
