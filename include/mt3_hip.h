@@ -144,10 +144,10 @@ enum {
   MT3_OPT_SEPARATE_QKV_PROJECTION = 8,
   /* never use the row-group decode schedule (see mt3_engine_decode): every decode stays on the caller's stream */
   MT3_OPT_NO_ROW_GROUPS = 16,
-  /* f32 engine: keep the encoder's dense layers on the f32 matrix instruction (v_mfma_f32_16x16x4_f32).  By default they
-   * multiply on the bf16 pipes with every f32 operand split EXACTLY into three bf16 terms and the six significant
-   * products accumulated in f32 -- at least as exact as the f32 instruction (measured 1.3e-7 against 2.1e-7 of sum |p| on
-   * a K = 512 dot product) at 2.7x its rate; DESIGN.md section 3 */
+  /* f32 engine: keep the encoder's dense layers and attention on the f32 matrix instruction (v_mfma_f32_16x16x4_f32).  By
+   * default they multiply on the bf16 pipes with every f32 operand split EXACTLY into three bf16 terms and the six
+   * significant products accumulated in f32 -- at least as exact as the f32 instruction (measured 1.3e-7 against 2.1e-7
+   * of sum |p| on a K = 512 dot product) at 2.7x its rate; DESIGN.md section 3 */
   MT3_OPT_ENCODER_F32_MFMA = 32
 };
 
