@@ -1270,8 +1270,8 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
 // (Three groups are never better than two or four.  EIGHT groups of 32 rows -- round 4, f32, B = 256: 2307 ms against
 // 1098 with four, the EOS-schedule decode 1052 against 380 ms, profiles/r4_ab_eight_row_groups.txt.  The cliff is at
 // exactly FIVE: 5 / 6 groups 2421 / 2306 ms against 1106 with four (3: 1144), the same with GPU_MAX_HW_QUEUES=8 in the
-// environment, profiles/r4_ab_five_six_row_groups.txt -- a fifth busy queue shares a compute pipe with another one and
-// the two take turns, so the decode waits for a group running at half speed.  Four is the hardware's number.)
+// environment, profiles/r4_ab_five_six_row_groups.txt -- as if a fifth busy queue shared one of four compute pipes with
+// another one and the two took turns (the decode waits for a group running at half speed).  Four it is.)
 static int row_groups_for(const mt3_engine_config& c, int batch) {
   const bool f32 = c.compute_dtype != MT3_BF16;
   if (batch >= (f32 ? 256 : 512)) return 4;
