@@ -1135,7 +1135,11 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), T = c.input_length;
   const int M = batch * T;
   const bool small = M < 2048;
-  if (e->x6 && !small) {
+  // (gemm_x6_kernel addresses its operands with 32-bit byte offsets: a batch whose widest f32 activation matrix reaches
+  // 4 GB -- 4096 segments at the MT3 shape -- takes the f32-instruction path below instead of failing)
+  const int widest = std::max(std::max(c.input_depth, emb), std::max(hd, c.mlp_dim));
+  const bool x6_fits = static_cast<size_t>(M) * widest * 4 < (1ull << 32);
+  if (e->x6 && !small && x6_fits) {
     // f32 engine, encoder-sized launches: every dense layer on the bf16 pipes with three planes per operand (gemm.hip,
     // gemm_x6_kernel: at least as exact as the f32 matrix instruction, 2.7x its rate); attention and norms as before
     auto x6 = [&](const void* A, void* (&W)[3], void* out, int N, int K, int ldo, bool norm, int epi, int seq) {
