@@ -15,6 +15,7 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 #define CK(x)                                                                 \
@@ -44,35 +45,71 @@ __global__ void k_stream(const float4* __restrict__ in, float* __restrict__ sink
   if (acc == 123.456f) sink[blockIdx.x] = acc;
 }
 
-static int make_queue_stream(hipStream_t* s) {   // a stream with a hardware queue of its own (a CU mask of all CUs)
+// (second experiment) the product's shapes.  An attention-like launch: 1536 workgroups x 3 waves, each streaming 256 KB
+// (one (batch, head) at 512 cached f32 keys) -- 18 of a CU's 32 wave slots, as dec_attn_kernel<float> leaves it;
+// a GEMM-like chain kernel: 104 workgroups x 256 threads, each pulling 64 KB of "weights" that rotate through a 96 MB
+// buffer (never L2-resident, as the f32 decode weights between two uses) before it writes its 4 KB tile
+__global__ __launch_bounds__(192) void k_attn_like(const float4* __restrict__ in, float* __restrict__ sink) {
+  const f32x4_t* src = reinterpret_cast<const f32x4_t*>(in) + static_cast<size_t>(blockIdx.x) * (256 * 1024 / 16);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < 256 * 1024 / 16; i += 192) {
+    const f32x4_t v = __builtin_nontemporal_load(src + i);
+    acc += v[0] + v[1] + v[2] + v[3];
+  }
+  if (acc == 123.456f) sink[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_gemm_like(const float4* __restrict__ w, float* __restrict__ out, int slice) {
+  const f32x4_t* src = reinterpret_cast<const f32x4_t*>(w) + (static_cast<size_t>(slice) * 104 + blockIdx.x) * (64 * 1024 / 16);
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int i = threadIdx.x; i < 64 * 1024 / 16; i += 256) acc += src[i];
+  out[blockIdx.x * 1024 + threadIdx.x * 4 + 0] += acc[0];
+  out[blockIdx.x * 1024 + threadIdx.x * 4 + 1] += acc[1];
+  out[blockIdx.x * 1024 + threadIdx.x * 4 + 2] += acc[2];
+  out[blockIdx.x * 1024 + threadIdx.x * 4 + 3] += acc[3];
+}
+
+// a stream with a hardware queue of its own: a CU mask of all CUs, or (third experiment) of CUs [lo, hi) in eighths
+static int make_queue_stream(hipStream_t* s, int lo8 = 0, int hi8 = 8) {
   int n_cu = 0;
   CK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0));
   std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
-  for (int i = 0; i < n_cu; ++i) mask[i >> 5] |= 1u << (i & 31);
+  for (int i = n_cu * lo8 / 8; i < n_cu * hi8 / 8; ++i) mask[i >> 5] |= 1u << (i & 31);
   CK(hipExtStreamCreateWithCUMask(s, static_cast<uint32_t>(mask.size()), mask.data()));
   return 0;
 }
 
-static int capture_chain(hipStream_t s, float* p, int n, hipGraphExec_t* out) {
+static int capture_chain(hipStream_t s, float* p, int n, hipGraphExec_t* out, const float4* weights = nullptr) {
   hipGraph_t g;
   CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-  for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_small, dim3(64), dim3(256), 0, s, p);
+  for (int i = 0; i < n; ++i) {
+    if (weights) hipLaunchKernelGGL(k_gemm_like, dim3(104), dim3(256), 0, s, weights, p, i % 14);   // 14 x 104 x 64 KB = 93 MB
+    else hipLaunchKernelGGL(k_small, dim3(64), dim3(256), 0, s, p);
+  }
   CK(hipStreamEndCapture(s, &g));
   CK(hipGraphInstantiate(out, g, nullptr, nullptr, 0));
   return 0;
 }
 
-int main() {
-  constexpr int kChain = 49, kReps = 400, kLoads = 3;
+int main(int argc, char** argv) {
+  constexpr int kChain = 49, kReps = 200, kLoads = 3;
   constexpr size_t kBig = 1ull << 30;
+  // gap_under_load [load_eighths [probe_on_the_rest]]: the loaded streams on the first load_eighths / 8 of the CUs (mask
+  // bits), the probe chain on all CUs or only on the remaining ones; then only the attention-like experiments run
+  const int load8 = argc > 1 ? atoi(argv[1]) : 8;
+  const bool probe_rest = argc > 2 && atoi(argv[2]) != 0;
   hipStream_t probe, load[kLoads];
-  if (make_queue_stream(&probe)) return 1;
+  if (make_queue_stream(&probe, probe_rest ? load8 : 0, 8)) return 1;
   for (int i = 0; i < kLoads; ++i)
-    if (make_queue_stream(&load[i])) return 1;
+    if (make_queue_stream(&load[i], 0, load8)) return 1;
+  if (load8 != 8) printf("loaded streams on %d/8 of the CUs, probe chain on %s\n", load8, probe_rest ? "the other CUs" : "all CUs");
   float *p_probe, *p_load[kLoads], *sink;
   float4* big[kLoads];
-  CK(hipMalloc(&p_probe, 64 * 256 * 4));
-  CK(hipMemset(p_probe, 0, 64 * 256 * 4));
+  CK(hipMalloc(&p_probe, 104 * 1024 * 4));
+  CK(hipMemset(p_probe, 0, 104 * 1024 * 4));
+  float4* weights;
+  CK(hipMalloc(&weights, 14ull * 104 * 64 * 1024));
+  CK(hipMemset(weights, 0, 14ull * 104 * 64 * 1024));
   CK(hipMalloc(&sink, 4096 * 4));
   for (int i = 0; i < kLoads; ++i) {
     CK(hipMalloc(&p_load[i], 64 * 256 * 4));
@@ -80,15 +117,18 @@ int main() {
     CK(hipMalloc(&big[i], kBig));
     CK(hipMemset(big[i], 0, kBig));
   }
-  hipGraphExec_t chain, load_chain[kLoads];
+  hipGraphExec_t chain, gemm_chain, load_chain[kLoads];
   if (capture_chain(probe, p_probe, kChain, &chain)) return 1;
+  if (capture_chain(probe, p_probe, kChain, &gemm_chain, weights)) return 1;
   for (int i = 0; i < kLoads; ++i)
     if (capture_chain(load[i], p_load[i], kChain, &load_chain[i])) return 1;
   CK(hipDeviceSynchronize());
 
-  for (int kind = 0; kind < 2; ++kind) {
+  for (int kind = 0; kind < 4; ++kind) {
     for (int n_load = 0; n_load <= kLoads; ++n_load) {
-      if (kind == 1 && n_load == 0) continue;
+      if ((kind == 1 || kind == 2) && n_load == 0) continue;
+      if (load8 != 8 && kind < 2) continue;
+      hipGraphExec_t timed_chain = kind == 3 ? gemm_chain : chain;
       std::atomic<bool> stop{false};
       std::vector<std::thread> feeders;
       for (int i = 0; i < n_load; ++i)
@@ -99,21 +139,23 @@ int main() {
               // 1024 workgroups x 1 MiB each: one pass over the buffer, ~0.2 ms at HBM speed
               hipLaunchKernelGGL(k_stream, dim3(1024), dim3(256), 0, load[i], big[i], sink, kBig / 16 / 1024);
               hipLaunchKernelGGL(k_stream, dim3(1024), dim3(256), 0, load[i], big[i], sink, kBig / 16 / 1024);
-            } else {
+            } else if (kind == 1) {
               (void)hipGraphLaunch(load_chain[i], load[i]);
               (void)hipGraphLaunch(load_chain[i], load[i]);
+            } else {                             // four attention-like launches of 1536 x 256 KB = 403 MB each
+              for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(k_attn_like, dim3(1536), dim3(192), 0, load[i], big[i], sink);
             }
             (void)hipStreamSynchronize(load[i]);
           }
         });
       // warm up, then time kReps replays of the chain
-      for (int r = 0; r < 20; ++r) CK(hipGraphLaunch(chain, probe));
+      for (int r = 0; r < 20; ++r) CK(hipGraphLaunch(timed_chain, probe));
       CK(hipStreamSynchronize(probe));
       hipEvent_t a, b;
       CK(hipEventCreate(&a));
       CK(hipEventCreate(&b));
       CK(hipEventRecord(a, probe));
-      for (int r = 0; r < kReps; ++r) CK(hipGraphLaunch(chain, probe));
+      for (int r = 0; r < kReps; ++r) CK(hipGraphLaunch(timed_chain, probe));
       CK(hipEventRecord(b, probe));
       CK(hipEventSynchronize(b));
       float ms = 0.f;
@@ -121,9 +163,12 @@ int main() {
       stop.store(true);
       for (auto& t : feeders) t.join();
       CK(hipDeviceSynchronize());
-      printf("%d other stream(s) %s: %.2f us per dependent launch of the probe chain\n", n_load,
-             kind == 0 ? "streaming 1 GiB buffers (HBM busy, queues quiet)" : "replaying their own chains (queues busy, HBM idle)",
-             ms * 1e3f / (kReps * kChain));
+      static const char* kKinds[4] = {"streaming 1 GiB buffers with every wave slot (HBM busy, queues quiet)",
+                                      "replaying their own chains (queues busy, HBM idle)",
+                                      "running attention-like launches (1536 x 3 waves x 256 KB)",
+                                      "running attention-like launches (1536 x 3 waves x 256 KB)"};
+      printf("%d other stream(s) %s: %.2f us per dependent launch of the %s chain\n", n_load, kKinds[kind],
+             ms * 1e3f / (kReps * kChain), kind == 3 ? "GEMM-like (104 workgroups x 64 KB of cold weights)" : "small-kernel");
       (void)hipEventDestroy(a);
       (void)hipEventDestroy(b);
     }
