@@ -1,0 +1,126 @@
+// Microbenchmark, round 5's first experiment in miniature (DESIGN.md section 7 a iii): four "row groups", each alternating an
+// attention-like launch (384 workgroups x 3 waves x 512 KB: a quarter-batch dec_attn_kernel<float> launch late in a decode) with three
+// dependent GEMM-like launches (104 workgroups x 64 KB of cold weights) -- eight such layers per step.
+//   A  one stream per group, every kernel on all CUs                              (the product's schedule today)
+//   B  two streams per group -- attention on the first 6/8 of the CUs, dense launches on the other 2/8 -- chained by
+//      events; a group's two queues are never busy at the same time, so at most four queues are (five busy queues are
+//      2.2x slower than four: profiles/r4_ab_five_six_row_groups.txt)
+//   C  as B with both streams on all CUs                                          (what the event hand-offs cost)
+// Prints microseconds per group step for each.   hipcc --offload-arch=gfx950 -O3 cu_split_groups.hip -o cu_split_groups -lpthread
+#include <hip/hip_ext.h>
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <thread>
+#include <vector>
+#define CK(x)                                                            \
+  do {                                                                   \
+    hipError_t e_ = (x);                                                 \
+    if (e_ != hipSuccess) {                                              \
+      printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); \
+      return 1;                                                          \
+    }                                                                    \
+  } while (0)
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(192) void k_attn_like(const f32x4_t* __restrict__ in, float* __restrict__ sink) {
+  const f32x4_t* src = in + static_cast<size_t>(blockIdx.x) * (512 * 1024 / 16);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < 512 * 1024 / 16; i += 192) {
+    const f32x4_t v = __builtin_nontemporal_load(src + i);
+    acc += v[0] + v[1] + v[2] + v[3];
+  }
+  if (acc == 123.456f) sink[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_gemm_like(const f32x4_t* __restrict__ w, float* __restrict__ out, int slice) {
+  const f32x4_t* src = w + (static_cast<size_t>(slice) * 104 + blockIdx.x) * (64 * 1024 / 16);
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int i = threadIdx.x; i < 64 * 1024 / 16; i += 256) acc += src[i];
+  float* o = out + blockIdx.x * 1024 + threadIdx.x * 4;
+  o[0] += acc[0], o[1] += acc[1], o[2] += acc[2], o[3] += acc[3];
+}
+
+static int make_stream(hipStream_t* s, int lo8, int hi8) {
+  int n_cu = 0;
+  CK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0));
+  std::vector<uint32_t> mask((n_cu + 31) / 32, 0u);
+  for (int i = n_cu * lo8 / 8; i < n_cu * hi8 / 8; ++i) mask[i >> 5] |= 1u << (i & 31);
+  CK(hipExtStreamCreateWithCUMask(s, static_cast<uint32_t>(mask.size()), mask.data()));
+  return 0;
+}
+
+int main() {
+  constexpr int G = 4, kSteps = 100, kLayers = 8, kDense = 3;
+  f32x4_t *kv[G], *weights;
+  float *out[G], *sink;
+  CK(hipMalloc(&weights, 14ull * 104 * 64 * 1024));
+  CK(hipMemset(weights, 0, 14ull * 104 * 64 * 1024));
+  CK(hipMalloc(&sink, 4096 * 4));
+  for (int g = 0; g < G; ++g) {
+    CK(hipMalloc(&kv[g], 8ull * 384 * 512 * 1024));          // eight layers' worth of "cache": 1.6 GB per group
+    CK(hipMemset(kv[g], 0, 8ull * 384 * 512 * 1024));
+    CK(hipMalloc(&out[g], 104 * 1024 * 4));
+    CK(hipMemset(out[g], 0, 104 * 1024 * 4));
+  }
+  const char* names[3] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
+                          "C two streams per group, both on all CUs"};
+  for (int variant = 0; variant < 3; ++variant) {
+    hipStream_t sa[G], sd[G];
+    hipEvent_t e1[G], e2[G];
+    // creation order: the four attention streams first, then the four dense streams
+    for (int g = 0; g < G; ++g)
+      if (make_stream(&sa[g], 0, variant == 1 ? 6 : 8)) return 1;
+    for (int g = 0; g < G; ++g) {
+      if (variant == 0) sd[g] = sa[g];
+      else if (make_stream(&sd[g], variant == 1 ? 6 : 0, 8)) return 1;
+      CK(hipEventCreateWithFlags(&e1[g], hipEventDisableTiming));
+      CK(hipEventCreateWithFlags(&e2[g], hipEventDisableTiming));
+    }
+    auto run = [&](int g, int steps) {
+      (void)hipSetDevice(0);
+      int slice = g * 3;
+      for (int t = 0; t < steps; ++t)
+        for (int l = 0; l < kLayers; ++l) {
+          hipLaunchKernelGGL(k_attn_like, dim3(384), dim3(192), 0, sa[g], kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16), sink);
+          if (variant != 0) {
+            (void)hipEventRecord(e1[g], sa[g]);
+            (void)hipStreamWaitEvent(sd[g], e1[g], 0);
+          }
+          for (int d = 0; d < kDense; ++d) {
+            hipLaunchKernelGGL(k_gemm_like, dim3(104), dim3(256), 0, sd[g], weights, out[g], slice % 14);
+            ++slice;
+          }
+          if (variant != 0) {
+            (void)hipEventRecord(e2[g], sd[g]);
+            (void)hipStreamWaitEvent(sa[g], e2[g], 0);
+          }
+        }
+      (void)hipStreamSynchronize(sa[g]);
+      (void)hipStreamSynchronize(sd[g]);
+    };
+    {   // warm-up
+      std::vector<std::thread> th;
+      for (int g = 0; g < G; ++g) th.emplace_back(run, g, 10);
+      for (auto& t : th) t.join();
+    }
+    CK(hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g) th.emplace_back(run, g, kSteps);
+    for (auto& t : th) t.join();
+    CK(hipDeviceSynchronize());
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    printf("%s: %.1f us per group step (%d layers of 1 attention-like + %d GEMM-like launches; four groups at once)\n",
+           names[variant], us / kSteps, kLayers, kDense);
+    for (int g = 0; g < G; ++g) {
+      (void)hipStreamDestroy(sa[g]);
+      if (variant != 0) (void)hipStreamDestroy(sd[g]);
+      (void)hipEventDestroy(e1[g]);
+      (void)hipEventDestroy(e2[g]);
+    }
+  }
+  return 0;
+}

@@ -98,11 +98,14 @@ int main(int argc, char** argv) {
   // bits), the probe chain on all CUs or only on the remaining ones; then only the attention-like experiments run
   const int load8 = argc > 1 ? atoi(argv[1]) : 8;
   const bool probe_rest = argc > 2 && atoi(argv[2]) != 0;
+  const int attn_wgs = argc > 3 ? atoi(argv[3]) : 1536;      // 384 = a row group's quarter-batch launch
   hipStream_t probe, load[kLoads];
   if (make_queue_stream(&probe, probe_rest ? load8 : 0, 8)) return 1;
   for (int i = 0; i < kLoads; ++i)
     if (make_queue_stream(&load[i], 0, load8)) return 1;
-  if (load8 != 8) printf("loaded streams on %d/8 of the CUs, probe chain on %s\n", load8, probe_rest ? "the other CUs" : "all CUs");
+  if (load8 != 8 || attn_wgs != 1536)
+    printf("loaded streams on %d/8 of the CUs, probe chain on %s, attention-like launches of %d workgroups\n", load8,
+           probe_rest ? "the other CUs" : "all CUs", attn_wgs);
   float *p_probe, *p_load[kLoads], *sink;
   float4* big[kLoads];
   CK(hipMalloc(&p_probe, 104 * 1024 * 4));
@@ -127,7 +130,7 @@ int main(int argc, char** argv) {
   for (int kind = 0; kind < 4; ++kind) {
     for (int n_load = 0; n_load <= kLoads; ++n_load) {
       if ((kind == 1 || kind == 2) && n_load == 0) continue;
-      if (load8 != 8 && kind < 2) continue;
+      if ((load8 != 8 || attn_wgs != 1536) && kind < 2) continue;
       hipGraphExec_t timed_chain = kind == 3 ? gemm_chain : chain;
       std::atomic<bool> stop{false};
       std::vector<std::thread> feeders;
@@ -143,7 +146,7 @@ int main(int argc, char** argv) {
               (void)hipGraphLaunch(load_chain[i], load[i]);
               (void)hipGraphLaunch(load_chain[i], load[i]);
             } else {                             // four attention-like launches of 1536 x 256 KB = 403 MB each
-              for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(k_attn_like, dim3(1536), dim3(192), 0, load[i], big[i], sink);
+              for (int k = 0; k < 4; ++k) hipLaunchKernelGGL(k_attn_like, dim3(attn_wgs), dim3(192), 0, load[i], big[i], sink);
             }
             (void)hipStreamSynchronize(load[i]);
           }
@@ -163,10 +166,10 @@ int main(int argc, char** argv) {
       stop.store(true);
       for (auto& t : feeders) t.join();
       CK(hipDeviceSynchronize());
-      static const char* kKinds[4] = {"streaming 1 GiB buffers with every wave slot (HBM busy, queues quiet)",
-                                      "replaying their own chains (queues busy, HBM idle)",
-                                      "running attention-like launches (1536 x 3 waves x 256 KB)",
-                                      "running attention-like launches (1536 x 3 waves x 256 KB)"};
+      char attn_label[96];
+      snprintf(attn_label, sizeof attn_label, "running attention-like launches (%d x 3 waves x 256 KB)", attn_wgs);
+      const char* kKinds[4] = {"streaming 1 GiB buffers with every wave slot (HBM busy, queues quiet)",
+                               "replaying their own chains (queues busy, HBM idle)", attn_label, attn_label};
       printf("%d other stream(s) %s: %.2f us per dependent launch of the %s chain\n", n_load, kKinds[kind],
              ms * 1e3f / (kReps * kChain), kind == 3 ? "GEMM-like (104 workgroups x 64 KB of cold weights)" : "small-kernel");
       (void)hipEventDestroy(a);
