@@ -1,4 +1,4 @@
-// Microbenchmark, round 5's first experiment in miniature (DESIGN.md section 7 a iii): four "row groups", each alternating an
+// Microbenchmark, the CU-split schedules of DESIGN.md section 7 a iii in miniature (measured: all slower than A): four "row groups", each alternating an
 // attention-like launch (384 workgroups x 3 waves x 512 KB: a quarter-batch dec_attn_kernel<float> launch late in a decode) with three
 // dependent GEMM-like launches (104 workgroups x 64 KB of cold weights) -- eight such layers per step.
 //   A  one stream per group, every kernel on all CUs                              (the product's schedule today)
@@ -6,6 +6,9 @@
 //      events; a group's two queues are never busy at the same time, so at most four queues are (five busy queues are
 //      2.2x slower than four: profiles/r4_ab_five_six_row_groups.txt)
 //   C  as B with both streams on all CUs                                          (what the event hand-offs cost)
+//   D  one stream per group again, the split done INSIDE the kernels: both kinds claim their work items from a counter,
+//      attention-like workgroups leave at once when HW_ID says they sit on one of the two last CUs of a shader engine,
+//      GEMM-like workgroups when they do not (profiles/r4_cu_mask_map.txt: that is the 6/8 - 2/8 split of B)
 // Prints microseconds per group step for each.   hipcc --offload-arch=gfx950 -O3 cu_split_groups.hip -o cu_split_groups -lpthread
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
@@ -43,6 +46,47 @@ __global__ __launch_bounds__(256) void k_gemm_like(const f32x4_t* __restrict__ w
   o[0] += acc[0], o[1] += acc[1], o[2] += acc[2], o[3] += acc[3];
 }
 
+// this wave's CU is one of the two reserved for the dense launches (hardware CU ids run 0..7 or, with CU 0 harvested, 1..8)
+__device__ __forceinline__ bool on_reserved_cu() {
+  const unsigned hw = __builtin_amdgcn_s_getreg(4 | (31 << 11));      // HW_REG_HW_ID
+  return (((hw >> 8) & 0xF) & 7u) >= 6u;
+}
+__global__ __launch_bounds__(192) void k_attn_claim(const f32x4_t* __restrict__ in, float* __restrict__ sink, int* counter, int items) {
+  if (on_reserved_cu()) return;
+  __shared__ int item;
+  for (;;) {
+    if (threadIdx.x == 0) item = atomicAdd(counter, 1);
+    __syncthreads();
+    const int it = item;
+    __syncthreads();
+    if (it >= items) return;
+    const f32x4_t* src = in + static_cast<size_t>(it) * (512 * 1024 / 16);
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < 512 * 1024 / 16; i += 192) {
+      const f32x4_t v = __builtin_nontemporal_load(src + i);
+      acc += v[0] + v[1] + v[2] + v[3];
+    }
+    if (acc == 123.456f) sink[it] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void k_gemm_claim(const f32x4_t* __restrict__ w, float* __restrict__ out, int slice, int* counter, int items) {
+  if (!on_reserved_cu()) return;
+  __shared__ int item;
+  for (;;) {
+    if (threadIdx.x == 0) item = atomicAdd(counter, 1);
+    __syncthreads();
+    const int it = item;
+    __syncthreads();
+    if (it >= items) return;
+    const f32x4_t* src = w + (static_cast<size_t>(slice) * 104 + it) * (64 * 1024 / 16);
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int i = threadIdx.x; i < 64 * 1024 / 16; i += 256) acc += src[i];
+    float* o = out + it * 1024 + threadIdx.x * 4;
+    o[0] += acc[0], o[1] += acc[1], o[2] += acc[2], o[3] += acc[3];
+  }
+}
+
 static int make_stream(hipStream_t* s, int lo8, int hi8) {
   int n_cu = 0;
   CK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, 0));
@@ -65,25 +109,42 @@ int main() {
     CK(hipMalloc(&out[g], 104 * 1024 * 4));
     CK(hipMemset(out[g], 0, 104 * 1024 * 4));
   }
-  const char* names[3] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
-                          "C two streams per group, both on all CUs"};
-  for (int variant = 0; variant < 3; ++variant) {
+  const char* names[4] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
+                          "C two streams per group, both on all CUs",
+                          "D one stream per group, work-claiming kernels that keep to 6/8 (attention) and 2/8 (dense) of the CUs"};
+  // one claim counter per launch of variant D
+  constexpr int kLaunches = (kSteps + 10) * kLayers * (1 + kDense);
+  int* counters[G];
+  for (int g = 0; g < G; ++g) CK(hipMalloc(&counters[g], kLaunches * 4));
+  for (int variant = 0; variant < 4; ++variant) {
+    for (int g = 0; g < G; ++g) CK(hipMemset(counters[g], 0, kLaunches * 4));
     hipStream_t sa[G], sd[G];
     hipEvent_t e1[G], e2[G];
     // creation order: the four attention streams first, then the four dense streams
     for (int g = 0; g < G; ++g)
       if (make_stream(&sa[g], 0, variant == 1 ? 6 : 8)) return 1;
     for (int g = 0; g < G; ++g) {
-      if (variant == 0) sd[g] = sa[g];
+      if (variant == 0 || variant == 3) sd[g] = sa[g];
       else if (make_stream(&sd[g], variant == 1 ? 6 : 0, 8)) return 1;
       CK(hipEventCreateWithFlags(&e1[g], hipEventDisableTiming));
       CK(hipEventCreateWithFlags(&e2[g], hipEventDisableTiming));
     }
-    auto run = [&](int g, int steps) {
+    auto run = [&](int g, int steps, int c0) {
       (void)hipSetDevice(0);
       int slice = g * 3;
+      int* ctr = counters[g] + c0;
       for (int t = 0; t < steps; ++t)
         for (int l = 0; l < kLayers; ++l) {
+          if (variant == 3) {
+            // 512 workgroups: about three quarters of them land on allowed CUs and claim the 384 items
+            hipLaunchKernelGGL(k_attn_claim, dim3(512), dim3(192), 0, sa[g], kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16), sink, ctr++, 384);
+            for (int d = 0; d < kDense; ++d) {
+              // 1024 workgroups: the quarter that lands on reserved CUs claims the 104 tiles
+              hipLaunchKernelGGL(k_gemm_claim, dim3(1024), dim3(256), 0, sa[g], weights, out[g], slice % 14, ctr++, 104);
+              ++slice;
+            }
+            continue;
+          }
           hipLaunchKernelGGL(k_attn_like, dim3(384), dim3(192), 0, sa[g], kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16), sink);
           if (variant != 0) {
             (void)hipEventRecord(e1[g], sa[g]);
@@ -103,13 +164,13 @@ int main() {
     };
     {   // warm-up
       std::vector<std::thread> th;
-      for (int g = 0; g < G; ++g) th.emplace_back(run, g, 10);
+      for (int g = 0; g < G; ++g) th.emplace_back(run, g, 10, 0);
       for (auto& t : th) t.join();
     }
     CK(hipDeviceSynchronize());
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> th;
-    for (int g = 0; g < G; ++g) th.emplace_back(run, g, kSteps);
+    for (int g = 0; g < G; ++g) th.emplace_back(run, g, kSteps, 10 * kLayers * (1 + kDense));
     for (auto& t : th) t.join();
     CK(hipDeviceSynchronize());
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
@@ -117,7 +178,7 @@ int main() {
            names[variant], us / kSteps, kLayers, kDense);
     for (int g = 0; g < G; ++g) {
       (void)hipStreamDestroy(sa[g]);
-      if (variant != 0) (void)hipStreamDestroy(sd[g]);
+      if (variant == 1 || variant == 2) (void)hipStreamDestroy(sd[g]);
       (void)hipEventDestroy(e1[g]);
       (void)hipEventDestroy(e2[g]);
     }
