@@ -224,6 +224,38 @@ int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t f
  * finalisation before it) and reports errors of the decode loop.  MT3_ERR_INVALID when no decode is in flight. */
 int mt3_engine_decode_wait(mt3_engine* e, int32_t* h_steps_run);
 
+/* Streaming transcription with IN-FLIGHT BATCHING: encode + decode of n_segments independent segments (any number;
+ * the reference's loop over `.batch(8)` calls of predict_batch_with_aux, NB:295-301, mt3/models.py:121-152) through the
+ * engine's max_batch decode SLOTS.  The reference's decode is batch-synchronous -- a batch ends when its LAST row has
+ * terminated (t5x decoding.beam_search's while_loop) -- so a finished row idles until then; here a finished slot hands
+ * its id row to the caller and restarts at position 0 on the next segment: every slot carries its own position counter
+ * (as the reference's cache index does per call, mt3/layers.py:246-314), self-attention cache rows past a slot's
+ * position are discarded by position, and the segment's cross-attention K/V arrive from an encoder pass that ran ahead
+ * on the caller's stream (chunks of up to 64 segments into a staging ring; the first min(n_segments, max_batch)
+ * segments are encoded straight into the caches).  Row count per row group is constant, so ONE captured step graph per
+ * group serves the whole job; when the queue of segments is empty the remaining rows are retired and compacted as
+ * under MT3_DECODE_EARLY_EXIT.
+ * d_inputs  [n_segments, T, input_depth] f32 (log-mel);  d_ids [n_segments, L] int32: row i = the ids of segment i,
+ * bit-identical to what mt3_engine_encode + mt3_engine_decode(MT3_DECODE_EARLY_EXIT) return for that segment (ids after
+ * a row's EOS are 0; a row without EOS has num_steps ids).  flags: MT3_DECODE_BEAM1, MT3_DECODE_NO_GRAPH,
+ * MT3_DECODE_SINGLE_STREAM (one row group); anything else is rejected.  The call BLOCKS until every segment is done
+ * (the calling thread drives the encoder passes, the engine's workers the row groups); d_inputs / d_ids must stay
+ * valid until it returns.  h_stats (may be NULL) reports what ran. */
+typedef struct mt3_transcribe_stats {
+  int32_t slots;           /* decode slots in use = min(n_segments, max_batch)                                   */
+  int32_t groups;          /* row groups                                                                         */
+  int32_t steps_run;       /* decode steps of the group that ran longest                                         */
+  int32_t polls;           /* refill polls (all groups)                                                          */
+  int32_t refills;         /* slots restarted on a new segment (= n_segments - slots)                            */
+  int32_t starved_polls;   /* polls at which finished slots found no encoded segment waiting (queue not empty)   */
+  int32_t encoder_chunks;  /* encoder passes after the first                                                     */
+  int32_t compactions;     /* live-row compactions once the queue was empty                                      */
+  int32_t used_graph;      /* 1: every group replayed a captured step graph                                      */
+  int32_t reserved[7];
+} mt3_transcribe_stats;
+int mt3_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
+                          int32_t* d_ids, mt3_transcribe_stats* h_stats, void* stream);
+
 /* Teacher-forced cached decode: Transformer.decode (mt3/network.py:303-361) on GIVEN decoder inputs, driven one
  * token per call through the same cached step (layers.py:246-314) the autoregressive loop uses -- the input of
  * step 0 is BOS, the input of step t+1 is d_forced_ids[b][t] (i.e. decoder_input_tokens = shift_right(forced),

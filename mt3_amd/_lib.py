@@ -48,6 +48,11 @@ class EngineConfig(C.Structure):
         "decode_chains", "kv_cache_dtype", "dense_dtype", "options")]
 
 
+class TranscribeStats(C.Structure):            # mt3_transcribe_stats
+    _fields_ = [(n, C.c_int32) for n in ("slots", "groups", "steps_run", "polls", "refills", "starved_polls",
+                                         "encoder_chunks", "compactions", "used_graph")] + [("reserved", C.c_int32 * 7)]
+
+
 class EventRange(C.Structure):
     _fields_ = [("type", C.c_int32), ("min_value", C.c_int32), ("max_value", C.c_int32)]
 
@@ -80,6 +85,7 @@ SIGNATURES = {
     "mt3_engine_encode": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
     "mt3_engine_decode": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.POINTER(C.c_int32), _P]),
     "mt3_engine_decode_wait": (C.c_int, [_P, C.POINTER(C.c_int32)]),
+    "mt3_engine_transcribe": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(TranscribeStats), _P]),
     "mt3_engine_decode_forced": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "mt3_engine_status": (C.c_int, [_P, C.c_int32]),
     "mt3_debug_engine_decode": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(float* __restrict__ lo
   if (tid == 0) {
     was_done = done[b];
     t = step[b];
-    if (rt.eos_at) eos_len = rt.eos_at[out_row];
+    if (rt.eos_at) eos_len = rt.eos_at[rt.slot_seg ? rt.slot_seg[b] : out_row];
     if (BEAM1) {
       live = beam_f[b];
       best = beam_f[beam_rows + b];
@@ -260,13 +260,11 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(float* __restrict__ lo
       if (BEAM1) t2.insert(s_v[4 + w], s_i[4 + w]);
     }
     int tok;
+    bool finished = false;                // this step finishes the slot
     if (!BEAM1) {
       if (forced) was_done = 0;           // teacher forcing: every step reports its own arg-max, no EOS bookkeeping
       tok = was_done ? 0 : (t + 1 >= eos_len ? 1 : t2.i1);      // synthetic EOS schedule: a point mass on EOS
-      if (!was_done && tok == 1 && !forced) {        // EOS
-        done[b] = 1;
-        atomicAdd(n_done, 1);
-      }
+      finished = !was_done && tok == 1 && !forced;   // EOS
     } else {
       tok = 0;
       if (!was_done) {
@@ -295,11 +293,14 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(float* __restrict__ lo
         beam_f[beam_rows + b] = best;
         beam_len[b] = blen;
         beam_len_row[out_row] = blen;
-        if (blen >= 0 && best > live / bp_max) {
-          done[b] = 1;
-          atomicAdd(n_done, 1);
-        }
+        finished = blen >= 0 && best > live / bp_max;
       }
+    }
+    // in-flight batching: a slot that has written max_len ids is finished as well (the row ran out of positions)
+    if (!was_done && rt.max_len > 0 && t + 1 >= rt.max_len) finished = true;
+    if (finished) {
+      done[b] = 1;
+      atomicAdd(n_done, 1);
     }
     ids[static_cast<size_t>(out_row) * ids_stride + t] = tok;
     // teacher forcing (Transformer.decode on given decoder_input_tokens, network.py:303-361): the NEXT input is
@@ -331,7 +332,7 @@ int launch_argmax_step(float* logits, int vocab, int* ids, int ids_stride, int* 
                        const StepRetire& rt, hipStream_t s) {
   if (beam && forced) return mt3::fail(MT3_ERR_INVALID, "argmax_step: teacher forcing is a greedy-path feature");
   if (beam && !beam->len_row) return mt3::fail(MT3_ERR_INVALID, "argmax_step: the beam state needs its row-indexed lengths");
-  if (forced && (rt.retire || rt.slot_row || rt.eos_at))
+  if (forced && (rt.retire || rt.slot_row || rt.eos_at || rt.slot_seg || rt.max_len))
     return mt3::fail(MT3_ERR_INVALID, "argmax_step: teacher forcing keeps every row live and in place");
   if (ls.ss && (ls.n_ss <= 0 || ls.n_ss > 64 || ls.dim <= 0))
     return mt3::fail(MT3_ERR_INVALID, "argmax_step: the row scale needs 1 .. 64 partial sums");
@@ -374,7 +375,10 @@ __global__ __launch_bounds__(128) void compact_move_kernel(CompactArgs c) {
   const int i = blockIdx.x, tid = threadIdx.x;
   const int n_live = c.perm[c.rows];
   if (i >= n_live) {
-    if (!GATHER && tid == 0) c.done[i] = 1;
+    if (!GATHER && tid == 0) {
+      c.done[i] = 1;
+      if (c.slot_seg) c.slot_seg[i] = -1;
+    }
     return;
   }
   const size_t src = GATHER ? static_cast<size_t>(c.perm[i]) : static_cast<size_t>(i), dst = i;
@@ -397,6 +401,7 @@ __global__ __launch_bounds__(128) void compact_move_kernel(CompactArgs c) {
       c.s_int[4 * dst + 1] = c.step[src];
       c.s_int[4 * dst + 2] = c.cur_tok[src];
       c.s_int[4 * dst + 3] = c.beam_len ? c.beam_len[src] : 0;
+      if (c.slot_seg) c.s_seg[dst] = c.slot_seg[src];
       if (c.beam_f) {
         c.s_beam[2 * dst + 0] = c.beam_f[src];
         c.s_beam[2 * dst + 1] = c.beam_f[c.beam_rows + src];
@@ -406,6 +411,7 @@ __global__ __launch_bounds__(128) void compact_move_kernel(CompactArgs c) {
       c.step[dst] = c.s_int[4 * dst + 1];
       c.cur_tok[dst] = c.s_int[4 * dst + 2];
       if (c.beam_len) c.beam_len[dst] = c.s_int[4 * dst + 3];
+      if (c.slot_seg) c.slot_seg[dst] = c.s_seg[dst];
       if (c.beam_f) {
         c.beam_f[dst] = c.s_beam[2 * dst + 0];
         c.beam_f[c.beam_rows + dst] = c.s_beam[2 * dst + 1];
@@ -418,11 +424,124 @@ __global__ __launch_bounds__(128) void compact_move_kernel(CompactArgs c) {
 int launch_compact(const CompactArgs& c, hipStream_t s) {
   if (!c.done || !c.slot_row || !c.step || !c.cur_tok || !c.y || !c.s_y || !c.s_int || !c.perm || c.rows <= 0 ||
       c.emb % 16 || c.q_n % 4 || (c.y_ct && !c.s_y_ct) || (c.y_ss && !c.s_y_ss) || (c.qkvf && !c.s_qkvf) ||
-      (c.beam_f && (!c.s_beam || !c.beam_len)))
+      (c.beam_f && (!c.s_beam || !c.beam_len)) || (c.slot_seg && !c.s_seg))
     return mt3::fail(MT3_ERR_INVALID, "compact: bad arguments");
   hipLaunchKernelGGL(compact_plan_kernel, dim3(1), dim3(64), 0, s, c.done, c.perm, c.rows);
   hipLaunchKernelGGL(compact_move_kernel<true>, dim3(c.rows), dim3(128), 0, s, c);
   hipLaunchKernelGGL(compact_move_kernel<false>, dim3(c.rows), dim3(128), 0, s, c);
+  MT3_HIP_CHECK(hipGetLastError());
+  return MT3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- slot refill
+// In-flight batching (RefillArgs, kernels.h).  Three launches on the group's stream at a poll of the group's loop:
+//   plan   one wave: plan[i] = i-th FINISHED slot of the group (ascending), plan[rows] = how many; the group's counter of
+//          finished slots drops by the number that restart
+//   cross  block (i, layer x {K, V [, scales]}, part): cross-attention K/V of segment first_seg + i from the staging chunk
+//          into the cache rows of slot plan[i]  (16-byte pieces, 256 lanes, a row of H*T*64 elements in `parts` pieces)
+//   slot   block i: id row of slot plan[i] -> the caller's row of the segment it decoded (beam-1: the finished
+//          hypothesis, as beam1_finalize_kernel would leave it); i < n_new: restart on segment first_seg + i
+__global__ __launch_bounds__(64) void refill_plan_kernel(const int* __restrict__ done, int* __restrict__ plan,
+                                                          int* __restrict__ n_done, int rows, int n_new) {
+  const int lane = threadIdx.x;
+  int n = 0;
+  for (int base = 0; base < rows; base += 64) {
+    const int i = base + lane;
+    const bool fin = i < rows && done[i] != 0;
+    const unsigned long long m = __ballot(fin);
+    if (fin) plan[n + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    n += __popcll(m);
+  }
+  if (lane == 0) {
+    plan[rows] = n;
+    *n_done -= n_new < n ? n_new : n;
+  }
+}
+
+__global__ __launch_bounds__(256) void refill_cross_kernel(RefillArgs a, int parts) {
+  const int i = blockIdx.x;
+  const int n_fin = a.plan[a.rows];
+  if (i >= a.n_new || i >= n_fin) return;
+  const int row = a.slot_row[a.plan[i]];
+  const int l = blockIdx.y / 3, what = blockIdx.y % 3;          // 0: K rows, 1: V rows, 2: scale rows (e4m3 caches)
+  const char* src;
+  char* dst;
+  size_t bytes;
+  if (what < 2) {
+    bytes = a.row_bytes;
+    src = a.src[l] + (static_cast<size_t>(what) * a.src_batch + a.src_entry0 + i) * bytes;
+    dst = a.dst[l] + (static_cast<size_t>(what) * a.dst_batch + row) * bytes;
+  } else {
+    if (!a.src_sc[l]) return;
+    bytes = a.sc_bytes;
+    src = a.src_sc[l] + static_cast<size_t>(a.src_entry0 + i) * bytes;
+    dst = a.dst_sc[l] + static_cast<size_t>(row) * bytes;
+  }
+  const size_t n16 = bytes >> 4;                                   // rows are multiples of 16 bytes (64 elements per key)
+  const u32x4* s4 = reinterpret_cast<const u32x4*>(src);
+  u32x4* d4 = reinterpret_cast<u32x4*>(dst);
+  for (size_t k = static_cast<size_t>(blockIdx.z) * 256 + threadIdx.x; k < n16; k += static_cast<size_t>(parts) * 256)
+    d4[k] = __builtin_nontemporal_load(s4 + k);
+}
+
+__global__ __launch_bounds__(128) void refill_slot_kernel(RefillArgs a) {
+  const int i = blockIdx.x, tid = threadIdx.x;
+  if (i >= a.plan[a.rows]) return;
+  const int slot = a.plan[i];
+  const int row = a.slot_row[slot];
+  const int seg_old = a.slot_seg[slot];
+  int* idrow = a.ids + static_cast<size_t>(row) * a.ids_stride;
+  if (seg_old >= 0) {
+    // the finished hypothesis of the beam-1 search: live[:n] + EOS + padding (beam1_finalize_kernel); n < 0: the live one
+    const int n = a.beam_len ? a.beam_len_row[row] : -1;
+    int* out = a.out_ids + static_cast<size_t>(seg_old) * a.ids_stride;
+    for (int k = tid; k < a.ids_stride; k += 128) out[k] = (n >= 0 && k >= n) ? (k == n ? 1 : 0) : idrow[k];
+  }
+  const bool restart = i < a.n_new;
+  __syncthreads();                  // every lane has read the old occupant's beam length before lane 0 resets it
+  // (a thread zeroes exactly the ids it has just copied out)
+  if (restart)
+    for (int k = tid; k < a.ids_stride; k += 128) idrow[k] = 0;
+  if (tid == 0) {
+    a.slot_seg[slot] = restart ? a.first_seg + i : -1;
+    if (restart) {
+      a.step[slot] = 0;
+      a.cur_tok[slot] = 0;                                       // BOS
+      a.done[slot] = 0;
+      if (a.beam_f) {                                            // t5x beam_search: live log-prob 0, nothing finished
+        a.beam_f[slot] = 0.f;
+        a.beam_f[a.beam_rows + slot] = 0.f;
+        a.beam_len[slot] = -1;
+        a.beam_len_row[row] = -1;
+      }
+    }
+  }
+  if (!restart) return;
+  // decoder input of position 0: Embed(BOS) + FixedEmbed[0], in the forms the step reads (embed_kernel)
+  for (int k = tid * 4; k < a.emb; k += 512) {
+    const float4 e4 = *reinterpret_cast<const float4*>(a.table + k), p4 = *reinterpret_cast<const float4*>(a.pos + k);
+    put_row_piece(make_float4(e4.x + p4.x, e4.y + p4.y, e4.z + p4.z, e4.w + p4.w), a.y, a.y_ct, a.y_ss, slot, a.emb, k);
+  }
+  if (a.rp.q_out) put_row_projection(a.rp, slot, 0, 0, tid, 128);
+}
+
+int launch_refill(const RefillArgs& a, hipStream_t s) {
+  if (!a.done || !a.slot_row || !a.slot_seg || !a.step || !a.cur_tok || !a.n_done || !a.y || !a.table || !a.pos || !a.ids ||
+      !a.out_ids || !a.plan || a.rows <= 0 || a.n_new < 0 || a.n_new > a.rows || a.emb % 16 || a.ids_stride <= 0 ||
+      (a.beam_f && (!a.beam_len || !a.beam_len_row)) || (a.y_ct && !a.y_ss) ||
+      (a.rp.q_out && (!a.rp.ew || !a.rp.pw || a.rp.q_n % 4)))
+    return mt3::fail(MT3_ERR_INVALID, "refill: bad arguments");
+  if (a.n_new > 0 && (a.n_layers <= 0 || a.n_layers > kRefillMaxLayers || a.row_bytes % 16 || a.sc_bytes % 16 ||
+                      a.src_batch <= 0 || a.dst_batch <= 0 || a.src_entry0 < 0 || a.src_entry0 + a.n_new > a.src_batch))
+    return mt3::fail(MT3_ERR_INVALID, "refill: bad staging chunk");
+  hipLaunchKernelGGL(refill_plan_kernel, dim3(1), dim3(64), 0, s, a.done, a.plan, a.n_done, a.rows, a.n_new);
+  if (a.n_new > 0) {
+    // a K or V row of one layer is H*T*64 elements (98 KB ... 393 KB): 8 blocks of 256 lanes per row keep >= 1000
+    // workgroups in flight for a handful of segments
+    const int parts = 8;
+    hipLaunchKernelGGL(refill_cross_kernel, dim3(a.n_new, a.n_layers * 3, parts), dim3(256), 0, s, a, parts);
+  }
+  hipLaunchKernelGGL(refill_slot_kernel, dim3(a.rows), dim3(128), 0, s, a);
   MT3_HIP_CHECK(hipGetLastError());
   return MT3_OK;
 }

@@ -98,8 +98,12 @@ struct LayerDev {
 // Variant bits of one decode step (index of a captured step graph): 1 / 2 = mt3_debug_engine_decode's skipped kernels,
 // 4 = beam-1 token selection, 8 = teacher forcing, 16 = row retirement (finished slots cost nothing, the slot map is
 // in use), 32 = the synthetic EOS schedule (mt3_debug_engine_set_eos_schedule)
-constexpr int kVarBeam = 4, kVarForced = 8, kVarRetire = 16, kVarEos = 32, kNumVariants = 64;
+// 64 = in-flight batching (mt3_engine_transcribe: finished slots restart on new segments, the slot -> segment map is in use)
+constexpr int kVarBeam = 4, kVarForced = 8, kVarRetire = 16, kVarEos = 32, kVarStream = 64, kNumVariants = 128;
 constexpr int kMaxGroups = 4;
+// staging ring of mt3_engine_transcribe: cross-attention K/V of segments that wait for a slot, kStageChunks chunks of up
+// to kStageChunkCap segments each (one encoder pass per chunk)
+constexpr int kStageChunks = 8, kStageChunkCap = 64, kStageMinBatch = 8;
 
 // One persistent host thread per row group (created with the first decode that needs it, joined at destroy): a
 // decode call hands each group's loop to one of them instead of spawning threads per call, and with
@@ -114,7 +118,7 @@ struct Worker {
 
 // a captured decode step of rows [row0, row0 + rows) of a `batch`-row decode
 struct GroupGraph {
-  int variant, batch, row0, rows, slot;
+  int variant, batch, row0, rows, slot, max_len;
   hipGraph_t graph;
   hipGraphExec_t exec;
 };
@@ -217,8 +221,20 @@ struct mt3_engine {
   // whose caches / ids it works on.  Live slots are compacted to the front of their row group at the early-exit poll
   // (launch_compact), so attention grids and the GEMMs' M shrink with the live set while the caches stay in place.
   int* slot_row = nullptr;       // [max_batch]
-  int* eos_at = nullptr;         // [max_batch] synthetic EOS schedule (mt3_debug_engine_set_eos_schedule)
+  int* eos_at = nullptr;         // [eos_cap] synthetic EOS schedule (mt3_debug_engine_set_eos_schedule): per row, or -- in
+                                 // mt3_engine_transcribe -- per segment
+  int eos_cap = 0;
   bool eos_on = false;
+  // In-flight batching (mt3_engine_transcribe): slot_seg maps a slot to the SEGMENT it is decoding (-1: none); a
+  // finished slot hands its id row to the caller's output and restarts on the next encoded segment (launch_refill)
+  int* slot_seg = nullptr;       // [max_batch]
+  int* cs_seg = nullptr;         // compaction scratch
+  int* refill_plan = nullptr;    // [max_batch + kMaxChains]: rows + 1 entries per group
+  int stream_max_len = 0;        // steps per segment of the transcribe call in flight (a kernel argument of its step graphs)
+  int stage_cap = 0;             // segments per staging chunk (0: staging not allocated yet)
+  std::vector<void*> stage_kv;       // per decoder layer: [kStageChunks][2][stage_cap][H][T][64] cache elements
+  std::vector<float2*> stage_scale;  // e4m3 caches: [kStageChunks][stage_cap][H][T]
+  mt3_transcribe_stats last_stats{};
   float* cs_y = nullptr;         // compaction scratch: same shapes as y / y_ct / y_ss / qkvf, 4 ints + 2 floats per slot
   void* cs_y_ct = nullptr;
   float* cs_y_ss = nullptr;
@@ -660,8 +676,10 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     const mt3k::RowProj rp{e->ew0, e->pw0, qkvf, 4 * hd};
     // folded logits arrive unnormalised: the row scale comes from the final residual row's partial sums
     const mt3k::LogitScale ls{fold ? y_ss : nullptr, emb / 16, emb};
+    const bool streaming = (skip & kVarStream) != 0;
     const mt3k::StepRetire rt{retire ? 1 : 0, retire ? e->slot_row + row0 : nullptr,
-                              (skip & kVarEos) ? e->eos_at + crow0 : nullptr};
+                              (skip & kVarEos) ? e->eos_at + crow0 : nullptr, streaming ? e->slot_seg + row0 : nullptr,
+                              streaming ? e->stream_max_len : 0};
     return mt3k::launch_argmax_step(logits, c.vocab_size, e->ids + crow0 * Lmax, Lmax,
                                     e->cur_tok + row0, e->done + row0, e->n_done + done_slot, step, e->embedding, e->pos_table,
                                     kMaxPos, y_buf(0), split && !f32 ? yct_buf(0) : nullptr, y_ss, emb, rows,
@@ -1101,6 +1119,10 @@ int mt3_engine_finalize(mt3_engine* e) {
   // row retirement: slot map, synthetic EOS schedule, compaction scratch
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->slot_row), static_cast<size_t>(Bm) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->eos_at), static_cast<size_t>(Bm) * 4))) return rc;
+  e->eos_cap = Bm;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->slot_seg), static_cast<size_t>(Bm) * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->cs_seg), static_cast<size_t>(Bm) * 4))) return rc;
+  if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->refill_plan), (static_cast<size_t>(Bm) + kMaxChains) * 4))) return rc;
   if ((rc = dmalloc(e, reinterpret_cast<void**>(&e->cs_y), static_cast<size_t>(Bm) * emb * 4))) return rc;
   if (e->y_split && c.compute_dtype == MT3_BF16 && (rc = dmalloc(e, &e->cs_y_ct, static_cast<size_t>(Bm) * emb * 2))) return rc;
   if (e->y_split && (rc = dmalloc(e, reinterpret_cast<void**>(&e->cs_y_ss), static_cast<size_t>(Bm) * (emb / 16) * 4))) return rc;
@@ -1124,14 +1146,18 @@ int mt3_engine_finalize(mt3_engine* e) {
   return MT3_OK;
 }
 
-int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float* d_encoded_f32, void* stream) {
-  if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: engine not finalized");
-  if (!d_inputs || batch <= 0 || batch > e->cfg.max_batch)
-    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: batch out of range");
-  if (e->pending.active)
-    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: a decode is in flight (MT3_DECODE_ASYNC): call mt3_engine_decode_wait first");
+// Where an encoder pass leaves the cross-attention K/V of its batch: the engine's caches (rows 0 .. batch - 1: what
+// mt3_engine_encode does), or a staging chunk of mt3_engine_transcribe ([2][batch][H][T][64] per layer, scales [batch][H][T])
+struct CrossDst {
+  void* const* kv = nullptr;         // per decoder layer (nullptr: the caches)
+  float2* const* scale = nullptr;
+};
+
+static int encode_impl(mt3_engine* e, const float* d_inputs, int32_t batch, float* d_encoded_f32, const CrossDst& dst,
+                       hipStream_t s) {
   const mt3_engine_config& c = e->cfg;
-  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto ckv = [&](int l) -> void* { return dst.kv ? dst.kv[l] : e->dec[l].cross_kv; };
+  auto csc = [&](int l) -> float2* { return dst.scale ? dst.scale[l] : e->dec[l].cross_scale; };
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), T = c.input_length;
   const int M = batch * T;
   const bool small = M < 2048;
@@ -1159,8 +1185,7 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
     }
     MT3_TRY(mt3k::launch_rmsnorm(dt, e->x, e->enc_norm, e->enc_out, d_encoded_f32, M, emb, s));
     for (int l = 0; l < c.num_decoder_layers; ++l)
-      MT3_TRY(x6(e->enc_out, e->dec[l].wkv_x_p, e->dec[l].cross_kv, 2 * hd, emb, 2 * hd, false, MT3_EPI_HEADS, T));
-    e->cur_batch = batch;
+      MT3_TRY(x6(e->enc_out, e->dec[l].wkv_x_p, ckv(l), 2 * hd, emb, 2 * hd, false, MT3_EPI_HEADS, T));
     return MT3_OK;
   }
   {
@@ -1218,14 +1243,13 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
     MT3_TRY(mt3k::launch_mx8_quantize(e->enc_out, false, M, emb, e->enc_q, e->enc_sc, nullptr, s));
     for (int l = 0; l < c.num_decoder_layers; ++l) {
       mt3k::Mx8Args g = mx(e->enc_q, e->enc_sc, e->dec[l].wkv_x_q, e->dec[l].wkv_x_sc, 2 * hd, emb);
-      g.out = e->kv_fp8 ? e->cross_stage : e->dec[l].cross_kv;
+      g.out = e->kv_fp8 ? e->cross_stage : ckv(l);
       g.seq_len = T;
       MT3_TRY(mt3k::launch_gemm_mx8(g, MT3_EPI_HEADS, s));
       if (e->kv_fp8)
-        MT3_TRY(mt3k::launch_kv_quantize_fp8(e->cross_stage, e->dec[l].cross_kv, e->dec[l].cross_scale,
+        MT3_TRY(mt3k::launch_kv_quantize_fp8(e->cross_stage, ckv(l), csc(l),
                                              batch * c.num_heads * T, s));
     }
-    e->cur_batch = batch;
     return MT3_OK;
   }
   // the split residual form feeds the LDS-DMA tile (K <= 1024); the decode-sized tile a small batch selects holds the
@@ -1255,14 +1279,24 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
   }
   MT3_TRY(mt3k::launch_rmsnorm(dt, e->x, e->enc_norm, e->enc_out, d_encoded_f32, M, emb, s));
   for (int l = 0; l < c.num_decoder_layers; ++l) {
-    mt3k::GemmArgs g = gemm_args(e->enc_out, e->dec[l].wkv_x, e->kv_fp8 ? e->cross_stage : e->dec[l].cross_kv, M,
+    mt3k::GemmArgs g = gemm_args(e->enc_out, e->dec[l].wkv_x, e->kv_fp8 ? e->cross_stage : ckv(l), M,
                                  2 * hd, emb, 2 * hd);
     g.seq_len = T;
     MT3_TRY(mt3k::launch_gemm(dt, g, false, false, MT3_EPI_HEADS, small, s));
     if (e->kv_fp8)     // bf16 [2][B][H][T][64] -> e4m3 rows + one power-of-two scale per (row, head, position)
-      MT3_TRY(mt3k::launch_kv_quantize_fp8(e->cross_stage, e->dec[l].cross_kv, e->dec[l].cross_scale,
+      MT3_TRY(mt3k::launch_kv_quantize_fp8(e->cross_stage, ckv(l), csc(l),
                                            batch * c.num_heads * T, s));
   }
+  return MT3_OK;
+}
+
+int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float* d_encoded_f32, void* stream) {
+  if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: engine not finalized");
+  if (!d_inputs || batch <= 0 || batch > e->cfg.max_batch)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: batch out of range");
+  if (e->pending.active)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_encode: a decode is in flight (MT3_DECODE_ASYNC): call mt3_engine_decode_wait first");
+  MT3_TRY(encode_impl(e, d_inputs, batch, d_encoded_f32, CrossDst{}, static_cast<hipStream_t>(stream)));
   e->cur_batch = batch;
   return MT3_OK;
 }
@@ -1281,6 +1315,10 @@ static int row_groups_for(const mt3_engine_config& c, int batch) {
   if (batch >= (f32 ? 256 : 512)) return 4;
   return batch >= 128 ? 2 : 1;
 }
+
+// Row groups of mt3_engine_transcribe (in-flight batching keeps every group's rows full, so the rule of the canonical
+// full-length schedule applies, not the ragged one's)
+static int stream_row_groups_for(const mt3_engine_config& c, int slots) { return row_groups_for(c, slots); }
 
 // ---- persistent group workers
 static void worker_main(Worker* w, int dev) {
@@ -1359,8 +1397,11 @@ static void drop_group_graphs(mt3_engine* e) {
 // an engine-owned stream in thread-local mode -- several group threads may be here at once, the cache is guarded.
 static hipGraphExec_t group_graph(mt3_engine* e, int variant, int batch, int row0, int rows, int slot) {
   std::lock_guard<std::mutex> lk(e->graph_mu);
+  const int max_len = (variant & kVarStream) ? e->stream_max_len : 0;      // baked into the step's token kernel
   for (const GroupGraph& g : e->group_graphs)
-    if (g.variant == variant && g.batch == batch && g.row0 == row0 && g.rows == rows && g.slot == slot) return g.exec;
+    if (g.variant == variant && g.batch == batch && g.row0 == row0 && g.rows == rows && g.slot == slot &&
+        g.max_len == max_len)
+      return g.exec;
   if (!e->cap_stream[slot] && hipStreamCreateWithFlags(&e->cap_stream[slot], hipStreamNonBlocking) != hipSuccess) {
     (void)hipGetLastError();
     return nullptr;
@@ -1379,7 +1420,7 @@ static hipGraphExec_t group_graph(mt3_engine* e, int variant, int batch, int row
     (void)hipGetLastError();
     return nullptr;
   }
-  e->group_graphs.push_back(GroupGraph{variant, batch, row0, rows, slot, g, x});
+  e->group_graphs.push_back(GroupGraph{variant, batch, row0, rows, slot, max_len, g, x});
   return x;
 }
 
@@ -1429,6 +1470,10 @@ static int compact_group(mt3_engine* e, const GroupRun& r, int cur) {
   a.s_int = e->cs_int + 4 * r0;
   a.perm = e->cs_perm + r0 + r.slot;
   a.rows = cur;
+  if (r.variant & kVarStream) {
+    a.slot_seg = e->slot_seg + r0;
+    a.s_seg = e->cs_seg + r0;
+  }
   return mt3k::launch_compact(a, r.s);
 }
 
@@ -1698,6 +1743,412 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
   return decode_finish(e, h_steps_run);
 }
 
+// ------------------------------------------------------------------------------------------- in-flight batching
+// mt3_engine_transcribe (mt3_hip.h): the engine's max_batch decode slots stay full while there are segments left.
+//
+//   producer  the CALLING thread, on the caller's stream: encoder passes over chunks of up to stage_cap segments, each
+//             into one chunk of the staging ring; a chunk is on offer once its pass has finished on the device
+//   consumers the row groups' worker threads: at every poll (32 steps; the stream is drained there as under
+//             MT3_DECODE_EARLY_EXIT) a group takes as many encoded segments off the ring as it has finished slots and
+//             issues the refill launches (decode_ops.hip) on its own stream; what it took at one poll it gives back to
+//             the producer at the NEXT poll, when the drain has proven the copies done
+// Everything the two sides share is host state under one mutex -- no cross-stream events, nobody waits on the device
+// for the other side.  The ring is sized so that a poll's demand is normally on offer (8 chunks of 64 segments).
+struct StageChunk {
+  int first_seg = 0;   // first segment on offer in this chunk
+  int n = 0;           // segments on offer
+  int pad = 0;         // entries in front of them: a short last chunk is encoded together with the `pad` segments before
+                       // it (already handed out earlier), so that every pass is one of >= kStageMinBatch segments and takes
+                       // the same tiles as a full one -- a segment's numbers do not depend on where the corpus ends
+  int batch = 0;       // encoder batch of the pass = pad + n = the plane stride of the chunk's [2][batch][H][T][64] blocks
+  int taken = 0, released = 0;
+};
+
+struct FeedRange {
+  int seq, first_seg, entry0, n, batch;
+};
+
+struct Feed {
+  std::mutex mu;
+  std::condition_variable cv;
+  int n_total = 0;
+  int next_seg = 0;          // first segment not yet handed to an encoder pass
+  int produced = 0;          // chunks on offer so far: sequence numbers [0, produced); sequence q lives in chunk[q % kStageChunks]
+  int head = 0;              // sequence number the consumers take from
+  bool finished = false;     // the producer is done: nothing will be added
+  bool failed = false;       // a group or the producer failed: everybody leaves
+  StageChunk chunk[kStageChunks];
+  int polls = 0, refills = 0, starved = 0;
+};
+
+// up to `want` encoded segments off the ring (whole runs of one chunk each); *dry: nothing is left and nothing will come
+static int feed_pop(Feed& f, int want, FeedRange* out, int max_out, bool* dry) {
+  std::lock_guard<std::mutex> lk(f.mu);
+  int n_out = 0;
+  ++f.polls;
+  while (f.head < f.produced) {
+    StageChunk& c = f.chunk[f.head % kStageChunks];
+    if (c.taken == c.n) {
+      ++f.head;
+      continue;
+    }
+    if (want <= 0 || n_out >= max_out) break;
+    const int avail = c.n - c.taken, take = avail < want ? avail : want;
+    out[n_out++] = FeedRange{f.head, c.first_seg + c.taken, c.pad + c.taken, take, c.batch};
+    c.taken += take;
+    want -= take;
+    f.refills += take;
+  }
+  *dry = f.finished && f.head == f.produced;
+  if (want > 0 && !*dry) ++f.starved;
+  return n_out;
+}
+
+static void feed_release(Feed& f, const std::vector<FeedRange>& held) {
+  if (held.empty()) return;
+  {
+    std::lock_guard<std::mutex> lk(f.mu);
+    for (const FeedRange& r : held) f.chunk[r.seq % kStageChunks].released += r.n;
+  }
+  f.cv.notify_all();
+}
+
+static void feed_fail(Feed& f) {
+  {
+    std::lock_guard<std::mutex> lk(f.mu);
+    f.failed = true;
+  }
+  f.cv.notify_all();
+}
+
+// a group with nothing live sleeps here until the encoder delivers (or there is nothing left to wait for)
+static void feed_wait(Feed& f) {
+  std::unique_lock<std::mutex> lk(f.mu);
+  f.cv.wait(lk, [&] {
+    if (f.failed || f.finished) return true;
+    for (int q = f.head; q < f.produced; ++q)
+      if (f.chunk[q % kStageChunks].taken < f.chunk[q % kStageChunks].n) return true;
+    return false;
+  });
+}
+
+static int ensure_stage(mt3_engine* e) {
+  if (e->stage_cap) return MT3_OK;
+  const mt3_engine_config& c = e->cfg;
+  const int cap = c.max_batch < kStageChunkCap ? c.max_batch : kStageChunkCap;
+  const size_t row = static_cast<size_t>(c.num_heads) * c.input_length * 64;
+  e->stage_kv.assign(c.num_decoder_layers, nullptr);
+  e->stage_scale.assign(c.num_decoder_layers, nullptr);
+  for (int l = 0; l < c.num_decoder_layers; ++l) {
+    MT3_TRY(dmalloc(e, &e->stage_kv[l], static_cast<size_t>(kStageChunks) * 2 * cap * row * e->kv_esize));
+    if (e->kv_fp8)
+      MT3_TRY(dmalloc(e, reinterpret_cast<void**>(&e->stage_scale[l]),
+                      static_cast<size_t>(kStageChunks) * cap * c.num_heads * c.input_length * sizeof(float2)));
+  }
+  e->stage_cap = cap;
+  return MT3_OK;
+}
+
+// the refill launches of one run of staged segments for row group `r` (rg == nullptr: finished slots only hand their
+// ids over -- the queue is empty)
+static int refill_group(mt3_engine* e, const GroupRun& r, int cur, const FeedRange* rg, int32_t* d_out) {
+  const mt3_engine_config& c = e->cfg;
+  const size_t r0 = static_cast<size_t>(r.row0);
+  const int emb = c.emb_dim, n4 = 4 * e->HD();
+  mt3k::RefillArgs a{};
+  a.done = e->done + r0;
+  a.slot_row = e->slot_row + r0;
+  a.slot_seg = e->slot_seg + r0;
+  a.step = e->step + r0;
+  a.cur_tok = e->cur_tok + r0;
+  a.n_done = e->n_done + r.slot;
+  if (r.variant & kVarBeam) {
+    a.beam_f = e->beam_f + r0;
+    a.beam_len = e->beam_len + r0;
+    a.beam_len_row = e->beam_len_row;
+    a.beam_rows = c.max_batch;
+  }
+  a.y = e->y + r0 * emb;                                   // the arg-max kernel leaves the next input row in buffer 0
+  if (e->y_split && c.compute_dtype == MT3_BF16) a.y_ct = static_cast<char*>(e->y_ct) + r0 * emb * 2;
+  if (e->y_split) a.y_ss = e->y_ss + r0 * (emb / 16);
+  a.emb = emb;
+  a.table = e->embedding;
+  a.pos = e->pos_table;
+  a.rp = mt3k::RowProj{e->ew0, e->pw0, e->qkv_fold ? e->qkvf + r0 * n4 : nullptr, n4};
+  a.ids = e->ids;
+  a.ids_stride = c.max_decode_len;
+  a.out_ids = d_out;
+  a.plan = e->refill_plan + r0 + r.slot;
+  a.rows = cur;
+  if (rg) {
+    a.n_new = rg->n;
+    a.first_seg = rg->first_seg;
+    a.n_layers = c.num_decoder_layers;
+    a.row_bytes = static_cast<size_t>(c.num_heads) * c.input_length * 64 * e->kv_esize;
+    a.sc_bytes = static_cast<size_t>(c.num_heads) * c.input_length * sizeof(float2);
+    const size_t chunk = static_cast<size_t>(rg->seq % kStageChunks);
+    for (int l = 0; l < c.num_decoder_layers; ++l) {
+      a.src[l] = static_cast<const char*>(e->stage_kv[l]) + chunk * 2 * e->stage_cap * a.row_bytes;
+      a.dst[l] = static_cast<char*>(e->dec[l].cross_kv);
+      if (e->kv_fp8) {
+        a.src_sc[l] = reinterpret_cast<const char*>(e->stage_scale[l]) + chunk * e->stage_cap * a.sc_bytes;
+        a.dst_sc[l] = reinterpret_cast<char*>(e->dec[l].cross_scale);
+      }
+    }
+    a.src_batch = rg->batch;
+    a.src_entry0 = rg->entry0;
+    a.dst_batch = r.batch;
+  }
+  return mt3k::launch_refill(a, r.s);
+}
+
+// One row group's loop of mt3_engine_transcribe: as run_group, but a finished slot restarts on the next staged segment
+// at the poll, and the loop ends when the queue is empty for good and every slot of the group has finished.
+static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out, long max_steps) {
+  const int kPoll = 32;
+  int cur = r.rows;
+  hipGraphExec_t exec = nullptr;
+  int exec_rows = -1, flushed_at = -1;
+  std::vector<FeedRange> held, got(kStageChunks + 2);
+  r.ran = 0;
+  r.used_graph = r.use_graph;
+  for (long t = 0;; ++t) {
+    if (t >= max_steps) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: a row group did not terminate");
+    if (r.use_graph && exec_rows != cur) {
+      exec = group_graph(e, r.variant, r.batch, r.row0, cur, r.slot);
+      exec_rows = cur;
+      if (!exec) {
+        r.use_graph = r.used_graph = false;
+        ++e->graph_fallbacks;
+      }
+    }
+    if (r.use_graph) MT3_HIP_CHECK(hipGraphLaunch(exec, r.s));
+    else MT3_TRY(enqueue_chain_step(e, r.row0, cur, r.slot, r.batch, r.variant, r.s, r.slot));
+    ++r.ran;
+    if (t % kPoll != kPoll - 1) continue;
+    // ---- the poll
+    MT3_HIP_CHECK(hipMemcpyAsync(e->h_pinned + r.slot, e->n_done + r.slot, 4, hipMemcpyDeviceToHost, r.s));
+    MT3_HIP_CHECK(hipStreamSynchronize(r.s));
+    feed_release(f, held);                       // the copies out of what was taken at the previous poll have run
+    held.clear();
+    int n_fin = e->h_pinned[r.slot];             // finished slots among the group's r.rows (dropped ones included)
+    bool dry = false;
+    for (;;) {
+      {
+        std::lock_guard<std::mutex> lk(f.mu);
+        if (f.failed) return MT3_OK;             // somebody else reports the error
+      }
+      const int refillable = n_fin - (r.rows - cur);
+      const int nr = feed_pop(f, refillable, got.data(), static_cast<int>(got.size()), &dry);
+      for (int i = 0; i < nr; ++i) {
+        MT3_TRY(refill_group(e, r, cur, &got[i], d_out));
+        held.push_back(got[i]);
+        n_fin -= got[i].n;
+      }
+      if (dry || n_fin < r.rows) break;
+      feed_wait(f);                              // nothing live and the encoder is behind: sleep, do not spin through empty steps
+    }
+    if (!dry) continue;
+    // ---- the queue is empty for good: finished slots hand over their ids, the live ones are compacted as under EARLY_EXIT
+    if (n_fin - (r.rows - cur) > 0 && n_fin != flushed_at) {
+      MT3_TRY(refill_group(e, r, cur, nullptr, d_out));
+      flushed_at = n_fin;
+    }
+    const int live = r.rows - n_fin;
+    if (live <= 0) break;
+    int want = (live + 31) & ~31;
+    if (want > r.rows) want = r.rows;
+    if (want < cur) {
+      MT3_TRY(compact_group(e, r, cur));
+      cur = want;
+      ++e->compactions_now;
+    }
+  }
+  MT3_HIP_CHECK(hipStreamSynchronize(r.s));
+  feed_release(f, held);
+  return MT3_OK;
+}
+
+// the producer side of the feed (calling thread, caller's stream)
+static int produce_chunks(mt3_engine* e, Feed& f, const float* d_inputs, hipStream_t s) {
+  const mt3_engine_config& c = e->cfg;
+  const size_t seg_floats = static_cast<size_t>(c.input_length) * c.input_depth;
+  const size_t row = static_cast<size_t>(c.num_heads) * c.input_length * 64;
+  const int min_batch = e->stage_cap < kStageMinBatch ? e->stage_cap : kStageMinBatch;
+  std::vector<void*> kv(c.num_decoder_layers);
+  std::vector<float2*> sc(c.num_decoder_layers, nullptr);
+  int rc = MT3_OK;
+  for (int q = 0; rc == MT3_OK; ++q) {
+    int first, n;
+    {
+      std::unique_lock<std::mutex> lk(f.mu);
+      if (f.next_seg >= f.n_total) break;
+      StageChunk& ch = f.chunk[q % kStageChunks];          // still holds sequence q - kStageChunks
+      f.cv.wait(lk, [&] { return f.failed || q < kStageChunks || ch.released == ch.n; });
+      if (f.failed) break;
+      first = f.next_seg;
+      n = f.n_total - first < e->stage_cap ? f.n_total - first : e->stage_cap;
+      f.next_seg += n;
+    }
+    int pad = n < min_batch ? min_batch - n : 0;
+    if (pad > first) pad = first;
+    const size_t chunk = static_cast<size_t>(q % kStageChunks);
+    for (int l = 0; l < c.num_decoder_layers; ++l) {
+      kv[l] = static_cast<char*>(e->stage_kv[l]) + chunk * 2 * e->stage_cap * row * e->kv_esize;
+      if (e->kv_fp8) sc[l] = e->stage_scale[l] + chunk * e->stage_cap * c.num_heads * c.input_length;
+    }
+    CrossDst dst;
+    dst.kv = kv.data();
+    dst.scale = e->kv_fp8 ? sc.data() : nullptr;
+    rc = encode_impl(e, d_inputs + static_cast<size_t>(first - pad) * seg_floats, pad + n, nullptr, dst, s);
+    if (rc == MT3_OK && hipStreamSynchronize(s) != hipSuccess) rc = mt3::fail(MT3_ERR_HIP, "mt3_engine_transcribe: encoder pass failed");
+    if (rc != MT3_OK) break;
+    {
+      std::lock_guard<std::mutex> lk(f.mu);
+      StageChunk& ch = f.chunk[q % kStageChunks];
+      ch = StageChunk();
+      ch.first_seg = first;
+      ch.n = n;
+      ch.pad = pad;
+      ch.batch = pad + n;
+      ++f.produced;
+    }
+    f.cv.notify_all();
+  }
+  {
+    std::lock_guard<std::mutex> lk(f.mu);
+    f.finished = true;
+    if (rc != MT3_OK) f.failed = true;
+  }
+  f.cv.notify_all();
+  return rc;
+}
+
+int mt3_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
+                          int32_t* d_ids, mt3_transcribe_stats* h_stats, void* stream) {
+  if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: engine not finalized");
+  if (e->pending.active)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: a decode is in flight (MT3_DECODE_ASYNC): call mt3_engine_decode_wait first");
+  const mt3_engine_config& c = e->cfg;
+  if (!d_inputs || !d_ids || n_segments <= 0) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: null buffer or no segments");
+  if (num_steps <= 0 || num_steps > c.max_decode_len) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: num_steps out of range");
+  if (flags & ~(MT3_DECODE_NO_GRAPH | MT3_DECODE_BEAM1 | MT3_DECODE_SINGLE_STREAM))
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: flags are MT3_DECODE_NO_GRAPH | MT3_DECODE_BEAM1 | MT3_DECODE_SINGLE_STREAM");
+  if (c.num_decoder_layers > mt3k::kRefillMaxLayers) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: at most 16 decoder layers");
+  if (e->eos_on && n_segments > e->eos_cap)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: the synthetic EOS schedule is shorter than n_segments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int L = c.max_decode_len, S = n_segments < c.max_batch ? n_segments : c.max_batch;
+  const bool beam1 = (flags & MT3_DECODE_BEAM1) != 0;
+  if (n_segments > S) MT3_TRY(ensure_stage(e));
+  int groups = ((flags & MT3_DECODE_SINGLE_STREAM) || (c.options & MT3_OPT_NO_ROW_GROUPS)) ? 1 : stream_row_groups_for(c, S);
+  if (ensure_group_streams(e, groups) != MT3_OK)
+    return mt3::fail(MT3_ERR_HIP, "mt3_engine_transcribe: could not create the row groups' streams");
+
+  // ---- the first S segments go straight into the caches; every slot starts as in mt3_engine_decode
+  MT3_TRY(encode_impl(e, d_inputs, S, nullptr, CrossDst{}, s));
+  e->cur_batch = S;
+  MT3_HIP_CHECK(hipMemsetAsync(d_ids, 0, static_cast<size_t>(n_segments) * L * 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->step, 0, static_cast<size_t>(S) * 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->n_done, 0, 4 * kMaxChains, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->done, 0, static_cast<size_t>(S) * 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->cur_tok, 0, static_cast<size_t>(S) * 4, s));
+  MT3_HIP_CHECK(hipMemsetAsync(e->ids, 0, static_cast<size_t>(S) * L * 4, s));
+  {
+    const mt3k::RowProj rp{e->ew0, e->pw0, e->qkv_fold ? e->qkvf : nullptr, 4 * e->HD()};
+    MT3_TRY(mt3k::launch_embed(e->embedding, e->pos_table, e->cur_tok, e->step, e->y,
+                               c.compute_dtype == MT3_BF16 ? e->y_ct : nullptr, e->y_ss, S, c.emb_dim, rp, s));
+  }
+  MT3_TRY(mt3k::launch_iota(e->slot_row, S, s));
+  MT3_TRY(mt3k::launch_iota(e->slot_seg, S, s));         // slot i starts on segment i
+  if (beam1) {
+    MT3_TRY(mt3k::launch_set_float(e->beam_cfg, brevity_penalty(num_steps + 1), s));
+    MT3_HIP_CHECK(hipMemsetAsync(e->beam_f, 0, static_cast<size_t>(2) * c.max_batch * 4, s));
+    MT3_HIP_CHECK(hipMemsetAsync(e->beam_len, 0xFF, static_cast<size_t>(c.max_batch) * 4, s));
+    MT3_HIP_CHECK(hipMemsetAsync(e->beam_len_row, 0xFF, static_cast<size_t>(c.max_batch) * 4, s));
+  }
+  if (e->group_graphs.size() > 96) drop_group_graphs(e);
+  e->stream_max_len = num_steps;
+  const int variant = (beam1 ? kVarBeam : 0) | kVarRetire | kVarStream | (e->eos_on ? kVarEos : 0);
+  const bool use_graph = !(flags & MT3_DECODE_NO_GRAPH);
+  MT3_HIP_CHECK(hipEventRecord(e->part_begin, s));
+
+  Feed feed;
+  feed.n_total = n_segments;
+  feed.next_seg = S;
+  feed.finished = n_segments == S;
+  PendingDecode& p = e->pending;
+  p = PendingDecode();
+  p.groups = groups;
+  p.active = true;                                       // every other entry point of the engine refuses meanwhile
+  // a segment needs at most num_steps steps; rounds of refills are bounded by the segments a slot can see
+  const long max_steps = static_cast<long>(num_steps + 64) * (static_cast<long>(n_segments) / S + 2);
+  bool posted_all = true;
+  for (int g = 0; g < groups && posted_all; ++g) {
+    auto body = [e, g, groups, S, variant, num_steps, use_graph, &feed, d_ids, max_steps]() {
+      PendingDecode& q = e->pending;
+      GroupRun r{};
+      chain_rows(S, groups, g, &r.row0, &r.rows);
+      r.batch = S;
+      r.variant = variant;
+      r.num_steps = num_steps;
+      r.slot = g;
+      r.early = true;
+      r.use_graph = use_graph;
+      r.s = e->part_stream[g];
+      hipError_t he = hipStreamWaitEvent(r.s, e->part_begin, 0);
+      if (he == hipSuccess) {
+        q.rcs[g] = run_group_stream(e, r, feed, d_ids, max_steps);
+        if (q.rcs[g] != MT3_OK) q.errs[g] = mt3_last_error();
+        he = hipStreamSynchronize(r.s);
+      }
+      if (q.rcs[g] == MT3_OK && he != hipSuccess) {
+        q.rcs[g] = MT3_ERR_HIP;
+        q.errs[g] = hipGetErrorString(he);
+      }
+      q.ran[g] = r.ran;
+      q.used_graph[g] = r.used_graph;
+      if (q.rcs[g] != MT3_OK) feed_fail(feed);           // nobody may wait for this group's entries any more
+    };
+    if (worker_post(e, g, body)) p.posted = g + 1;
+    else posted_all = false;
+  }
+  int rc = MT3_OK;
+  if (!posted_all) {
+    feed_fail(feed);
+    rc = mt3::fail(MT3_ERR_HIP, "mt3_engine_transcribe: could not start a row group's worker thread");
+  } else if (n_segments > S) {
+    rc = produce_chunks(e, feed, d_inputs, s);
+  }
+  const std::string producer_err = rc != MT3_OK ? mt3_last_error() : "";
+  for (int g = 0; g < p.posted; ++g) worker_wait(e, g);
+  p.active = false;
+  e->compactions = e->compactions_now.exchange(0);
+  e->last_groups = groups;
+  int most = 0;
+  e->last_used_graph = 1;
+  for (int g = 0; g < p.posted; ++g) {
+    if (rc == MT3_OK && p.rcs[g] != MT3_OK)
+      rc = mt3::fail(p.rcs[g], "mt3_engine_transcribe (row group " + std::to_string(g) + "): " + p.errs[g]);
+    most = p.ran[g] > most ? p.ran[g] : most;
+    if (!p.used_graph[g]) e->last_used_graph = 0;
+  }
+  mt3_transcribe_stats st{};
+  st.slots = S;
+  st.groups = groups;
+  st.steps_run = most;
+  st.polls = feed.polls;
+  st.refills = feed.refills;
+  st.starved_polls = feed.starved;
+  st.encoder_chunks = feed.produced;
+  st.compactions = e->compactions;
+  st.used_graph = e->last_used_graph;
+  e->last_stats = st;
+  if (h_stats) *h_stats = st;
+  if (rc != MT3_OK && !producer_err.empty()) return mt3::fail(rc, producer_err);
+  return rc;
+}
+
 int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t* d_ids,
                       float* d_first_logits, int32_t* h_steps_run, void* stream) {
   return decode_impl(e, batch, num_steps, flags, 0, nullptr, nullptr, d_ids, d_first_logits, h_steps_run, stream);
@@ -1730,8 +2181,18 @@ int mt3_debug_engine_set_eos_schedule(mt3_engine* e, const int32_t* h_lengths, i
     e->eos_on = false;
     return MT3_OK;
   }
-  if (n <= 0 || n > e->cfg.max_batch) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_set_eos_schedule: 1 .. max_batch lengths");
-  std::vector<int32_t> h(static_cast<size_t>(e->cfg.max_batch), 0x7fffffff);       // rows past n: never
+  if (n <= 0) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_set_eos_schedule: n must be positive");
+  if (n > e->eos_cap) {
+    // a schedule per SEGMENT of an mt3_engine_transcribe call: a larger array (the captured step graphs hold the old
+    // address, so they go; the old array stays in the engine's allocation list until destroy)
+    int* grown = nullptr;
+    MT3_TRY(dmalloc(e, reinterpret_cast<void**>(&grown), static_cast<size_t>(n) * 4));
+    drop_graph(e);
+    drop_group_graphs(e);
+    e->eos_at = grown;
+    e->eos_cap = n;
+  }
+  std::vector<int32_t> h(static_cast<size_t>(e->eos_cap), 0x7fffffff);       // rows / segments past n: never
   for (int i = 0; i < n; ++i) {
     if (h_lengths[i] < 1) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_set_eos_schedule: lengths must be >= 1");
     h[i] = h_lengths[i];
@@ -1743,6 +2204,7 @@ int mt3_debug_engine_set_eos_schedule(mt3_engine* e, const int32_t* h_lengths, i
 
 int mt3_debug_engine_poison_caches(mt3_engine* e, int32_t pattern, int32_t cross, void* stream) {
   if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_poison_caches: engine not finalized");
+  if (e->pending.active) return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_poison_caches: a decode is in flight");
   const mt3_engine_config& c = e->cfg;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t heads = static_cast<size_t>(c.max_batch) * c.num_heads;

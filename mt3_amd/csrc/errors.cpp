@@ -16,5 +16,5 @@ int fail(int code, const std::string& msg) {
 
 extern "C" {
 const char* mt3_last_error(void) { return g_last_error.c_str(); }
-int mt3_abi_version(void) { return 3; }   // 3: MT3_DECODE_ASYNC + mt3_engine_decode_wait, row retirement; the launch-shape knobs are gone
+int mt3_abi_version(void) { return 4; }   // 4: mt3_engine_transcribe (in-flight batching); 3: MT3_DECODE_ASYNC + mt3_engine_decode_wait, row retirement
 }

@@ -133,10 +133,16 @@ struct BeamState {
 //   eos_at  : [rows] bench / test hook (mt3_debug_engine_set_eos_schedule): row r's distribution at step eos_at[r] - 1
 //             is replaced by a point mass on EOS -- greedy emits EOS there, the beam-1 search finishes prefix + EOS with
 //             log-prob 0 and closes (its live hypothesis drops to -inf)
+//   slot_seg: [B] in-flight batching (mt3_engine_transcribe): the SEGMENT a slot is decoding -- `eos_at` is then indexed by
+//             segment, not by row (a cache row serves many segments in turn)
+//   max_len : > 0: a slot whose position counter reaches max_len is finished whether or not it emitted EOS (a refilled slot
+//             starts at position 0 at an arbitrary step of its group's loop, so the loop bound cannot do it)
 struct StepRetire {
   int retire;
   const int* slot_row;
   const int* eos_at;
+  const int* slot_seg;
+  int max_len;
 };
 // token pick + bookkeeping for one decode step (see decode_ops.hip); beam == nullptr: greedy;
 // forced != nullptr (greedy only): teacher forcing, the next input token is forced[b * forced_stride + t]
@@ -171,8 +177,56 @@ struct CompactArgs {
   float* s_beam;        // [rows][2]
   int* perm;            // [rows + 1]: perm[i] = source slot of new slot i; perm[rows] = n_live
   int rows;             // slots of the group in use before the compaction
+  // in-flight batching: the slot -> segment map travels with the slot; a dropped slot decodes nothing (-1)
+  int* slot_seg;        // (nullptr: not in use)
+  int* s_seg;           // scratch [rows]
 };
 int launch_compact(const CompactArgs& c, hipStream_t s);
+// Refill of finished slots (in-flight batching, mt3_engine_transcribe): at a poll of a row group's loop every FINISHED
+// slot of the group hands its id row to the caller's output (row = the segment it decoded; the beam-1 finalisation of
+// that row applied on the way) and the first `n_new` of them, in ascending slot order, restart at position 0 on segments
+// first_seg, first_seg + 1, ...: BOS input row in its three forms, layer 0's projected row, counters, beam state, a
+// zeroed id row, and the segment's cross-attention K/V copied from the staging chunk an encoder pass left them in into
+// the cache rows the slot owns (the self-attention cache needs nothing: what lies past a row's position is discarded by
+// position).  The others decode nothing from then on (slot_seg = -1) until a later refill.  All slot-indexed pointers are
+// those of the group's first slot; ids / beam_len_row / the caches are batch bases (reached through slot_row).
+constexpr int kRefillMaxLayers = 16;
+struct RefillArgs {
+  int* done;
+  int* slot_row;
+  int* slot_seg;
+  int* step;
+  int* cur_tok;
+  int* n_done;          // the group's counter of finished slots: decremented by the number of slots refilled
+  float* beam_f;        // [2][beam_rows] (nullptr: greedy)
+  int* beam_len;
+  int* beam_len_row;    // batch base
+  int beam_rows;
+  float* y;             // [rows][emb] f32 input rows of the next step
+  void* y_ct;           // bf16 copy (nullptr: f32 engine)
+  float* y_ss;          // (nullptr: single residual stream)
+  int emb;
+  const float* table;   // token embedding (row 0 = BOS) and position table (row 0)
+  const float* pos;
+  RowProj rp;           // q_out = the group's qkvf rows (nullptr: no qkv-fold)
+  int* ids;             // engine id rows [max_batch][ids_stride] (batch base)
+  int ids_stride;
+  int* out_ids;         // caller's [n_segments][ids_stride]
+  int* plan;            // [rows + 1] scratch: plan[i] = i-th finished slot (ascending), plan[rows] = how many
+  int rows;             // slots of the group in use
+  int n_new;            // segments handed out by this call (<= finished slots)
+  int first_seg;
+  // cross-attention K/V: per decoder layer, staging chunk [2][src_batch][row_bytes] -> cache [2][dst_batch][row_bytes];
+  // with e4m3 caches also the scale rows [src_batch][sc_bytes] -> [dst_batch][sc_bytes]
+  int n_layers;
+  const char* src[kRefillMaxLayers];
+  char* dst[kRefillMaxLayers];
+  const char* src_sc[kRefillMaxLayers];
+  char* dst_sc[kRefillMaxLayers];
+  int src_batch, src_entry0, dst_batch;
+  size_t row_bytes, sc_bytes;
+};
+int launch_refill(const RefillArgs& a, hipStream_t s);
 int launch_iota(int* dst, int n, hipStream_t s);
 int launch_set_float(float* dst, float v, hipStream_t s);
 int launch_beam1_finalize(int* ids, int L, const int* beam_len, int B, hipStream_t s);

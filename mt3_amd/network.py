@@ -229,6 +229,30 @@ class Transformer:
         self.steps_run = ran.value
         return (ids, logits) if return_first_logits else ids
 
+    def transcribe(self, encoder_input_tokens, num_steps: Optional[int] = None, beam1: bool = False,
+                   use_graph: bool = True, single_stream: bool = False):
+        """mt3_engine_transcribe: encode + decode of ANY number of segments through the engine's `max_batch` decode slots
+        with in-flight batching -- a slot whose segment has finished restarts on the next one (the reference's loop over
+        `.batch(8)` calls of predict_batch_with_aux, NB:295-301, without its batch-synchronous wait for the longest row).
+        encoder_input_tokens: CUDA f32 [N, T, input_depth].  Returns int32 CUDA [N, L] ids, row i = segment i, bit-identical
+        to encode() + decode(early_exit=True) of that segment; `self.transcribe_stats` says what ran."""
+        import torch
+        x = encoder_input_tokens
+        if x.dim() != 3 or x.shape[1] != self.input_length or x.shape[2] != self.config.input_depth:
+            raise ValueError(f"expected [N, {self.input_length}, {self.config.input_depth}], got {tuple(x.shape)}")
+        x = x.to(device="cuda", dtype=torch.float32).contiguous()
+        N, L = x.shape[0], self.max_decode_length
+        ids = torch.empty((N, L), device="cuda", dtype=torch.int32)
+        flags = (0 if use_graph else _lib.DECODE_NO_GRAPH) | (_lib.DECODE_BEAM1 if beam1 else 0) | \
+            (_lib.DECODE_SINGLE_STREAM if single_stream else 0)
+        st = _lib.TranscribeStats()
+        _lib.check(self._lib.mt3_engine_transcribe(self._h, x.data_ptr(), N, num_steps or L, flags, ids.data_ptr(),
+                                                   C.byref(st), torch.cuda.current_stream().cuda_stream))
+        self._batch = min(N, self.max_batch)
+        self.transcribe_stats = {n: int(getattr(st, n)) for n, _ in st._fields_ if n != "reserved"}
+        self.steps_run = st.steps_run
+        return ids
+
     def decode_wait(self):
         """mt3_engine_decode_wait: join the decode a `decode(wait=False)` started; returns what that call would have."""
         ran = C.c_int32()

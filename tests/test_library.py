@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported_and_typed():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in mt3_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.mt3_abi_version() == 3
+    assert lib.mt3_abi_version() == 4
 
 
 def test_argument_errors_are_reported_not_swallowed():
