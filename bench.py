@@ -65,12 +65,16 @@ def kernel_source_hash(files=("attention.hip", "device.h", "kernels.h")):
 
 
 # ----------------------------------------------------------------------------------------- CPU baseline
-def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int, small_segments: int = 0):
+def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int, small_segments: int = 0, parity_file: str = ""):
     """The oracle (CPU restatement of the reference path: numpy frontend + torch-CPU f32 network + pure-Python
     note decoding; NOT JAX -- SURVEY 8c: jax/t5x are not installable here) timed on this box's host cores on a
     bounded sample: (a) the full path on `n_segments` segments as ONE batch (reduced configs[2]; 8 = the reference
     InferenceModel's batch size, NB:190), (b) a batch-scaling probe at `small_segments` segments (first 48 decode steps
-    only), (c) configs[1]: log-mel + encoder only on `enc_segments` segments."""
+    only), (c) configs[1]: log-mel + encoder only on `enc_segments` segments.
+    parity_file (written by the GPU leg): the audio of the FIRST `n_segments` rows of the headline batch, the product's
+    log-mel, ids and notes of those rows as the headline's own schedule produced them -- the timed sample then runs on
+    that audio and its tokens / notes are COMPARED with the product's (`parity`): the driver-run line carries parity at
+    the credited configuration."""
     import numpy as np
     import torch
     from mt3_amd import network
@@ -79,6 +83,12 @@ def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int, small_se
     cfg = network.T5Config(dtype="float32")
     params = network.init_random_params(cfg, seed=0)
     audio = OF.synth_audio(max(n_segments, enc_segments), seed=0)
+    par = None
+    if parity_file:
+        with np.load(parity_file) as z:
+            par = {k: z[k] for k in z.files}
+        n_segments = min(n_segments, par["audio"].shape[0])
+        audio = np.concatenate([par["audio"][:n_segments].astype(audio.dtype), audio[n_segments:]])
     orc = ON.Oracle(params, ON.T5Config())
     vocab = OS.GenericTokenVocabulary(1388, extra_ids=100)
     codec = OS.build_codec(OS.VocabularyConfig(num_velocity_bins=1))
@@ -106,21 +116,64 @@ def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int, small_se
             t0 = time.perf_counter()
             lm = np.stack([OF.compute_logmel(a, np.float32) for a in audio[:n]])
             enc = orc.encode(lm)
-            ids = orc.greedy_decode(enc, decode_steps)
+            ids, logits = orc.greedy_decode(enc, decode_steps, return_logits=True)
             toks = vocab.decode_tf(ids)
             preds = [{"est_tokens": OS.trim_eos(t), "start_time": OS.floor_start_time(i * SEG_SECONDS, 100)}
                      for i, t in enumerate(toks)]
-            OS.event_predictions_to_ns(preds, codec, "ties")
-            return time.perf_counter() - t0, threads
+            ns = OS.event_predictions_to_ns(preds, codec, "ties")["est_ns"]
+            return time.perf_counter() - t0, threads, (lm, ids, logits, ns)
+
+    def divergences(ids_cpu, logits, ids_gpu):
+        """(rows token-exact over all steps, [first divergence of every other row with the oracle's top-2 margin there])"""
+        exact, div = 0, []
+        for r in range(ids_cpu.shape[0]):
+            d = np.nonzero(ids_cpu[r] != ids_gpu[r, : ids_cpu.shape[1]])[0]
+            if d.size == 0:
+                exact += 1
+                continue
+            t = int(d[0])
+            lg = logits[r, t].double()
+            top = torch.topk(lg, 2).values
+            div.append({"row": r, "step": t, "oracle_id": int(ids_cpu[r, t]), "product_id": int(ids_gpu[r, t]),
+                        "oracle_top2_margin_over_sigma": float((top[0] - top[1]) / lg.std())})
+        return exact, div
 
     t_begin = time.perf_counter()
-    dt, threads = full_path(n_segments, (16, 32, 64))
+    dt, threads, (lm_cpu, ids_cpu, logits_cpu, ns_cpu) = full_path(n_segments, (16, 32, 64))
     out = {"value": n_segments * SEG_SECONDS / dt, "unit": "audio-s/s", "cores": threads, "nproc": nproc,
            "kind": "port",
            "sample": "%d segments as one batch (%.1f s of audio; the reference InferenceModel's own batch size, NB:190), "
                      "same path: log-mel + encoder + %d greedy steps + note decoding; oracle restatement (numpy/torch-CPU "
                      "f32), not JAX; %d torch threads (fastest of 16/32/64 of nproc=%d on a 4-step probe); %.1f s wall"
                      % (n_segments, n_segments * SEG_SECONDS, decode_steps, threads, nproc, dt)}
+    if par is not None:
+        # ---- parity at the credited configuration: the oracle's audio -> tokens -> notes of these rows against the
+        # product's, as the HEADLINE's schedule (row groups, graph replay) produced them inside the full batch
+        ids_gpu = par["ids"][:n_segments]
+        exact, div = divergences(ids_cpu, logits_cpu, ids_gpu)
+        lm_gpu = par["logmel"][:n_segments]
+        sig = np.exp(lm_cpu) > 1e-2
+        got_notes = [tuple(r) for r in par["notes"].tolist()]
+        ref_notes = [tuple(float(v) for v in t[:6]) for t in ns_cpu.as_tuples()]
+        parity = {"rows": int(n_segments), "steps": int(decode_steps), "token_exact_rows": exact, "first_divergence": div,
+                  "notes_equal": got_notes == ref_notes, "notes": len(ref_notes),
+                  "logmel_max_abs_diff_where_mel_above_1e-2": float(np.abs(lm_gpu - lm_cpu)[sig].max()),
+                  "what": "oracle (numpy frontend -> torch-CPU f32 network -> greedy loop -> pure-Python note decoding) "
+                          "on the audio of the first %d rows of the headline batch, against the ids / notes the "
+                          "headline engine produced for those rows inside its %d-row batch (%s)"
+                          % (n_segments, int(par["batch"]), str(par["schedule"]))}
+        if div and time.perf_counter() - t_begin < 120.0:
+            # rows that differ end to end: is it the frontend's 1e-4 or the network?  the oracle's network alone, fed the
+            # PRODUCT's log-mel of those rows
+            rows = [d["row"] for d in div]
+            with torch.no_grad():
+                ids2, lg2 = orc.greedy_decode(orc.encode(lm_gpu[rows]), decode_steps, return_logits=True)
+            ex2, div2 = divergences(ids2, lg2, ids_gpu[rows])
+            for d in div2:
+                d["row"] = rows[d["row"]]
+            parity["network_on_product_logmel"] = {"rows": len(rows), "token_exact_rows": ex2, "first_divergence": div2}
+            parity["token_exact_rows_network"] = exact + ex2
+        out["parity"] = parity
     if small_segments and time.perf_counter() - t_begin < 110.0:
         # does a LARGER batch use the host better?  (VERDICT r2 #9 asked for 32 segments: measured on MI355X hosts it is
         # SLOWER per audio-second -- 190 s for the full 1024 steps, 0.35 against 0.52 audio-s/s -- so the full-length
@@ -219,10 +272,11 @@ def main():
     ap.add_argument("--cpu-small-segments", type=int, default=32, help="batch of the CPU batch-scaling probe (0: skip)")
     ap.add_argument("--cpu-enc-segments", type=int, default=64)
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-parity-file", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print("CPU_BASELINE " + json.dumps(cpu_baseline(args.cpu_segments, args.decode_steps, args.cpu_enc_segments,
-                                                        args.cpu_small_segments)), flush=True)
+                                                        args.cpu_small_segments, args.cpu_parity_file)), flush=True)
         return 0
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
@@ -807,12 +861,38 @@ def main():
             "extra": extras,
         }
         if not args.no_cpu_baseline and world == 1:
+            parity_args = []
+            if args.dtype == "float32" and args.model == "mt3" and not args.kv_dtype and not args.dense_dtype and not corpus:
+                # the rows the oracle will be compared on: the first cpu_segments rows of the headline batch, decoded once
+                # more by the headline engine in the headline's schedule inside the full batch
+                try:
+                    import tempfile
+                    n8 = min(args.cpu_segments, B)
+                    with torch.cuda.stream(stream):
+                        lm_all = spectrograms.compute_spectrogram_batch(audio[:B], None)
+                        eng.encode(lm_all)
+                        ids_all = eng.decode(num_steps=args.decode_steps, beam1=False)
+                        tok8 = vocab.decode_tf(ids_all[:n8]).cpu().numpy()
+                    eos8 = tok8 == vocabularies.DECODED_EOS_ID
+                    n_tok = np.where(eos8.any(1), eos8.argmax(1), tok8.shape[1])
+                    ns8, _, _ = metrics_utils._run(codec, note_sequences.NoteEncodingWithTiesSpec.spec_id,
+                                                   [r[:n] for r, n in zip(tok8, n_tok)], start_times[:n8])
+                    notes8 = np.array([[n.start_time, n.end_time, n.pitch, n.velocity, n.program, float(n.is_drum)]
+                                       for n in ns8.notes], np.float64).reshape(-1, 6)
+                    sched = "%d row groups, %s" % (eng.status(_lib.STATUS_LAST_DECODE_GROUPS),
+                                                   "graph replay" if eng.status(_lib.STATUS_LAST_DECODE_USED_GRAPH) else "direct launches")
+                    pf = os.path.join(tempfile.mkdtemp(prefix="mt3_parity_"), "rows.npz")
+                    np.savez(pf, audio=audio[:n8].cpu().numpy(), logmel=lm_all[:n8].cpu().numpy(),
+                             ids=ids_all[:n8].cpu().numpy(), notes=notes8, batch=np.int64(B), schedule=np.str_(sched))
+                    parity_args = ["--cpu-parity-file", pf]
+                except Exception as ex:
+                    out["cpu_parity_error"] = repr(ex)[:300]
             # separate process, hard wall-clock bound: the bench must finish in minutes on any host
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-segments",
                                     str(args.cpu_segments), "--cpu-small-segments", str(args.cpu_small_segments),
                                     "--cpu-enc-segments", str(args.cpu_enc_segments),
-                                    "--decode-steps", str(args.decode_steps)],
+                                    "--decode-steps", str(args.decode_steps)] + parity_args,
                                    capture_output=True, text=True, timeout=300)
                 line = [l for l in r.stdout.splitlines() if l.startswith("CPU_BASELINE ")]
                 out["cpu_baseline"] = json.loads(line[-1][len("CPU_BASELINE "):]) if line else \

@@ -177,11 +177,15 @@ class Oracle:
 
     @torch.no_grad()
     def greedy_decode(self, encoded: torch.Tensor, max_steps: int, eos_id: int = 1,
-                      return_logits: bool = False):
+                      return_logits: bool = False, eos_lengths=None):
         """Greedy: argmax each step (ties -> lowest id), BOS = 0; once a row has
         emitted EOS its later ids are 0 (pad).  Returns int32 [B, max_steps]
-        (and the per-step logits if asked)."""
+        (and the per-step logits if asked).  eos_lengths [B] (tests / bench only): the
+        synthetic EOS schedule of SURVEY.md 8(d) -- row b's distribution at step
+        eos_lengths[b] - 1 is a point mass on EOS (include/mt3_hip_debug.h states the
+        same rule for the engine)."""
         B = encoded.shape[0]
+        forced = None if eos_lengths is None else torch.as_tensor(np.asarray(eos_lengths, np.int64))
         cache = self._init_cache(encoded)
         tok = torch.zeros(B, dtype=torch.int64)
         done = torch.zeros(B, dtype=torch.bool)
@@ -192,6 +196,8 @@ class Oracle:
             if return_logits:
                 all_logits.append(logits.clone())
             nxt = torch.argmax(logits, dim=-1)
+            if forced is not None:
+                nxt = torch.where(t + 1 >= forced, torch.full_like(nxt, eos_id), nxt)
             nxt = torch.where(done, torch.zeros_like(nxt), nxt)
             ids[:, t] = nxt.to(torch.int32)
             done = done | (nxt == eos_id)
