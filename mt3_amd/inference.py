@@ -12,7 +12,13 @@ mt3/inference.py:34-138 (the t5x `infer` write_fn).
 Differences that are deliberate: the t5x/gin/tf.data plumbing is gone -- segments
 are cut and padded on the host exactly as the reference's preprocessors do
 (`_audio_to_frames`, split into `inputs_length`-frame chunks, zero rows after the
-log for a short last segment), everything numeric runs in libmt3hip.so.  Decoding
+log for a short last segment), everything numeric runs in libmt3hip.so.  `batch_size`
+stays the reference's 8 as an ATTRIBUTE (`input_shapes`, NB:190), but the engine behind
+`predict_tokens` is sized to the JOB -- up to `max_slots` decode slots, grown lazily -- and
+runs mt3_engine_transcribe: a 10-minute file is ONE engine call whose finished rows are
+refilled with the file's next segments, not 37 batch-synchronous calls of 8 rows
+(`schedule="batch"` keeps the reference's loop for comparison); the log-mel stays on
+the device between `preprocess` and `predict_tokens`.  Decoding
 defaults to `decoding="beam1"`: the selection rule of t5x beam search with one beam and
 alpha 0.6, which is what the reference's predict_batch_with_aux runs (SURVEY.md A.5);
 `decoding="greedy"` stops a row at its first arg-max EOS.
@@ -49,11 +55,16 @@ class InferenceModel(object):
 
     def __init__(self, checkpoint_path, model_type="mt3", *, config: Optional[network.T5Config] = None,
                  dtype: str = "float32", batch_size: int = 8, early_exit: bool = True,
-                 decoding: str = "beam1"):
+                 decoding: str = "beam1", max_slots: int = 256, schedule: str = "refill"):
         """dtype: 'float32' (default) = the reference's own precision (gin/model.gin:50 restores and runs
         float32): f32 MFMA operands, f32 K/V cache, token-exact against the oracle.  'bfloat16' is the explicit
         opt-in fast path (bf16 operands and caches, f32 accumulation / residual / softmax; what bench.py times;
-        logits within 3e-2 rel-L2 of f32 at every cache depth, tests/test_gpu_parity_deep.py)."""
+        logits within 3e-2 rel-L2 of f32 at every cache depth, tests/test_gpu_parity_deep.py).
+        max_slots: the most decode slots the engine behind `predict_tokens` may hold (its K/V caches are allocated for
+        that many rows: 3.2 GB per 64 slots in f32 at the MT3 shape); the engine starts at `batch_size` slots and is rebuilt
+        with more (next power of two) when a job has more segments.  schedule: 'refill' = one mt3_engine_transcribe call
+        per job (in-flight batching; needs early_exit); 'batch' = the reference's loop, one batch-synchronous engine call
+        per `batch_size` segments (NB:295-301)."""
         if model_type == "ismir2021":
             num_velocity_bins = 127
             self.encoding_spec = note_sequences.NoteEncodingSpec
@@ -65,7 +76,11 @@ class InferenceModel(object):
         else:
             raise ValueError("unknown model_type: %s" % model_type)
 
-        self.batch_size = batch_size             # reference default 8; bigger batches fill the GPU
+        self.batch_size = batch_size             # the reference's 8 (NB:190): what input_shapes reports
+        if schedule not in ("refill", "batch"):
+            raise ValueError("schedule must be 'refill' or 'batch', got %r" % (schedule,))
+        self.schedule = schedule
+        self.max_slots = max(int(max_slots), batch_size)
         self.outputs_length = 1024
         self.sequence_length = {"inputs": self.inputs_length, "targets": self.outputs_length}
         self.early_exit = early_exit
@@ -84,6 +99,7 @@ class InferenceModel(object):
             **{f: getattr(base, f) for f in base.__dataclass_fields__},
             "vocab_size": vocabularies.num_embeddings(self.vocabulary), "dtype": dtype,
             "input_depth": spectrograms.input_depth(self.spectrogram_config)})
+        self._params = None
         self.model = network.Transformer(self.model_config, input_length=self.inputs_length,
                                          max_decode_length=self.outputs_length, max_batch=self.batch_size)
         self.restore_from_checkpoint(checkpoint_path)
@@ -116,7 +132,26 @@ class InferenceModel(object):
             raise ValueError("unsupported checkpoint %r: pass a t5x checkpoint directory, a flat .npz, a dict, "
                              "or 'random:<seed>'"
                              % (checkpoint_path,))
+        self._params = params                    # kept: the engine is rebuilt with more slots when a job asks for them
         self.model.load_params(params)
+
+    @property
+    def engine_slots(self) -> int:
+        return self.model.max_batch
+
+    def _ensure_slots(self, n_segments: int):
+        """the engine sized to the job: min(n_segments, max_slots) decode slots, in powers of two so that a run of files
+        of similar length rebuilds it once (the attribute `batch_size` does not change)"""
+        want = min(max(n_segments, self.batch_size), self.max_slots)
+        if want <= self.model.max_batch:
+            return
+        slots = self.batch_size
+        while slots < want:
+            slots *= 2
+        slots = min(slots, self.max_slots)
+        self.model = network.Transformer(self.model_config, input_length=self.inputs_length,
+                                         max_decode_length=self.outputs_length, max_batch=slots)
+        self.model.load_params(self._params)
 
     # ------------------------------------------------------------------ model call
     def predict_tokens(self, batch: Dict[str, Any], seed: int = 0) -> np.ndarray:
@@ -125,18 +160,36 @@ class InferenceModel(object):
         import torch
         x = batch["encoder_input_tokens"]
         x = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.asarray(x, np.float32))
+        x = x.cuda()
+        beam1 = self.decoding == "beam1"
+        if self.schedule == "refill" and self.early_exit:
+            # ONE engine call for the whole job: finished rows restart on the job's next segments
+            self._ensure_slots(x.shape[0])
+            self.rows_per_engine_call = [int(x.shape[0])]
+            return self.vocabulary.decode_tf(self.model.transcribe(x, beam1=beam1)).cpu().numpy()
         out = []
-        for s in range(0, x.shape[0], self.batch_size):
-            self.model.encode(x[s:s + self.batch_size].cuda())
-            ids = self.model.decode(early_exit=self.early_exit, beam1=self.decoding == "beam1")
+        step = min(self.batch_size, self.model.max_batch)
+        self.rows_per_engine_call = []
+        for s in range(0, x.shape[0], step):
+            self.model.encode(x[s:s + step])
+            ids = self.model.decode(early_exit=self.early_exit, beam1=beam1)
             out.append(self.vocabulary.decode_tf(ids))
+            self.rows_per_engine_call.append(int(min(step, x.shape[0] - s)))
         return torch.cat(out, 0).cpu().numpy()
 
     def __call__(self, audio):
         """1-d numpy array of 16 kHz samples -> NoteSequence."""
         ds = self.audio_to_dataset(audio)
         examples = self.preprocess(ds)
-        batch = models.convert_features(examples, self.sequence_length)     # pad/trim to [T, 512] / [1024]
+        # the frontend kernel has already written the feature converter's form of every segment -- [T, 512] rows, 0.0
+        # after a short last segment's frames (mt3/models.py:48-98 via models.convert_features) -- and it is still on the
+        # device: no host round trip between preprocess and predict_tokens
+        dev = getattr(self, "_logmel_dev", None)
+        if dev is not None and dev.shape[0] == len(examples):
+            batch = {"encoder_input_tokens": dev}
+        else:
+            batch = models.convert_features(examples, self.sequence_length)     # pad/trim to [T, 512] / [1024]
+        self._logmel_dev = None
         tokens = self.predict_tokens(batch)
         predictions = [self.postprocess(t, ex) for t, ex in zip(tokens, examples)]
         result = metrics_utils.event_predictions_to_ns(predictions, codec=self.codec,
@@ -171,8 +224,9 @@ class InferenceModel(object):
             chunk = frames[s * T:(s + 1) * T]
             audio[s, : chunk.size] = chunk.reshape(-1)
             counts.append(len(chunk))
-        logmel = spectrograms.compute_spectrogram_batch(torch.from_numpy(audio).cuda(), counts,
-                                                        self.spectrogram_config).cpu().numpy()
+        self._logmel_dev = spectrograms.compute_spectrogram_batch(torch.from_numpy(audio).cuda(), counts,
+                                                                  self.spectrogram_config)     # stays on the device
+        logmel = self._logmel_dev.cpu().numpy()             # the examples the reference's preprocess returns are host arrays
         return [{"inputs": logmel[s, : counts[s]], "input_times": times[s * T:(s + 1) * T],
                  "raw_inputs": audio[s, : counts[s] * hop], "targets": np.zeros((0,), np.int32)}
                 for s in range(n_seg)]

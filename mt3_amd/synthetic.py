@@ -64,3 +64,24 @@ def synth_slakh_shaped(n_segments: int, seed: int = 0, seg_frames: int = 256, ho
         files.append((first, count))
         first += count
     return audio, n_frames, files
+
+
+def boost_note_events(params, tie: float = 6.0, pitch: float = 2.5, shift: float = 2.0, eos: float = 2.5,
+                      num_velocity_bins: int = 1):
+    """Random-init weights that DECODE NOTES (smoke / end-to-end tests only; there is no checkpoint offline): the logits
+    columns of the tokens a note needs are scaled -- `tie` (ends the tie section a segment starts in,
+    mt3/note_sequences.py:313-408), the 128 pitches, the first 200 time shifts, EOS -- so that a greedy / beam-1 decode of
+    random weights walks through valid note events instead of the flat soup random logits give (58 notes per 262,144
+    tokens).  Token ids follow vocabularies.build_codec (mt3/vocabularies.py:119-140): id = 3 + event index; shift
+    0..1000 | pitch | velocity | tie | program | drum.  Returns a new dict."""
+    out = dict(params)
+    k = params["decoder/logits_dense/kernel"].copy()
+    first_pitch = 3 + 1001
+    first_vel = first_pitch + 128
+    tie_id = first_vel + num_velocity_bins + 1
+    k[:, 1] *= eos
+    k[:, 3 + 1: 3 + 201] *= shift
+    k[:, first_pitch: first_pitch + 128] *= pitch
+    k[:, tie_id] *= tie
+    out["decoder/logits_dense/kernel"] = k
+    return out
