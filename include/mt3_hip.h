@@ -148,7 +148,12 @@ enum {
    * default they multiply on the bf16 pipes with every f32 operand split EXACTLY into three bf16 terms and the six
    * significant products accumulated in f32 -- at least as exact as the f32 instruction (measured 1.3e-7 against 2.1e-7
    * of sum |p| on a K = 512 dot product) at 2.7x its rate; DESIGN.md section 3 */
-  MT3_OPT_ENCODER_F32_MFMA = 32
+  MT3_OPT_ENCODER_F32_MFMA = 32,
+  /* host side only (no numerics): the engine's worker threads SPIN while they wait for the device (hipStreamSynchronize,
+   * the runtime's own queue back-pressure) as they did up to round 4.  By default a worker keeps at most two windows
+   * of 16 decode steps enqueued ahead of the device and sleeps on a blocking-sync event for the older one, and the polls of
+   * MT3_DECODE_EARLY_EXIT / mt3_engine_transcribe sleep the same way */
+  MT3_OPT_SPIN_WAITS = 64
 };
 
 typedef struct mt3_engine mt3_engine;

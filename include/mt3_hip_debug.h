@@ -32,9 +32,17 @@ int mt3_debug_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int
  * row is replaced by a point mass on EOS: the greedy decode emits EOS there (the row's output has h_lengths[r] tokens,
  * the last one EOS), the beam-1 search finishes `prefix + EOS` with log-probability 0 and closes.  Everything before
  * that step is the model's own arithmetic.  h_lengths [n] host int32, each >= 1 (rows >= n: never forced);
- * NULL switches the schedule off.  Synchronous (a setup call); applies to every later mt3_engine_decode of the engine,
+ * n may exceed max_batch: in mt3_engine_transcribe entry i is the length of SEGMENT i (the call refuses a schedule
+ * shorter than its n_segments).  NULL switches the schedule off.  Synchronous (a setup call); applies to every later mt3_engine_decode of the engine,
  * not to mt3_engine_decode_forced. */
 int mt3_debug_engine_set_eos_schedule(mt3_engine* e, const int32_t* h_lengths, int32_t n);
+
+/* mt3_engine_transcribe with the two schedule parameters the product fixes, for A/B measurements: poll_steps = decode
+ * steps between two refill polls of a row group (0: the product's 32), row_groups = 1 .. 4 (0: the product's rule).  Same
+ * ids whatever the values (tests/test_gpu_transcribe.py). */
+int mt3_debug_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
+                                int32_t poll_steps, int32_t row_groups, int32_t* d_ids, mt3_transcribe_stats* h_stats,
+                                void* stream);
 
 /* Fill the engine's self-attention K/V caches (and, with fp8 caches, their scale arrays) with the byte `pattern`
  * (0xFF = NaN in bf16 / f32 / e4m3; 0x7F.. etc.), and with cross != 0 also the cross-attention K/V buffers

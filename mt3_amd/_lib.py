@@ -20,6 +20,7 @@ DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SINGLE_STREAM, DECODE_A
 (OPT_SINGLE_RESIDUAL_STREAM, OPT_SEPARATE_PROJECTIONS, OPT_ENCODER_SINGLE_RESIDUAL_STREAM,
  OPT_SEPARATE_QKV_PROJECTION, OPT_NO_ROW_GROUPS) = 1, 2, 4, 8, 16              # mt3_engine_config.options
 OPT_ENCODER_F32_MFMA = 32
+OPT_SPIN_WAITS = 64
 # include/mt3_hip_debug.h (measurement / fault injection; not the product ABI)
 DEBUG_SKIP_SELF_ATTN, DEBUG_SKIP_CROSS_ATTN = 1, 2
 (STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8, STATUS_Q_FOLD,
@@ -89,6 +90,8 @@ SIGNATURES = {
     "mt3_engine_decode_forced": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "mt3_engine_status": (C.c_int, [_P, C.c_int32]),
     "mt3_debug_engine_decode": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    "mt3_debug_engine_transcribe": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
+                                              C.POINTER(TranscribeStats), _P]),
     "mt3_debug_engine_poison_caches": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "mt3_debug_engine_set_eos_schedule": (C.c_int, [_P, _P, C.c_int32]),
     "mt3_ids_to_tokens": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),

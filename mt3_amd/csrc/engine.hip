@@ -104,6 +104,8 @@ constexpr int kMaxGroups = 4;
 // staging ring of mt3_engine_transcribe: cross-attention K/V of segments that wait for a slot, kStageChunks chunks of up
 // to kStageChunkCap segments each (one encoder pass per chunk)
 constexpr int kStageChunks = 8, kStageChunkCap = 64, kStageMinBatch = 8;
+constexpr int kStreamPollSteps = 32;    // steps between two refill polls of a row group
+constexpr int kThrottleWindow = 16;     // steps per window of the sleeping enqueue throttle (mt3_engine::wait_ev)
 
 // One persistent host thread per row group (created with the first decode that needs it, joined at destroy): a
 // decode call hands each group's loop to one of them instead of spawning threads per call, and with
@@ -263,6 +265,12 @@ struct mt3_engine {
   // 588 ms whether the masks are disjoint halves, overlap, or cover every CU (one graph-replayed chain: 626 ms).
   hipStream_t part_stream[kMaxGroups] = {};
   hipEvent_t part_begin = nullptr;
+  // Sleeping waits (round 5): a group's worker keeps at most two windows of kThrottleWindow steps enqueued ahead of the
+  // device and waits for the older one on a BLOCKING-SYNC event -- the thread sleeps until the interrupt instead of
+  // spinning in the runtime's queue back-pressure / hipStreamSynchronize (round 4: five cores busy for the length of a
+  // decode).  Index kMaxGroups = the caller's stream (single-stream schedule, the encoder passes of transcribe).
+  hipEvent_t wait_ev[kMaxGroups + 1][2] = {};
+  bool spin_waits = false;       // MT3_OPT_SPIN_WAITS: round 4's behaviour
   int part_failed = 0;           // partitioned decodes that fell back to the single-stream schedule (stream creation failed)
   int last_groups = 1;           // row groups of the most recent decode
 
@@ -909,7 +917,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
   if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM |
-                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_ENCODER_F32_MFMA))
+                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_ENCODER_F32_MFMA | MT3_OPT_SPIN_WAITS))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -920,6 +928,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   }
   e->dense_fp8 = cfg->dense_dtype == MT3_FP8_E4M3;
   e->x6 = cfg->compute_dtype == MT3_F32 && !(cfg->options & MT3_OPT_ENCODER_F32_MFMA);
+  e->spin_waits = (cfg->options & MT3_OPT_SPIN_WAITS) != 0;
   e->esize = cfg->compute_dtype == MT3_BF16 ? 2 : 4;
   e->kv_fp8 = cfg->kv_cache_dtype == MT3_FP8_E4M3;
   e->kv_esize = e->kv_fp8 ? 1 : e->esize;
@@ -939,6 +948,9 @@ void mt3_engine_destroy(mt3_engine* e) {
   for (int g = 0; g < kMaxGroups; ++g)
     if (e->part_stream[g]) (void)hipStreamDestroy(e->part_stream[g]);
   if (e->part_begin) (void)hipEventDestroy(e->part_begin);
+  for (auto& pair : e->wait_ev)
+    for (hipEvent_t ev : pair)
+      if (ev) (void)hipEventDestroy(ev);
   if (e->h_pinned) (void)hipHostFree(e->h_pinned);
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
@@ -1436,6 +1448,43 @@ struct GroupRun {
   bool used_graph;
 };
 
+// ---- sleeping waits (mt3_engine::wait_ev)
+static hipEvent_t wait_event(mt3_engine* e, int slot, int which) {
+  hipEvent_t& ev = e->wait_ev[slot][which];
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    ev = nullptr;
+  }
+  return ev;
+}
+
+// everything enqueued on `s` so far has run; the calling thread sleeps meanwhile (spins with MT3_OPT_SPIN_WAITS or when
+// no event could be created)
+static hipError_t wait_stream(mt3_engine* e, int slot, hipStream_t s) {
+  hipEvent_t ev = e->spin_waits ? nullptr : wait_event(e, slot, 0);
+  if (!ev) return hipStreamSynchronize(s);
+  hipError_t he = hipEventRecord(ev, s);
+  return he == hipSuccess ? hipEventSynchronize(ev) : he;
+}
+
+// after step t has been enqueued: at the end of every window, sleep until the window before the previous one is done
+struct Throttle {
+  mt3_engine* e;
+  int slot;
+  hipStream_t s;
+  int recorded = 0;
+  hipError_t tick(long t) {
+    if (e->spin_waits || t % kThrottleWindow != kThrottleWindow - 1) return hipSuccess;
+    hipEvent_t ev = wait_event(e, slot, 1);
+    if (!ev) return hipSuccess;
+    hipError_t he = hipSuccess;
+    if (recorded) he = hipEventSynchronize(ev);          // the window recorded one window ago: <= 2 windows in flight
+    if (he == hipSuccess) he = hipEventRecord(ev, s);
+    recorded = 1;
+    return he;
+  }
+};
+
 static int compact_group(mt3_engine* e, const GroupRun& r, int cur) {
   const mt3_engine_config& c = e->cfg;
   const size_t r0 = static_cast<size_t>(r.row0);
@@ -1486,6 +1535,8 @@ static int run_group(mt3_engine* e, GroupRun& r) {
   int exec_rows = -1;
   r.ran = 0;
   r.used_graph = r.use_graph;
+  const int wslot = r.s == e->part_stream[r.slot] ? r.slot : kMaxGroups;
+  Throttle throttle{e, wslot, r.s};
   for (int t = 0; t < r.num_steps; ++t) {
     if (r.use_graph && exec_rows != cur) {
       exec = group_graph(e, r.variant, r.batch, r.row0, cur, r.slot);
@@ -1504,10 +1555,11 @@ static int run_group(mt3_engine* e, GroupRun& r) {
     if (whole && r.d_step_logits)
       MT3_HIP_CHECK(hipMemcpyAsync(r.d_step_logits + static_cast<size_t>(t) * r.batch * c.vocab_size, e->logits,
                                    static_cast<size_t>(r.batch) * c.vocab_size * 4, hipMemcpyDeviceToDevice, r.s));
+    if (!r.early) MT3_HIP_CHECK(throttle.tick(t));
     if (r.early && t % 32 == 31) {
       // the poll: how many rows of THIS group are finished (every group stops as soon as its own rows are)
       MT3_HIP_CHECK(hipMemcpyAsync(e->h_pinned + r.slot, e->n_done + r.slot, 4, hipMemcpyDeviceToHost, r.s));
-      MT3_HIP_CHECK(hipStreamSynchronize(r.s));
+      MT3_HIP_CHECK(wait_stream(e, wslot, r.s));
       const int live = r.rows - e->h_pinned[r.slot];
       if (live <= 0) break;
       if (retire) {
@@ -1665,7 +1717,7 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
           // decode when every group stream has a host thread in hipStreamSynchronize, 1166-1170 ms when only the
           // caller's stream (waiting for events of the groups) is synchronised -- a stream nobody waits on retires its
           // commands through the runtime's interrupt path.
-          if (he == hipSuccess) he = hipStreamSynchronize(r.s);
+          if (he == hipSuccess) he = wait_stream(e, g, r.s);
           if (q.rcs[g] == MT3_OK && he != hipSuccess) {
             q.rcs[g] = MT3_ERR_HIP;
             q.errs[g] = hipGetErrorString(he);
@@ -1705,7 +1757,7 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
                                      static_cast<size_t>(batch) * c.vocab_size * 4, hipMemcpyDeviceToDevice, s));
       if (early && (t % 32 == 31)) {
         MT3_HIP_CHECK(hipMemcpyAsync(e->h_pinned, e->n_done, 4, hipMemcpyDeviceToHost, s));
-        MT3_HIP_CHECK(hipStreamSynchronize(s));
+        MT3_HIP_CHECK(wait_stream(e, kMaxGroups, s));
         if (e->h_pinned[0] >= batch) break;
       }
     }
@@ -1904,8 +1956,7 @@ static int refill_group(mt3_engine* e, const GroupRun& r, int cur, const FeedRan
 
 // One row group's loop of mt3_engine_transcribe: as run_group, but a finished slot restarts on the next staged segment
 // at the poll, and the loop ends when the queue is empty for good and every slot of the group has finished.
-static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out, long max_steps) {
-  const int kPoll = 32;
+static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out, long max_steps, int kPoll) {
   int cur = r.rows;
   hipGraphExec_t exec = nullptr;
   int exec_rows = -1, flushed_at = -1;
@@ -1928,7 +1979,7 @@ static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out,
     if (t % kPoll != kPoll - 1) continue;
     // ---- the poll
     MT3_HIP_CHECK(hipMemcpyAsync(e->h_pinned + r.slot, e->n_done + r.slot, 4, hipMemcpyDeviceToHost, r.s));
-    MT3_HIP_CHECK(hipStreamSynchronize(r.s));
+    MT3_HIP_CHECK(wait_stream(e, r.slot, r.s));
     feed_release(f, held);                       // the copies out of what was taken at the previous poll have run
     held.clear();
     int n_fin = e->h_pinned[r.slot];             // finished slots among the group's r.rows (dropped ones included)
@@ -1964,7 +2015,7 @@ static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out,
       ++e->compactions_now;
     }
   }
-  MT3_HIP_CHECK(hipStreamSynchronize(r.s));
+  MT3_HIP_CHECK(wait_stream(e, r.slot, r.s));
   feed_release(f, held);
   return MT3_OK;
 }
@@ -2001,7 +2052,7 @@ static int produce_chunks(mt3_engine* e, Feed& f, const float* d_inputs, hipStre
     dst.kv = kv.data();
     dst.scale = e->kv_fp8 ? sc.data() : nullptr;
     rc = encode_impl(e, d_inputs + static_cast<size_t>(first - pad) * seg_floats, pad + n, nullptr, dst, s);
-    if (rc == MT3_OK && hipStreamSynchronize(s) != hipSuccess) rc = mt3::fail(MT3_ERR_HIP, "mt3_engine_transcribe: encoder pass failed");
+    if (rc == MT3_OK && wait_stream(e, kMaxGroups, s) != hipSuccess) rc = mt3::fail(MT3_ERR_HIP, "mt3_engine_transcribe: encoder pass failed");
     if (rc != MT3_OK) break;
     {
       std::lock_guard<std::mutex> lk(f.mu);
@@ -2024,8 +2075,9 @@ static int produce_chunks(mt3_engine* e, Feed& f, const float* d_inputs, hipStre
   return rc;
 }
 
-int mt3_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
-                          int32_t* d_ids, mt3_transcribe_stats* h_stats, void* stream) {
+// poll_steps / groups_override: 0 = the product's choice (mt3_debug_engine_transcribe sets them for A/B runs)
+static int transcribe_impl(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
+                           int32_t* d_ids, mt3_transcribe_stats* h_stats, void* stream, int poll_steps, int groups_override) {
   if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: engine not finalized");
   if (e->pending.active)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: a decode is in flight (MT3_DECODE_ASYNC): call mt3_engine_decode_wait first");
@@ -2042,6 +2094,9 @@ int mt3_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segmen
   const bool beam1 = (flags & MT3_DECODE_BEAM1) != 0;
   if (n_segments > S) MT3_TRY(ensure_stage(e));
   int groups = ((flags & MT3_DECODE_SINGLE_STREAM) || (c.options & MT3_OPT_NO_ROW_GROUPS)) ? 1 : stream_row_groups_for(c, S);
+  if (groups_override > 0) groups = groups_override;
+  while (groups > 1 && S / groups < 16) --groups;
+  const int poll = poll_steps > 0 ? poll_steps : kStreamPollSteps;
   if (ensure_group_streams(e, groups) != MT3_OK)
     return mt3::fail(MT3_ERR_HIP, "mt3_engine_transcribe: could not create the row groups' streams");
 
@@ -2085,7 +2140,7 @@ int mt3_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segmen
   const long max_steps = static_cast<long>(num_steps + 64) * (static_cast<long>(n_segments) / S + 2);
   bool posted_all = true;
   for (int g = 0; g < groups && posted_all; ++g) {
-    auto body = [e, g, groups, S, variant, num_steps, use_graph, &feed, d_ids, max_steps]() {
+    auto body = [e, g, groups, S, variant, num_steps, use_graph, &feed, d_ids, max_steps, poll]() {
       PendingDecode& q = e->pending;
       GroupRun r{};
       chain_rows(S, groups, g, &r.row0, &r.rows);
@@ -2098,9 +2153,9 @@ int mt3_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segmen
       r.s = e->part_stream[g];
       hipError_t he = hipStreamWaitEvent(r.s, e->part_begin, 0);
       if (he == hipSuccess) {
-        q.rcs[g] = run_group_stream(e, r, feed, d_ids, max_steps);
+        q.rcs[g] = run_group_stream(e, r, feed, d_ids, max_steps, poll);
         if (q.rcs[g] != MT3_OK) q.errs[g] = mt3_last_error();
-        he = hipStreamSynchronize(r.s);
+        he = wait_stream(e, g, r.s);
       }
       if (q.rcs[g] == MT3_OK && he != hipSuccess) {
         q.rcs[g] = MT3_ERR_HIP;
@@ -2147,6 +2202,19 @@ int mt3_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segmen
   if (h_stats) *h_stats = st;
   if (rc != MT3_OK && !producer_err.empty()) return mt3::fail(rc, producer_err);
   return rc;
+}
+
+int mt3_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
+                          int32_t* d_ids, mt3_transcribe_stats* h_stats, void* stream) {
+  return transcribe_impl(e, d_inputs, n_segments, num_steps, flags, d_ids, h_stats, stream, 0, 0);
+}
+
+int mt3_debug_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
+                                int32_t poll_steps, int32_t row_groups, int32_t* d_ids, mt3_transcribe_stats* h_stats,
+                                void* stream) {
+  if (poll_steps < 0 || poll_steps > 1024 || row_groups < 0 || row_groups > kMaxGroups)
+    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_transcribe: poll_steps in [0, 1024], row_groups in [0, 4]");
+  return transcribe_impl(e, d_inputs, n_segments, num_steps, flags, d_ids, h_stats, stream, poll_steps, row_groups);
 }
 
 int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t* d_ids,

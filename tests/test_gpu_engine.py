@@ -290,7 +290,7 @@ def test_inference_edge_cases():
     1-frame segment), more segments than `batch_size` (several engine batches == one big batch, row for row),
     and the C ABI's error path surfacing as an exception instead of a silent fallback."""
     from mt3_amd import _lib, inference
-    small = dict(batch_size=2, early_exit=True, decoding="greedy")
+    small = dict(batch_size=2, early_exit=True, decoding="greedy", schedule="batch")     # the reference's loop (NB:295-301)
     m = inference.InferenceModel("random:0", "mt3", **small)
     ns = m(np.zeros(0, np.float32))
     ex = m.preprocess(m.audio_to_dataset(np.zeros(0, np.float32)))
@@ -303,8 +303,10 @@ def test_inference_edge_cases():
     for i, e in enumerate(ex):
         feats[i, : e["inputs"].shape[0]] = e["inputs"]
     split = m.predict_tokens({"encoder_input_tokens": feats})               # batches of 2 + 1
+    assert m.rows_per_engine_call == [2, 1]
     big = inference.InferenceModel("random:0", "mt3", batch_size=4, early_exit=True, decoding="greedy")
-    whole = big.predict_tokens({"encoder_input_tokens": feats})
+    whole = big.predict_tokens({"encoder_input_tokens": feats})             # one refilled engine call (the default)
+    assert big.rows_per_engine_call == [3] and big.batch_size == 4
     assert np.array_equal(split, whole)
     # error path: decode before any encode, bad shapes
     eng = network.Transformer(network.T5Config(), input_length=256, max_decode_length=1024, max_batch=2)

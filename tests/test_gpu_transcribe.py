@@ -70,13 +70,14 @@ def test_refilled_slots_decode_every_segment_bit_identically(dtype, kv, B, group
             r = ref.cpu().numpy()
             assert (r[:, :S] == 1).any(1).mean() > 0.8
             eng.debug_set_eos_schedule(lens)                 # one schedule entry per SEGMENT
-            for kw in (dict(), dict(use_graph=False), dict(single_stream=True)):
+            # (the last one: mt3_debug_engine_transcribe -- another poll interval, another number of row groups)
+            for kw in (dict(), dict(use_graph=False), dict(single_stream=True), dict(debug_poll_steps=8, debug_row_groups=3)):
                 got = eng.transcribe(lm, num_steps=S, beam1=beam1, **kw)
                 st = eng.transcribe_stats
                 bad = (got != ref).any(1).nonzero().flatten().tolist()
                 assert not bad, (dtype, kv, beam1, kw, bad[:8], st)
                 assert st["slots"] == B and st["refills"] == N - B and st["encoder_chunks"] >= 1, st
-                assert st["groups"] == (1 if kw.get("single_stream") else groups), st
+                assert st["groups"] == (1 if kw.get("single_stream") else kw.get("debug_row_groups") or groups), st
                 assert st["used_graph"] == (0 if kw.get("use_graph") is False else 1), st
                 assert eng.status(_lib.STATUS_GRAPH_FALLBACKS) == 0
             # far fewer steps than one batch-synchronous call after the other would take

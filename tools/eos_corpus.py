@@ -35,6 +35,11 @@ def main():
     ap.add_argument("--reps", type=int, default=1)
     ap.add_argument("--single-stream", action="store_true")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--spin-waits", action="store_true", help="MT3_OPT_SPIN_WAITS: the workers spin as in round 4")
+    ap.add_argument("--decode-probe", action="store_true",
+                    help="also time one canonical full-length decode of `--slots` rows (ms, host CPU seconds)")
+    ap.add_argument("--polls", default="0", help="refill mode: comma list of poll intervals to try (0 = the product's)")
+    ap.add_argument("--groups", default="0", help="refill mode: comma list of row-group counts to try (0 = the product's)")
     args = ap.parse_args()
 
     import numpy as np
@@ -43,7 +48,8 @@ def main():
 
     N, S, L = args.segments, args.slots, 1024
     cfg = network.T5Config(dtype=args.dtype, kv_dtype=args.kv_dtype)
-    eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=S)
+    eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=S,
+                              options=_lib.OPT_SPIN_WAITS if args.spin_waits else 0)
     eng.load_params(network.init_random_params(cfg, seed=0))
     vocab = vocabularies.vocabulary_from_codec(vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1)))
     audio = torch.cat([synthetic.synth_audio(min(1024, N - s), seed=1000 + s) for s in range(0, N, 1024)])
@@ -69,10 +75,13 @@ def main():
             host = torch.cat(toks).cpu().numpy()
         return host, {"decode_steps_run": steps, "calls": -(-N // S)}
 
+    variant = {"poll": 0, "groups": 0}
+
     def run_refill():
         with torch.cuda.stream(stream):
             eng.debug_set_eos_schedule(lens)
-            ids = eng.transcribe(logmel_all(), num_steps=args.decode_steps, single_stream=args.single_stream)
+            ids = eng.transcribe(logmel_all(), num_steps=args.decode_steps, single_stream=args.single_stream,
+                                 debug_poll_steps=variant["poll"], debug_row_groups=variant["groups"])
             host = vocab.decode_tf(ids).cpu().numpy()
         return host, dict(eng.transcribe_stats)
 
@@ -99,9 +108,27 @@ def main():
     ll = np.minimum(lens, args.decode_steps).astype(np.float64)
     live_bytes = nl * float((kv1 * (ll * (ll + 1) / 2) + (kv1 + qo) * ll).sum() + ((kv1 * 256 + qo) * ll).sum())
     out = {"segments": N, "slots": S, "dtype": args.dtype + ("+fp8kv" if args.kv_dtype else ""),
+           "spin_waits": args.spin_waits,
            "lengths": {"mean": float(ll.mean()), "max": int(ll.max())}, "live_row_kv_bytes": live_bytes,
            "single_stream": args.single_stream}
     hosts = {}
+    if args.decode_probe:
+        with torch.cuda.stream(stream):
+            eng.encode(spectrograms.compute_spectrogram_batch(audio[:S], None))
+            eng.decode(num_steps=8)
+        torch.cuda.synchronize()
+        probe = {}
+        for key, kw in (("row_groups", {}), ("single_stream", {"single_stream": True})):
+            r0 = resource.getrusage(resource.RUSAGE_SELF)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(stream):
+                eng.decode(num_steps=args.decode_steps, **kw)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            r1 = resource.getrusage(resource.RUSAGE_SELF)
+            probe[key] = {"decode_ms": dt * 1e3, "host_cpu_s": (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime),
+                          "groups": eng.status(_lib.STATUS_LAST_DECODE_GROUPS)}
+        out["full_length_decode"] = probe
     try:
         for mode, fn in (("batch", run_batch), ("refill", run_refill)):
             if args.mode not in ("both", mode):
@@ -115,6 +142,19 @@ def main():
                          "graph_fallbacks": eng.status(_lib.STATUS_GRAPH_FALLBACKS), **info}
     finally:
         eng.debug_set_eos_schedule(None)
+    ab = [(int(p), int(g)) for p in args.polls.split(",") for g in args.groups.split(",") if (int(p), int(g)) != (0, 0)]
+    if ab and args.mode in ("both", "refill"):
+        out["variants"] = []
+        try:
+            for p, g in ab:
+                variant.update(poll=p, groups=g)
+                dt, cpu, host, info = timed(run_refill)
+                out["variants"].append({"poll_steps": p, "row_groups": g, "audio_s_per_s": N * SEG_SECONDS / dt, "seconds": dt,
+                                        "host_cpu_s": cpu, "steps_run": info["steps_run"], "polls": info["polls"],
+                                        "starved_polls": info["starved_polls"],
+                                        "same_tokens": bool(np.array_equal(host, hosts.get("refill", host)))})
+        finally:
+            eng.debug_set_eos_schedule(None)
     if "batch" in out and "refill" in out:
         out["speedup"] = out["refill"]["audio_s_per_s"] / out["batch"]["audio_s_per_s"]
         same = bool(np.array_equal(hosts["batch"], hosts["refill"]))
