@@ -1177,9 +1177,12 @@ static int encode_impl(mt3_engine* e, const float* d_inputs, int32_t batch, floa
   // 4 GB -- 4096 segments at the MT3 shape -- takes the f32-instruction path below instead of failing)
   const int widest = std::max(std::max(c.input_depth, emb), std::max(hd, c.mlp_dim));
   const bool x6_fits = static_cast<size_t>(M) * widest * 4 < (1ull << 32);
-  if (e->x6 && !small && x6_fits) {
-    // f32 engine, encoder-sized launches: every dense layer on the bf16 pipes with three planes per operand (gemm.hip,
-    // gemm_x6_kernel: at least as exact as the f32 matrix instruction, 2.7x its rate); attention and norms as before
+  if (e->x6 && x6_fits) {
+    // f32 engine: every dense layer and the attention on the bf16 pipes with three planes per operand (gemm.hip,
+    // gemm_x6_kernel: at least as exact as the f32 matrix instruction, 2.7x its rate).  Since round 5 at EVERY batch size
+    // (up to round 4 passes of fewer than 2048 rows took the f32 instruction's decode-sized tiles, so a segment's f32
+    // encoder output depended on the batch it sat in by ~1e-7 -- ADVICE r4): a file's last short batch, a refill chunk of
+    // mt3_engine_transcribe and a 1250-segment corpus call now give a segment the same bits
     auto x6 = [&](const void* A, void* (&W)[3], void* out, int N, int K, int ldo, bool norm, int epi, int seq) {
       mt3k::GemmArgs g = gemm_args(A, W[0], out, M, N, K, ldo);
       g.aux = e->pos_table;
