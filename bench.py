@@ -110,11 +110,11 @@ def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int, small_se
     def full_path(n, candidates):
         with torch.no_grad():
             torch.set_num_threads(min(nproc, 32))
-            enc_probe = orc.encode(np.stack([OF.compute_logmel(a, np.float32) for a in audio[:n]]))
+            enc_probe = orc.encode(np.stack([OF.compute_logmel(a, np.float32, tables="tf32") for a in audio[:n]]))
             threads = pick_threads(enc_probe, candidates)
             torch.set_num_threads(threads)
             t0 = time.perf_counter()
-            lm = np.stack([OF.compute_logmel(a, np.float32) for a in audio[:n]])
+            lm = np.stack([OF.compute_logmel(a, np.float32, tables="tf32") for a in audio[:n]])
             enc = orc.encode(lm)
             ids, logits = orc.greedy_decode(enc, decode_steps, return_logits=True)
             toks = vocab.decode_tf(ids)
@@ -182,7 +182,7 @@ def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int, small_se
         nb = small_segments
         with torch.no_grad():
             torch.set_num_threads(min(nproc, 32))
-            enc_nb = orc.encode(np.stack([OF.compute_logmel(a, np.float32) for a in audio[:nb]]))
+            enc_nb = orc.encode(np.stack([OF.compute_logmel(a, np.float32, tables="tf32") for a in audio[:nb]]))
             th_nb = pick_threads(enc_nb, (32, 64, 128))
             torch.set_num_threads(th_nb)
             t0 = time.perf_counter()
@@ -204,7 +204,7 @@ def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int, small_se
         if time.perf_counter() - t_begin > 150.0:      # a slow (shared) host: keep the whole CPU leg bounded
             enc_segments = max(16, enc_segments // 2)
         t1 = time.perf_counter()
-        lm2 = np.stack([OF.compute_logmel(a, np.float32) for a in audio[:enc_segments]])
+        lm2 = np.stack([OF.compute_logmel(a, np.float32, tables="tf32") for a in audio[:enc_segments]])
         orc.encode(lm2)
         dt2 = time.perf_counter() - t1
     out["encoder_only"] = {"value": enc_segments * SEG_SECONDS / dt2, "unit": "audio-s/s",

@@ -66,6 +66,12 @@ typedef struct mt3_frontend_config {
   int32_t fft_size;      /* 2048   spectrograms.py:28 */
   float lo_hz;           /* 20.0   spectrograms.py:29 */
   float hi_hz;           /* 7600.0 spectral_ops.py:79 */
+  int32_t table_dtype;   /* arithmetic the Hann window and the mel matrix are BUILT in.  0 (default): float32 in
+                            TensorFlow's op order -- tf.signal.stft's window and linear_to_mel_weight_matrix default to
+                            dtype=float32 and the reference passes none (spectral_ops.py:42-47,69-71), so this is the side
+                            of the <= 2.8e-3 log-domain gap between the two evaluations the reference most likely sits on
+                            [TF's op order restated from memory: still unpinned against TensorFlow itself];
+                            1: float64, rounded once (rounds 1-4) */
 } mt3_frontend_config;
 
 typedef struct mt3_frontend mt3_frontend;

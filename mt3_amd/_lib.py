@@ -39,7 +39,7 @@ class Mt3Error(RuntimeError):
 
 class FrontendConfig(C.Structure):
     _fields_ = [("sample_rate", C.c_int32), ("hop_width", C.c_int32), ("num_mel_bins", C.c_int32),
-                ("fft_size", C.c_int32), ("lo_hz", C.c_float), ("hi_hz", C.c_float)]
+                ("fft_size", C.c_int32), ("lo_hz", C.c_float), ("hi_hz", C.c_float), ("table_dtype", C.c_int32)]
 
 
 class EngineConfig(C.Structure):

@@ -198,7 +198,12 @@ int mt3_frontend_create(const mt3_frontend_config* cfg, mt3_frontend** out) {
   mt3_frontend* fe = new (std::nothrow) mt3_frontend();
   if (!fe) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
   fe->cfg = *cfg;
-  fe->host = mt3fe::build_tables(cfg->sample_rate, cfg->fft_size, cfg->num_mel_bins, cfg->lo_hz, cfg->hi_hz);
+  if (cfg->table_dtype != 0 && cfg->table_dtype != 1) {
+    delete fe;
+    return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_create: table_dtype must be 0 (float32, as TensorFlow builds them) or 1 (float64)");
+  }
+  fe->host = mt3fe::build_tables(cfg->sample_rate, cfg->fft_size, cfg->num_mel_bins, cfg->lo_hz, cfg->hi_hz,
+                                 cfg->table_dtype == 0);
   if (static_cast<int>(fe->host.w.size()) > kMaxBandWeights) {
     delete fe;
     return mt3::fail(MT3_ERR_INVALID, "mt3_frontend_create: mel band table too large for the kernel's LDS budget");

@@ -35,13 +35,22 @@ class SpectrogramConfig:
 
 
 _frontends = {}
+# Arithmetic the frontend's Hann window and mel matrix are built in (mt3_frontend_config.table_dtype): "float32" = as
+# TensorFlow builds them (tf.signal's dtype default, which the reference does not override: spectral_ops.py:42-47,69-71);
+# "float64" = rounds 1-4's evaluation.  A module-level setting like the reference's module constants, read when a
+# frontend is first created for a configuration.
+TABLE_DTYPE = "float32"
 
 
-def _frontend(cfg: SpectrogramConfig):
-    key = (cfg.sample_rate, cfg.hop_width, cfg.num_mel_bins)
+def _frontend(cfg: SpectrogramConfig, table_dtype: str = None):
+    table_dtype = table_dtype or TABLE_DTYPE
+    if table_dtype not in ("float32", "float64"):
+        raise ValueError("table_dtype must be 'float32' or 'float64'")
+    key = (cfg.sample_rate, cfg.hop_width, cfg.num_mel_bins, table_dtype)
     if key not in _frontends:
         lib = _lib.load()
-        fc = _lib.FrontendConfig(cfg.sample_rate, cfg.hop_width, cfg.num_mel_bins, FFT_SIZE, MEL_LO_HZ, MEL_HI_HZ)
+        fc = _lib.FrontendConfig(cfg.sample_rate, cfg.hop_width, cfg.num_mel_bins, FFT_SIZE, MEL_LO_HZ, MEL_HI_HZ,
+                                 0 if table_dtype == "float32" else 1)
         h = C.c_void_p()
         _lib.check(lib.mt3_frontend_create(C.byref(fc), C.byref(h)))
         _frontends[key] = h
@@ -66,15 +75,17 @@ def input_depth(spectrogram_config: SpectrogramConfig):
     return spectrogram_config.num_mel_bins
 
 
-def mel_matrix(spectrogram_config: SpectrogramConfig = SpectrogramConfig()) -> np.ndarray:
+def mel_matrix(spectrogram_config: SpectrogramConfig = SpectrogramConfig(), table_dtype: str = None) -> np.ndarray:
     """The dense [1025, 512] f32 mel matrix the kernel's band tables were built from."""
     out = np.zeros((FFT_SIZE // 2 + 1, spectrogram_config.num_mel_bins), np.float32)
     nnz = C.c_int64()
-    _lib.check(_lib.load().mt3_frontend_mel_matrix(_frontend(spectrogram_config), out.ctypes.data, C.byref(nnz)))
+    _lib.check(_lib.load().mt3_frontend_mel_matrix(_frontend(spectrogram_config, table_dtype), out.ctypes.data,
+                                                   C.byref(nnz)))
     return out
 
 
-def compute_spectrogram_batch(audio, n_frames, spectrogram_config: SpectrogramConfig = SpectrogramConfig()):
+def compute_spectrogram_batch(audio, n_frames, spectrogram_config: SpectrogramConfig = SpectrogramConfig(),
+                              table_dtype: str = None):
     """Batched segments.  audio: CUDA f32 [S, F*hop]; n_frames: sequence of S ints (true frame count of
     each segment, <= F) or None.  Returns CUDA f32 [S, F, mel] with rows >= n_frames[s] equal to 0.0
     (the zero padding the reference's feature converter applies after the log)."""
@@ -91,7 +102,7 @@ def compute_spectrogram_batch(audio, n_frames, spectrogram_config: SpectrogramCo
         nf = np.ascontiguousarray(np.asarray(n_frames, np.int32))
         if nf.shape != (S,):
             raise ValueError("n_frames must have one entry per segment")
-    _lib.check(_lib.load().mt3_frontend_logmel(_frontend(spectrogram_config), a.data_ptr(), S, F,
+    _lib.check(_lib.load().mt3_frontend_logmel(_frontend(spectrogram_config, table_dtype), a.data_ptr(), S, F,
                                                nf.ctypes.data if nf is not None else None, out.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream))
     return out

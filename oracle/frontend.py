@@ -67,16 +67,23 @@ def frame_signal(x: np.ndarray, frame_length=FFT_SIZE, frame_step=HOP_WIDTH) -> 
     return padded[idx] if num else np.zeros((0, frame_length), x.dtype)
 
 
-def compute_logmel(samples: np.ndarray, dtype=np.float64) -> np.ndarray:
+def compute_logmel(samples: np.ndarray, dtype=np.float64, tables: str = "float64") -> np.ndarray:
     """spectral_ops.compute_logmel on ONE segment's flattened samples -> [frames, 512].
 
     dtype=float64: the "true" value; dtype=float32: every stage rounded to f32 the
     way a float32 TF graph would (FFT itself evaluated in f64 then rounded, i.e. a
-    best-case f32 FFT)."""
+    best-case f32 FFT).  tables: how the two constant tables were BUILT -- "float64"
+    (the mathematical definition, rounded once) or "tf32" (float32 in TensorFlow's op
+    order, hann_periodic_tf32 / mel_weight_matrix_tf32 below: the product's default since
+    round 5, mt3_frontend_config.table_dtype) -- independently of `dtype`, the
+    arithmetic they are USED in."""
+    if tables not in ("float64", "tf32"):
+        raise ValueError("tables must be 'float64' or 'tf32'")
     x = np.asarray(samples, dtype)
-    frames = frame_signal(x) * hann_periodic().astype(dtype)[None, :]
+    hann, melw = (hann_periodic_tf32(), mel_weight_matrix_tf32()) if tables == "tf32" else (hann_periodic(), mel_weight_matrix())
+    frames = frame_signal(x) * hann.astype(dtype)[None, :]
     mag = np.abs(np.fft.rfft(frames.astype(np.float64), axis=-1)).astype(dtype)
-    mel = mag @ mel_weight_matrix().astype(dtype)
+    mel = mag @ melw.astype(dtype)
     safe = np.where(mel <= 0.0, dtype(LOG_EPS), mel)
     return np.log(safe).astype(dtype)
 
@@ -91,6 +98,12 @@ def compute_logmel(samples: np.ndarray, dtype=np.float64) -> np.ndarray:
 #   linspace(start, stop, n)   = concat(start, start + delta * [1 .. n-2], stop), delta = (stop - start) / (n - 1), all f32
 #   _hertz_to_mel(f)           = 1127.0 * log(1.0 + f / 700.0)                   (plain log, not log1p; f32)
 #   hann_window(N, periodic)   = 0.5 - 0.5 * cos(2 pi * k / N)                   (2 pi as an f32 constant, f32 cos)
+# Round 5: `log` and `cos` are taken CORRECTLY ROUNDED to float32 (evaluated in float64, rounded once).  No float32 log at
+# hand is: numpy's differs from the correctly rounded value at 10 % of its arguments, glibc's and Eigen's (TensorFlow's) at
+# others, and one ulp of a mel value moves a triangle weight by up to 4.5e-5 -- three float32 evaluations of this formula
+# land up to 9.1e-5 apart in a weight, MORE than the 6.8e-5 between any of them and the float64 table.  TensorFlow's table
+# is one more point of that cloud; the correctly rounded log is its centre and is reproducible anywhere, so the product's
+# default tables (mt3_amd/csrc/frontend_tables.h, the same rule in C++) equal these bit for bit.
 #   mel = tensordot(|rfft|, W) , log                                              (f32; the FFT itself in f32: scipy.fft keeps
 #                                                                                 single precision, numpy.fft would not)
 def _f32(x):
@@ -105,7 +118,8 @@ def linspace_tf32(start, stop, n) -> np.ndarray:
 
 
 def hertz_to_mel_tf32(f):
-    return (np.float32(1127.0) * np.log(np.float32(1.0) + _f32(f) / np.float32(700.0))).astype(np.float32)
+    arg = (np.float32(1.0) + _f32(f) / np.float32(700.0)).astype(np.float32)
+    return (np.float32(1127.0) * np.log(arg.astype(np.float64)).astype(np.float32)).astype(np.float32)
 
 
 def mel_weight_matrix_tf32(num_mel_bins=NUM_MEL_BINS, num_spectrogram_bins=FFT_SIZE // 2 + 1,
@@ -124,7 +138,7 @@ def mel_weight_matrix_tf32(num_mel_bins=NUM_MEL_BINS, num_spectrogram_bins=FFT_S
 def hann_periodic_tf32(n=FFT_SIZE) -> np.ndarray:
     count = np.arange(n, dtype=np.float32)
     arg = (np.float32(2.0 * np.pi) * count / np.float32(n)).astype(np.float32)      # periodic, even n: divisor n
-    return (np.float32(0.5) - np.float32(0.5) * np.cos(arg)).astype(np.float32)
+    return (np.float32(0.5) - np.float32(0.5) * np.cos(arg.astype(np.float64)).astype(np.float32)).astype(np.float32)
 
 
 def compute_logmel_tf32(samples: np.ndarray) -> np.ndarray:

@@ -28,11 +28,18 @@ static float padded_bin(int i, const int* k0, const float* wp, int j, const floa
   }
 }
 
-extern "C" int emul_logmel(const float* audio, int n_frames, int frames_per_segment, float* out) {
-  static const mt3fe::HostTables T = mt3fe::build_tables(16000, 2048, 512, 20.0, 7600.0);
+// tf32: the tables as mt3_frontend_config.table_dtype = 0 builds them (float32 in TensorFlow's op order); else float64
+static const mt3fe::HostTables& tables(int tf32) {
+  static const mt3fe::HostTables T64 = mt3fe::build_tables(16000, 2048, 512, 20.0, 7600.0, false);
+  static const mt3fe::HostTables T32 = mt3fe::build_tables(16000, 2048, 512, 20.0, 7600.0, true);
+  return tf32 ? T32 : T64;
+}
+
+extern "C" int emul_logmel(const float* audio, int n_frames, int frames_per_segment, float* out, int tf32) {
+  const mt3fe::HostTables& T = tables(tf32);
   const int hop = 128, G = 16, tile = G * hop + 1920;
   const int valid = n_frames * hop;
-  static const std::vector<float> WP = mt3fe::build_padded_weights(T);     // the kernel's group-padded table
+  const std::vector<float> WP = mt3fe::build_padded_weights(T);     // the kernel's group-padded table
   if (!mt3fe::bands_fit(T)) return 1;
   std::vector<mt3fe::LaneConst> lc(64);
   for (int l = 0; l < 64; ++l)
@@ -70,8 +77,14 @@ extern "C" int emul_logmel(const float* audio, int n_frames, int frames_per_segm
   return 0;
 }
 
-extern "C" int emul_mel_dense(float* out) {
-  static const mt3fe::HostTables T = mt3fe::build_tables(16000, 2048, 512, 20.0, 7600.0);
+extern "C" int emul_mel_dense(float* out, int tf32) {
+  const mt3fe::HostTables& T = tables(tf32);
   std::memcpy(out, T.mel_dense.data(), T.mel_dense.size() * sizeof(float));
   return static_cast<int>(T.nnz);
+}
+
+extern "C" int emul_hann(float* out, int tf32) {
+  const mt3fe::HostTables& T = tables(tf32);
+  std::memcpy(out, T.hann.data(), T.hann.size() * sizeof(float));
+  return static_cast<int>(T.hann.size());
 }

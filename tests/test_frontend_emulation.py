@@ -23,28 +23,44 @@ def emul(tmp_path_factory):
     return ctypes.CDLL(out)
 
 
-def _run(lib, x, n):
+TABLES = ("float64", "tf32")          # mt3_frontend_config.table_dtype 1 / 0 (the default)
+
+
+def _run(lib, x, n, tables="float64"):
     x = np.ascontiguousarray(x, np.float32)
     out = np.full((256, 512), np.nan, np.float32)
-    lib.emul_logmel(x.ctypes.data_as(ctypes.c_void_p), n, 256, out.ctypes.data_as(ctypes.c_void_p))
+    lib.emul_logmel(x.ctypes.data_as(ctypes.c_void_p), n, 256, out.ctypes.data_as(ctypes.c_void_p), int(tables == "tf32"))
     return out
 
 
 def test_tables_match_oracle(emul):
-    md = np.zeros((1025, 512), np.float32)
-    nnz = emul.emul_mel_dense(md.ctypes.data_as(ctypes.c_void_p))
-    assert nnz == 1934
-    np.testing.assert_array_equal(md, F.mel_weight_matrix().astype(np.float32))
+    """both constructions of the window and the mel matrix equal the oracle's BIT FOR BIT: the float64 one (rounded once)
+    and the float32-in-TensorFlow's-op-order one (every operation one IEEE float32 operation, log / cos correctly rounded:
+    no libm can differ)"""
+    for tf32, mel_ref, hann_ref in ((0, F.mel_weight_matrix().astype(np.float32), F.hann_periodic().astype(np.float32)),
+                                    (1, F.mel_weight_matrix_tf32(), F.hann_periodic_tf32())):
+        md = np.zeros((1025, 512), np.float32)
+        nnz = emul.emul_mel_dense(md.ctypes.data_as(ctypes.c_void_p), tf32)
+        assert nnz == 1934
+        np.testing.assert_array_equal(md, mel_ref)
+        hw = np.zeros(2048, np.float32)
+        assert emul.emul_hann(hw.ctypes.data_as(ctypes.c_void_p), tf32) == 2048
+        np.testing.assert_array_equal(hw, hann_ref)
+    # how far the two constructions are apart, and how far float32 evaluations of the SAME formula are from each other
+    a, b = F.mel_weight_matrix_tf32(), F.mel_weight_matrix().astype(np.float32)
+    assert ((a != 0) == (b != 0)).all() and 3e-5 < np.abs(a - b).max() < 1e-4
 
 
+@pytest.mark.parametrize("tables", TABLES)
 @pytest.mark.parametrize("n", [256, 100, 17, 1])
-def test_lane_program_matches_oracle(emul, n):
+def test_lane_program_matches_oracle(emul, n, tables):
     audio = F.synth_audio(2, seed=n)
     for x in audio:
-        got = _run(emul, x, n)
-        ref = F.compute_logmel(x[: n * 128], np.float64)
+        got = _run(emul, x, n, tables)
+        ref = F.compute_logmel(x[: n * 128], np.float64, tables=tables)
         assert np.all(got[n:] == 0.0)
-        frames = F.frame_signal(x[: n * 128].astype(np.float64)) * F.hann_periodic()
+        hann = F.hann_periodic_tf32().astype(np.float64) if tables == "tf32" else F.hann_periodic()
+        frames = F.frame_signal(x[: n * 128].astype(np.float64)) * hann
         peak = np.abs(np.fft.rfft(frames, axis=-1)).max(1)
         lin = np.abs(np.exp(got[:n].astype(np.float64)) - np.exp(ref))
         assert np.all(lin <= 4e-6 * peak[:, None] + 1.1e-10)

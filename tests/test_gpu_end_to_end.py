@@ -25,7 +25,7 @@ def _oracle_notes(params, wav, decoding, T=256, hop=128):
     segs = [frames[i:i + T] for i in range(0, len(frames), T)]
     lm = np.zeros((len(segs), T, 512), np.float32)
     for i, sg in enumerate(segs):
-        lm[i, : len(sg)] = OF.compute_logmel(sg.reshape(-1), np.float32)[: len(sg)]
+        lm[i, : len(sg)] = OF.compute_logmel(sg.reshape(-1), np.float32, tables="tf32")[: len(sg)]
     orc = ON.Oracle(params, ON.T5Config(**CFG))
     with torch.no_grad():
         enc = orc.encode(lm)

@@ -451,23 +451,33 @@ def test_ids_to_tokens_bit_exact():
 
 
 # ----------------------------------------------------------------------- frontend
-def test_frontend_vs_oracle():
+@pytest.mark.parametrize("tables", ["tf32", "float64"])
+def test_frontend_vs_oracle(tables):
+    """tables: how the Hann window and the mel matrix are BUILT (mt3_frontend_config.table_dtype): "tf32" = float32 in
+    TensorFlow's op order, the product's default since round 5 (tf.signal's dtype default, which the reference does not
+    override: mt3/spectral_ops.py:42-47,69-71); "float64" = rounds 1-4.  Each against the oracle on the SAME tables, at
+    the same bounds: the kernel's distance from the oracle is its f32 FFT, whatever the tables."""
     from oracle import frontend as F
     from mt3_amd import spectrograms as SP
+    td = "float32" if tables == "tf32" else "float64"
     audio = F.synth_audio(6, seed=0)
     rng = np.random.default_rng(1)
     audio[4] = rng.uniform(-1, 1, 32768).astype(np.float32)      # white noise: no empty-energy bins
     audio[5] = 0.0                                               # silence: every bin must be log(1e-5)
     n_frames = [256, 256, 100, 1, 256, 256]
-    out = SP.compute_spectrogram_batch(torch.from_numpy(audio).cuda(), n_frames).cpu().numpy()
-    # mel matrix the kernel was built from == oracle's (f64 -> f32)
-    np.testing.assert_array_equal(SP.mel_matrix(), F.mel_weight_matrix().astype(np.float32))
+    out = SP.compute_spectrogram_batch(torch.from_numpy(audio).cuda(), n_frames, table_dtype=td).cpu().numpy()
+    if tables == "tf32":           # the default is the float32 construction
+        np.testing.assert_array_equal(out, SP.compute_spectrogram_batch(torch.from_numpy(audio).cuda(), n_frames).cpu().numpy())
+    # mel matrix the kernel was built from == the oracle's, bit for bit, in both constructions
+    mel_ref_w = F.mel_weight_matrix_tf32() if tables == "tf32" else F.mel_weight_matrix().astype(np.float32)
+    np.testing.assert_array_equal(SP.mel_matrix(table_dtype=td), mel_ref_w)
+    hann = F.hann_periodic_tf32().astype(np.float64) if tables == "tf32" else F.hann_periodic()
     for s, n in enumerate(n_frames):
-        ref = F.compute_logmel(audio[s][: n * 128], np.float64)             # [n, 512]
+        ref = F.compute_logmel(audio[s][: n * 128], np.float64, tables=tables)             # [n, 512]
         assert ref.shape == (n, 512)
         got = out[s]
         assert np.all(got[n:] == 0.0), "pad rows must be exactly 0.0 (not log(eps))"
-        frames = F.frame_signal(audio[s][: n * 128].astype(np.float64)) * F.hann_periodic()
+        frames = F.frame_signal(audio[s][: n * 128].astype(np.float64)) * hann
         peak = np.abs(np.fft.rfft(frames, axis=-1)).max(1)                   # per-frame spectral peak
         mel_ref, mel_got = np.exp(ref), np.exp(got[:n].astype(np.float64))
         # f32 FFT noise floor scales with the frame's peak magnitude: linear-domain bound
@@ -479,6 +489,11 @@ def test_frontend_vs_oracle():
             assert np.abs(got[:n] - ref)[sig].max() < 1e-3
         # the two structurally empty mel columns are exactly log(1e-5)
         assert np.all(got[:n, [1, 10]] == np.float32(np.log(np.float32(1e-5))))
+        if tables == "tf32" and n == 256 and s < 2:
+            # ... and against the whole-float32 restatement of a TensorFlow graph (f32 FFT as well): both sides now carry
+            # f32 FFT noise, so the linear bound doubles
+            ref32 = F.compute_logmel_tf32(audio[s]).astype(np.float64)
+            assert np.all(np.abs(mel_got - np.exp(ref32)) <= 1.2e-5 * peak[:, None] + 1e-9)
     assert np.all(out[5] == np.float32(np.log(np.float32(1e-5))))
     # linearity property at full size: scaling the audio by 2 adds log 2 to every signal-carrying bin
     big = F.synth_audio(8, seed=3)
