@@ -779,6 +779,121 @@ def main():
             except Exception as ex:
                 extras.setdefault("eos_schedule", {})[okey] = {"value": None, "error": repr(ex)[:300]}
 
+            # ---- the same synthetic EOS schedule on BASELINE configs[3]'s corpus: 10,000 independent
+            # segments through 1250 decode slots, (a) as the reference's loop has it -- one batch-synchronous engine call per
+            # 1250 segments (NB:295-301; early exit + row retirement inside a call) -- and (b) with IN-FLIGHT BATCHING
+            # (mt3_engine_transcribe): a finished slot restarts on the next encoded segment.  Same tokens either way.
+            def eos_schedule_corpus(ecfg, key, n_corpus=10000, slots=1250):
+                try:
+                    ce = network.Transformer(ecfg, input_length=256, max_decode_length=L, max_batch=slots)
+                    ce.load_params(network.init_random_params(ecfg, seed=0))
+                    aud = torch.cat([synthetic.synth_audio(min(1024, n_corpus - a), seed=1000 + a)
+                                     for a in range(0, n_corpus, 1024)])
+                    lens = np.clip(np.rint(np.random.default_rng(0).normal(args.eos_mean, args.eos_sd, n_corpus)), 1,
+                                   args.decode_steps).astype(np.int32)
+
+                    def run_batch(n):
+                        toks = []
+                        with torch.cuda.stream(stream):
+                            for a in range(0, n, slots):
+                                ce.debug_set_eos_schedule(lens[a:a + slots])
+                                ce.encode(spectrograms.compute_spectrogram_batch(aud[a:min(a + slots, n)], None))
+                                toks.append(vocab.decode_tf(ce.decode(num_steps=args.decode_steps, early_exit=True)))
+                            return torch.cat(toks).cpu().numpy()
+
+                    def run_refill(n):
+                        with torch.cuda.stream(stream):
+                            ce.debug_set_eos_schedule(lens[:n])
+                            lm = torch.empty((n, 256, 512), device="cuda", dtype=torch.float32)
+                            for a in range(0, n, 1024):
+                                lm[a:a + 1024] = spectrograms.compute_spectrogram_batch(aud[a:min(a + 1024, n)], None)
+                            return vocab.decode_tf(ce.transcribe(lm, num_steps=args.decode_steps)).cpu().numpy()
+
+                    def clocked(fn):
+                        fn(min(n_corpus, 2 * slots))                 # warm-up on a fifth of the corpus: graphs, staging ring
+                        torch.cuda.synchronize()
+                        r0 = resource.getrusage(resource.RUSAGE_SELF)
+                        t1 = time.perf_counter()
+                        host = fn(n_corpus)
+                        torch.cuda.synchronize()
+                        d = time.perf_counter() - t1
+                        r1 = resource.getrusage(resource.RUSAGE_SELF)
+                        return d, (r1.ru_utime - r0.ru_utime) + (r1.ru_stime - r0.ru_stime), host
+                    d_b, cpu_b, host_b = clocked(run_batch)
+                    d_r, cpu_r, host_r = clocked(run_refill)
+                    st = dict(ce.transcribe_stats)
+                    esz = 2 if ecfg.dtype == "bfloat16" else 4
+                    H, nl = ecfg.num_heads, ecfg.num_decoder_layers
+                    kv1, qo = 2.0 * H * 64 * esz, 2.0 * H * 64 * esz
+                    ll = lens.astype(np.float64)
+                    live = nl * float((kv1 * (ll * (ll + 1) / 2) + (kv1 + qo) * ll).sum() + ((kv1 * 256 + qo) * ll).sum())
+                    extras.setdefault("eos_schedule_corpus", {})[key] = {
+                        "value": n_corpus * SEG_SECONDS / d_r, "unit": "audio-s/s", "seconds_per_pass": d_r, "steps": 1, "warmup": 1,
+                        "dtype": "bf16" if ecfg.dtype == "bfloat16" else "f32",
+                        "workload": "SYNTHETIC EOS SCHEDULE on BASELINE configs[3]'s corpus: %d segments, output lengths ~ clipped "
+                                    "N(%g, %g) per segment (seed 0), %d decode slots with IN-FLIGHT BATCHING "
+                                    "(mt3_engine_transcribe: finished slots restart on the next encoded segment); log-mel of "
+                                    "every segment, encoder passes, greedy decode, ids->tokens and the host copy inside the clock"
+                                    % (n_corpus, args.eos_mean, args.eos_sd, slots),
+                        "transcribe_stats": st, "host_cpu_s_per_pass": cpu_r,
+                        "live_row_kv_bytes_per_pass": live,
+                        "whole_pass_hbm_frac_on_live_bytes": live / d_r / 1e9 / HBM_PEAK_GBS,
+                        "batch_synchronous": {"value": n_corpus * SEG_SECONDS / d_b, "seconds_per_pass": d_b,
+                                              "host_cpu_s_per_pass": cpu_b,
+                                              "whole_pass_hbm_frac_on_live_bytes": live / d_b / 1e9 / HBM_PEAK_GBS,
+                                              "what": "the reference's shape of loop: one engine call per %d segments, each "
+                                                      "until its longest row is done (early exit + row retirement)" % slots},
+                        "refill_over_batch_synchronous": d_b / d_r,
+                        "tokens_identical": bool(np.array_equal(host_b, host_r))}
+                    ce.debug_set_eos_schedule(None)
+                    del ce
+                except Exception as ex:
+                    extras.setdefault("eos_schedule_corpus", {})[key] = {"value": None, "error": repr(ex)[:300]}
+
+            eos_schedule_corpus(cfg, "f32" if args.dtype == "float32" else "bf16")
+
+            # ---- BASELINE configs[0]'s analogue: ONE file through the drop-in class, InferenceModel.__call__
+            # (NB:283-308), reference precision.  A 10-minute "Slakh-shaped" file (six tones per segment, ragged last segment);
+            # random-init weights whose logits favour note events and EOS (synthetic.boost_note_events: rows end of their own
+            # accord, no imposed lengths).  (a) as shipped: the engine sized to the file, one refilled engine call;
+            # (b) schedule="batch": the reference's literal loop of batch-synchronous 8-row calls (NB:190,295-301).
+            def single_file(minutes=10.0):
+                try:
+                    from mt3_amd import inference
+                    n_seg = int(math.ceil(minutes * 60.0 / SEG_SECONDS))
+                    wav = synthetic.synth_audio(n_seg, seed=77, tones=6).reshape(-1)[: int(minutes * 60.0 * 16000)].cpu().numpy()
+                    icfg = network.T5Config(dtype=args.dtype)
+                    prm = synthetic.boost_note_events(network.init_random_params(icfg, seed=0), eos=4.0)
+                    rec = {}
+                    notes = {}
+                    for key, kw in (("file_sized_engine_refill", {}), ("reference_batches_of_8", {"schedule": "batch"})):
+                        m = inference.InferenceModel(prm, "mt3", dtype=args.dtype, decoding="beam1", **kw)
+                        with torch.cuda.stream(stream):
+                            m(wav)                                   # warm-up: engine growth, graphs
+                            torch.cuda.synchronize()
+                            t1 = time.perf_counter()
+                            ns = m(wav)
+                            torch.cuda.synchronize()
+                        d = time.perf_counter() - t1
+                        notes[key] = [(n.start_time, n.end_time, n.pitch, n.velocity, n.program, n.is_drum) for n in ns.notes]
+                        rec[key] = {"wall_s": d, "audio_s_per_s": len(wav) / 16000.0 / d, "engine_slots": m.engine_slots,
+                                    "rows_per_engine_call": m.rows_per_engine_call[:4] + (["..."] if len(m.rows_per_engine_call) > 4 else []),
+                                    "engine_calls": len(m.rows_per_engine_call), "batch_size_attribute": m.batch_size,
+                                    "notes": len(ns.notes)}
+                        del m
+                    rec["speedup"] = rec["reference_batches_of_8"]["wall_s"] / rec["file_sized_engine_refill"]["wall_s"]
+                    rec["notes_identical"] = notes["file_sized_engine_refill"] == notes["reference_batches_of_8"]
+                    rec["workload"] = ("one %.0f-minute 16 kHz file (%d segments, six tones each, ragged last segment) through "
+                                       "InferenceModel.__call__: host framing, log-mel, encoder, beam-1 decode with early exit, ids -> "
+                                       "tokens, note decoding; %s; random-init weights with boosted note-event / EOS logits (rows "
+                                       "end of their own accord); the CPU oracle's rate on this path is cpu_baseline.value"
+                                       % (minutes, n_seg, "f32" if args.dtype == "float32" else "bf16"))
+                    extras["single_file"] = rec
+                except Exception as ex:
+                    extras["single_file"] = {"error": repr(ex)[:300]}
+
+            single_file()
+
             # ---- "also report a pure uniform(-1, 1) noise run, which has no empty-energy bins": the
             # headline pipeline on white-noise segments (3 timed steps after a warm-up)
             try:

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdlib>
@@ -104,7 +105,9 @@ constexpr int kMaxGroups = 4;
 // staging ring of mt3_engine_transcribe: cross-attention K/V of segments that wait for a slot, kStageChunks chunks of up
 // to kStageChunkCap segments each (one encoder pass per chunk)
 constexpr int kStageChunks = 8, kStageChunkCap = 64, kStageMinBatch = 8;
-constexpr int kStreamPollSteps = 32;    // steps between two refill polls of a row group
+constexpr int kStreamPollSteps = 8;     // steps between two refill polls of a row group (measured f32, 10,000 ragged segments:
+                                        // 32 / 16 / 8 steps -> 2395 / 2417 / 2423 audio-s/s at 1250 slots, 1861 / 1889 / 1905 at
+                                        // 256: a finished slot idles half an interval on average, a poll costs ~50 us)
 constexpr int kThrottleWindow = 16;     // steps per window of the sleeping enqueue throttle (mt3_engine::wait_ev)
 
 // One persistent host thread per row group (created with the first decode that needs it, joined at destroy): a
@@ -1325,9 +1328,12 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
 // exactly FIVE: 5 / 6 groups 2421 / 2306 ms against 1106 with four (3: 1144), the same with GPU_MAX_HW_QUEUES=8 in the
 // environment, profiles/r4_ab_five_six_row_groups.txt -- as if a fifth busy queue shared one of four compute pipes with
 // another one and the two took turns (the decode waits for a group running at half speed).  Four it is.)
-static int row_groups_for(const mt3_engine_config& c, int batch) {
+// Under MT3_DECODE_EARLY_EXIT (the ragged regime: rows retire, the step is launch latency, not bandwidth) f32 follows
+// the bf16 rule: at B = 256 two groups 370.5 ms, four 380.7, one stream 377.5 (profiles/r4_ab_tall_tiles_groups_wait.txt,
+// profiles/r4_bench_driver_like.json eos_schedule); bf16 two groups 212.3 against 220.0 on one stream.
+static int row_groups_for(const mt3_engine_config& c, int batch, bool early_exit = false) {
   const bool f32 = c.compute_dtype != MT3_BF16;
-  if (batch >= (f32 ? 256 : 512)) return 4;
+  if (batch >= (f32 && !early_exit ? 256 : 512)) return 4;
   return batch >= 128 ? 2 : 1;
 }
 
@@ -1454,11 +1460,26 @@ struct GroupRun {
 // ---- sleeping waits (mt3_engine::wait_ev)
 static hipEvent_t wait_event(mt3_engine* e, int slot, int which) {
   hipEvent_t& ev = e->wait_ev[slot][which];
-  if (!ev && hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming) != hipSuccess) {
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
     (void)hipGetLastError();
     ev = nullptr;
   }
   return ev;
+}
+
+// The calling thread SLEEPS until `ev` has happened: hipEventQuery between naps of 20 .. 200 us (measured in round 5:
+// hipEventSynchronize spins a core for the length of the wait on this runtime even on an event created with
+// hipEventBlockingSync -- the CPU seconds of a decode did not move -- so the nap is explicit).  The naps start short so
+// that a poll's answer is picked up within tens of microseconds and grow while nothing happens.
+static hipError_t sleep_until(hipEvent_t ev) {
+  long nap_ns = 20000;
+  for (;;) {
+    const hipError_t he = hipEventQuery(ev);
+    if (he != hipErrorNotReady) return he;
+    (void)hipGetLastError();                               // NotReady is sticky in the thread's last-error slot
+    std::this_thread::sleep_for(std::chrono::nanoseconds(nap_ns));
+    if (nap_ns < 200000) nap_ns += nap_ns / 2;
+  }
 }
 
 // everything enqueued on `s` so far has run; the calling thread sleeps meanwhile (spins with MT3_OPT_SPIN_WAITS or when
@@ -1467,10 +1488,12 @@ static hipError_t wait_stream(mt3_engine* e, int slot, hipStream_t s) {
   hipEvent_t ev = e->spin_waits ? nullptr : wait_event(e, slot, 0);
   if (!ev) return hipStreamSynchronize(s);
   hipError_t he = hipEventRecord(ev, s);
-  return he == hipSuccess ? hipEventSynchronize(ev) : he;
+  return he == hipSuccess ? sleep_until(ev) : he;
 }
 
-// after step t has been enqueued: at the end of every window, sleep until the window before the previous one is done
+// after step t has been enqueued: at the end of every window, sleep until the window before it is done (at most two
+// windows of kThrottleWindow steps are ever enqueued ahead of the device: the runtime's own back-pressure, which spins,
+// is never reached)
 struct Throttle {
   mt3_engine* e;
   int slot;
@@ -1481,7 +1504,7 @@ struct Throttle {
     hipEvent_t ev = wait_event(e, slot, 1);
     if (!ev) return hipSuccess;
     hipError_t he = hipSuccess;
-    if (recorded) he = hipEventSynchronize(ev);          // the window recorded one window ago: <= 2 windows in flight
+    if (recorded) he = sleep_until(ev);                  // the window recorded one window ago
     if (he == hipSuccess) he = hipEventRecord(ev, s);
     recorded = 1;
     return he;
@@ -1690,7 +1713,7 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
 
   // ---- the row-group schedule (see mt3_engine::part_stream): batches of >= 128 rows, unless the caller asked for
   // one stream / graph chains, or wants per-step logits (those live on the caller's stream)
-  int groups = row_groups_for(c, batch);
+  int groups = row_groups_for(c, batch, early);
   if (groups > 1 && !(flags & MT3_DECODE_SINGLE_STREAM) && req_chains == 0 && e->cfg.decode_chains <= 1 &&
       !(c.options & MT3_OPT_NO_ROW_GROUPS) && debug_skip == 0 && !d_forced && !d_step_logits && !d_first_logits) {
     if (ensure_group_streams(e, groups) == MT3_OK) {

@@ -47,8 +47,10 @@ def _tuples(ns):
 @pytest.mark.parametrize("decoding", ["beam1", "greedy"])
 def test_audio_to_notes_matches_the_oracles_own_audio_to_notes(decoding):
     cfg = network.T5Config(dtype="float32", **CFG)
-    params = synthetic.boost_note_events(network.init_random_params(cfg, seed=2, norm_scale_jitter=0.1), eos=4.0)
-    wav = synthetic.synth_audio(3, seed=0).reshape(-1)[: 2 * 32768 + 9000].cpu().numpy()     # 2 segments + a short one
+    params = synthetic.boost_note_events(network.init_random_params(cfg, seed=1, norm_scale_jitter=0.1), eos=3.0)
+    # 2 segments + a short one; generated on the CPU so that the samples -- and with them the 28 notes the oracle decodes
+    # from these weights -- are the same on every box
+    wav = synthetic.synth_audio(3, seed=0, device="cpu").reshape(-1)[: 2 * 32768 + 9000].numpy()
     m = inference.InferenceModel(params, "mt3", config=cfg, decoding=decoding)
     ns = m(wav)
     ex = m.preprocess(m.audio_to_dataset(wav))
@@ -74,8 +76,8 @@ def test_one_file_gives_the_same_notes_in_one_refilled_call_and_in_the_reference
     refilled) while `batch_size` stays the reference's 8; `schedule="batch"` is the reference's literal loop of 8-row
     batch-synchronous calls (NB:190,295-301).  Same notes; the log-mel never leaves the device in between."""
     cfg = network.T5Config(dtype="float32", **CFG)
-    params = synthetic.boost_note_events(network.init_random_params(cfg, seed=2, norm_scale_jitter=0.1), eos=4.0)
-    wav = synthetic.synth_audio(43, seed=4).reshape(-1)[: 42 * 32768 + 777].cpu().numpy()    # 43 segments: 88 s of audio
+    params = synthetic.boost_note_events(network.init_random_params(cfg, seed=1, norm_scale_jitter=0.1), eos=3.0)
+    wav = synthetic.synth_audio(43, seed=4, device="cpu").reshape(-1)[: 42 * 32768 + 777].numpy()    # 43 segments: 88 s of audio
     a = inference.InferenceModel(params, "mt3", config=cfg, max_slots=32)
     b = inference.InferenceModel(params, "mt3", config=cfg, schedule="batch")
     na, nb = a(wav), b(wav)

@@ -38,7 +38,7 @@ def _lengths(B, mean, sd, hi, seed):
     return np.clip(np.rint(rng.normal(mean, sd, B)), 1, hi).astype(np.int32)
 
 
-@pytest.mark.parametrize("dtype,kv,B,groups", [("float32", "", 131, 2), ("bfloat16", "", 131, 2), ("float32", "", 259, 4),
+@pytest.mark.parametrize("dtype,kv,B,groups", [("float32", "", 131, 2), ("bfloat16", "", 131, 2), ("float32", "", 259, 2),
                                                ("bfloat16", "fp8_e4m3", 140, 2)])
 def test_retired_rows_change_no_id(dtype, kv, B, groups):
     S = 192
