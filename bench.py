@@ -544,20 +544,19 @@ def main():
             enc_tf = ENC_GFLOP_PER_SEGMENT * Br / (enc_ms * 1e-3) / 1e3
 
             def mfma_block(tf):
-                """roofline fields of an encoder figure.  The f32 engine's dense layers multiply on the bf16 pipes: every
-                f32 operand as three exact bf16 terms, six bf16 products per f32 product (csrc/gemm.hip: gemm_x6_kernel),
-                so its matrix-instruction work is 6x the algorithmic flops and is priced against the BF16 peak -- against
-                the f32 instruction's peak the same figure would read above 1"""
+                """roofline fields of an encoder figure.  The f32 engine's encoder multiplies on the bf16 pipes -- dense layers
+                AND attention (round 4): every f32 operand as three exact bf16 terms, six bf16 products per f32 product
+                (csrc/gemm.hip: gemm_x6_kernel, csrc/enc_attention_x6.hip) -- so its matrix-instruction work is 6x the
+                algorithmic flops and is priced against the BF16 peak; against the f32 instruction's peak the same figure
+                would read above 1"""
                 if esize == 2:
                     return {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}
-                dense = 1.0 - ENC_ATTN_GFLOP_PER_SEGMENT / ENC_GFLOP_PER_SEGMENT      # share of the flops in the dense layers
-                return {"bound": "mfma", "achieved": 6.0 * dense * tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": 6.0 * dense * tf / MFMA_BF16_PEAK_TFLOPS, "f32_equivalent_tflops": tf,
+                return {"bound": "mfma", "achieved": 6.0 * tf, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": 6.0 * tf / MFMA_BF16_PEAK_TFLOPS, "f32_equivalent_tflops": tf,
                         "f32_mfma_peak": MFMA_F32_PEAK_TFLOPS,
-                        "note": "achieved = bf16 matrix-instruction work of the dense layers (6 bf16 MFMAs per f32 product: "
-                                "three exact bf16 planes per operand) over the WHOLE time, of which the encoder attention -- %.1f %% "
-                                "of the flops, on the f32 instruction -- takes about a fifth; f32_equivalent_tflops = all "
-                                "algorithmic flops / time" % (100.0 * (1.0 - dense))}
+                        "note": "achieved = bf16 matrix-instruction work of the whole encoder, dense layers and attention "
+                                "(6 bf16 MFMAs per f32 product: three exact bf16 planes per operand), over the whole time; "
+                                "f32_equivalent_tflops = algorithmic flops / time"}
             extras["encoder"] = {"segments": Br, "ms": enc_ms, **mfma_block(enc_tf),
                                  "algorithmic_gflop_per_segment": ENC_GFLOP_PER_SEGMENT}
             # BASELINE configs[1]: batch 64, log-mel + encoder (+ cross-K/V), encoder-only throughput
@@ -638,8 +637,9 @@ def main():
                 r_other["note"] = ("bf16 MFMA operands and K/V caches, f32 accumulation / residual / softmax: NOT the reference's "
                               "precision -- see extra.divergence_vs_f32 for how far its free-running tokens drift"
                               if other == "bfloat16" else
-                              "reference precision (model.gin:50 dtype float32): f32 MFMA operands "
-                              "(4 x v_mfma_f32_16x16x4_f32 per chunk), f32 K/V cache; token-exact vs the oracle")
+                              "reference precision (model.gin:50 dtype float32): f32 operands and K/V caches; the decode step on "
+                              "v_mfma_f32_16x16x4_f32, the encoder on the bf16 pipes with three exact bf16 planes per operand; "
+                              "token-exact vs the oracle")
             # ---- BASELINE configs[4] ingredients, one warm-up + 3 timed steps each (never the headline):
             #   fp8_kv    : this workload with e4m3 K/V caches (half the bytes of the HBM-bound decode stream)
             #   fp8_kv_mx8: the same plus the encoder's dense layers / cross-K/V projections as MXFP8 on the scaled MFMA

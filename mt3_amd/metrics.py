@@ -101,11 +101,15 @@ def precision_recall_f1_overlap(ref_intervals, ref_pitches, est_intervals, est_p
     """(precision, recall, F) of mir_eval.transcription.precision_recall_f1_overlap (its 4th value, the average overlap
     ratio of the matched pairs, is discarded at every call site of mt3/metrics.py and not computed here)."""
     n_ref, n_est = len(np.asarray(ref_pitches)), len(np.asarray(est_pitches))
+    # mir_eval.transcription.validate runs FIRST (before the emptiness check) and, per side, util.validate_frequencies
+    # rejects pitches that are not positive -- so a pitch 0 on one side raises even when the other side is empty
+    # (an empty side itself only warns there)
+    for side in (ref_pitches, est_pitches):
+        a = np.asarray(side, np.float64)
+        if a.size and (a <= 0).any():
+            raise ValueError("precision_recall_f1_overlap: pitches must be positive (mir_eval.transcription.validate)")
     if n_ref == 0 or n_est == 0:
         return 0.0, 0.0, 0.0
-    # mir_eval.transcription.validate -> util.validate_frequencies rejects pitches that are not positive
-    if (np.asarray(ref_pitches, np.float64) <= 0).any() or (np.asarray(est_pitches, np.float64) <= 0).any():
-        raise ValueError("precision_recall_f1_overlap: pitches must be positive (mir_eval.transcription.validate)")
     m = match_notes(ref_intervals, ref_pitches, est_intervals, est_pitches, onset_tolerance, pitch_tolerance,
                     offset_ratio, offset_min_tolerance, strict)
     p, r = m / n_est, m / n_ref

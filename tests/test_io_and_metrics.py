@@ -191,3 +191,18 @@ def test_midi_bytes_of_a_one_note_sequence_follow_the_smf_specification():
     d = NoteSequence(notes=[Note(0.0, 0.0005, 38, 127, 0, True, 9)], total_time=0.01)
     b = midi_io.note_sequence_to_midi_bytes(d)
     assert bytes([0x00, 0x99, 0x26, 0x7F, 0x01, 0x89, 0x26, 0x00]) in b
+
+
+def test_pitch_validation_runs_before_the_emptiness_check():
+    """mir_eval.transcription.precision_recall_f1_overlap validates its arguments first: a non-positive pitch on one side
+    raises even when the OTHER side is empty; two empty sides, or an empty side against valid pitches, score 0."""
+    import pytest
+    from mt3_amd import metrics
+    iv = np.array([[0.0, 1.0]])
+    none_iv, none_p = np.zeros((0, 2)), np.zeros((0,))
+    with pytest.raises(ValueError):
+        metrics.precision_recall_f1_overlap(none_iv, none_p, iv, np.array([0.0]))
+    with pytest.raises(ValueError):
+        metrics.precision_recall_f1_overlap(iv, np.array([-3.0]), none_iv, none_p)
+    assert metrics.precision_recall_f1_overlap(none_iv, none_p, iv, np.array([60.0])) == (0.0, 0.0, 0.0)
+    assert metrics.precision_recall_f1_overlap(none_iv, none_p, none_iv, none_p) == (0.0, 0.0, 0.0)
