@@ -105,9 +105,11 @@ constexpr int kMaxGroups = 4;
 // staging ring of mt3_engine_transcribe: cross-attention K/V of segments that wait for a slot, kStageChunks chunks of up
 // to kStageChunkCap segments each (one encoder pass per chunk)
 constexpr int kStageChunks = 8, kStageChunkCap = 64, kStageMinBatch = 8;
-constexpr int kStreamPollSteps = 8;     // steps between two refill polls of a row group (measured f32, 10,000 ragged segments:
-                                        // 32 / 16 / 8 steps -> 2395 / 2417 / 2423 audio-s/s at 1250 slots, 1861 / 1889 / 1905 at
-                                        // 256: a finished slot idles half an interval on average, a poll costs ~50 us)
+constexpr int kStreamPollSteps = 4;     // steps between two refill polls of a row group.  Drained polls, f32, 10,000 ragged segments:
+                                        // 32 / 16 / 8 steps -> 2395 / 2417 / 2423 audio-s/s at 1250 slots, 1861 / 1889 / 1905 at 256
+                                        // (a finished slot idles half an interval on average, a drained poll costs a bubble of
+                                        // ~50 us, more when the host sleeps); the pipelined poll has no bubble and reacts one
+                                        // interval later: a slot idles 1.5 intervals on average
 constexpr int kThrottleWindow = 16;     // steps per window of the sleeping enqueue throttle (mt3_engine::wait_ev)
 
 // One persistent host thread per row group (created with the first decode that needs it, joined at destroy): a
@@ -272,7 +274,7 @@ struct mt3_engine {
   // device and waits for the older one on a BLOCKING-SYNC event -- the thread sleeps until the interrupt instead of
   // spinning in the runtime's queue back-pressure / hipStreamSynchronize (round 4: five cores busy for the length of a
   // decode).  Index kMaxGroups = the caller's stream (single-stream schedule, the encoder passes of transcribe).
-  hipEvent_t wait_ev[kMaxGroups + 1][2] = {};
+  hipEvent_t wait_ev[kMaxGroups + 1][4] = {};     // [0] waits, [1] throttle, [2], [3] the two poll snapshots of transcribe
   bool spin_waits = false;       // MT3_OPT_SPIN_WAITS: round 4's behaviour
   int part_failed = 0;           // partitioned decodes that fell back to the single-stream schedule (stream creation failed)
   int last_groups = 1;           // row groups of the most recent decode
@@ -1989,6 +1991,16 @@ static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out,
   std::vector<FeedRange> held, got(kStageChunks + 2);
   r.ran = 0;
   r.used_graph = r.use_graph;
+  // The poll is PIPELINED: at the end of interval j the group's counter of finished slots is copied to pinned memory and
+  // an event recorded behind the copy -- and the host goes straight on to enqueue interval j + 1; it looks at snapshot j
+  // only after that (sleeping until the event if need be), so the device always has an interval of steps queued and never
+  // waits for the host's answer (round 5: with drained polls a sleeping host cost 1.3 % at 256 slots).  What the
+  // snapshot triggers -- refills, the hand-over of finished ids, a compaction -- is enqueued BEHIND interval j + 1 and in
+  // front of snapshot j + 1, so every snapshot already accounts for it.  The kernels act on the device's state when they
+  // run (decode_ops.hip: the plan kernels scan the done flags), the snapshot only says how many staged segments to hand
+  // out: it may be an interval stale, never wrong (finished slots stay finished until a refill restarts them).
+  int parity = 0;
+  bool pending = false;
   for (long t = 0;; ++t) {
     if (t >= max_steps) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: a row group did not terminate");
     if (r.use_graph && exec_rows != cur) {
@@ -2003,43 +2015,56 @@ static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out,
     else MT3_TRY(enqueue_chain_step(e, r.row0, cur, r.slot, r.batch, r.variant, r.s, r.slot));
     ++r.ran;
     if (t % kPoll != kPoll - 1) continue;
-    // ---- the poll
-    MT3_HIP_CHECK(hipMemcpyAsync(e->h_pinned + r.slot, e->n_done + r.slot, 4, hipMemcpyDeviceToHost, r.s));
-    MT3_HIP_CHECK(wait_stream(e, r.slot, r.s));
-    feed_release(f, held);                       // the copies out of what was taken at the previous poll have run
-    held.clear();
-    int n_fin = e->h_pinned[r.slot];             // finished slots among the group's r.rows (dropped ones included)
-    bool dry = false;
-    for (;;) {
-      {
-        std::lock_guard<std::mutex> lk(f.mu);
-        if (f.failed) return MT3_OK;             // somebody else reports the error
+    // ---- the previous interval's snapshot
+    if (pending) {
+      hipEvent_t pev = wait_event(e, r.slot, 2 + (parity ^ 1));
+      MT3_HIP_CHECK(e->spin_waits ? hipEventSynchronize(pev) : sleep_until(pev));
+      feed_release(f, held);                     // what was taken one snapshot ago was copied out in front of this one
+      held.clear();
+      int n_fin = e->h_pinned[r.slot + kMaxGroups * (parity ^ 1)];   // finished slots among the group's r.rows (dropped ones included)
+      bool dry = false;
+      for (;;) {
+        {
+          std::lock_guard<std::mutex> lk(f.mu);
+          if (f.failed) return MT3_OK;           // somebody else reports the error
+        }
+        const int refillable = n_fin - (r.rows - cur);
+        const int nr = feed_pop(f, refillable, got.data(), static_cast<int>(got.size()), &dry);
+        for (int i = 0; i < nr; ++i) {
+          MT3_TRY(refill_group(e, r, cur, &got[i], d_out));
+          held.push_back(got[i]);
+          n_fin -= got[i].n;
+        }
+        if (dry || n_fin < r.rows) break;
+        feed_wait(f);                            // nothing live and the encoder is behind: sleep, do not spin through empty steps
       }
-      const int refillable = n_fin - (r.rows - cur);
-      const int nr = feed_pop(f, refillable, got.data(), static_cast<int>(got.size()), &dry);
-      for (int i = 0; i < nr; ++i) {
-        MT3_TRY(refill_group(e, r, cur, &got[i], d_out));
-        held.push_back(got[i]);
-        n_fin -= got[i].n;
+      if (dry) {
+        // the queue is empty for good: finished slots hand over their ids, the live ones are compacted as under EARLY_EXIT
+        const int live = r.rows - n_fin;
+        int want = (live + 31) & ~31;
+        if (want > r.rows) want = r.rows;
+        const bool compact = live > 0 && want < cur;
+        // (the hand-over runs on the device's own done flags, directly in front of a compaction or of the exit: no slot
+        // that finished after the snapshot can be dropped with its ids still in the engine)
+        if ((n_fin - (r.rows - cur) > 0 && n_fin != flushed_at) || compact || live <= 0) {
+          MT3_TRY(refill_group(e, r, cur, nullptr, d_out));
+          flushed_at = n_fin;
+        }
+        if (live <= 0) break;
+        if (compact) {
+          MT3_TRY(compact_group(e, r, cur));
+          cur = want;
+          ++e->compactions_now;
+        }
       }
-      if (dry || n_fin < r.rows) break;
-      feed_wait(f);                              // nothing live and the encoder is behind: sleep, do not spin through empty steps
     }
-    if (!dry) continue;
-    // ---- the queue is empty for good: finished slots hand over their ids, the live ones are compacted as under EARLY_EXIT
-    if (n_fin - (r.rows - cur) > 0 && n_fin != flushed_at) {
-      MT3_TRY(refill_group(e, r, cur, nullptr, d_out));
-      flushed_at = n_fin;
-    }
-    const int live = r.rows - n_fin;
-    if (live <= 0) break;
-    int want = (live + 31) & ~31;
-    if (want > r.rows) want = r.rows;
-    if (want < cur) {
-      MT3_TRY(compact_group(e, r, cur));
-      cur = want;
-      ++e->compactions_now;
-    }
+    // ---- this interval's snapshot
+    hipEvent_t ev = wait_event(e, r.slot, 2 + parity);
+    if (!ev) return mt3::fail(MT3_ERR_HIP, "mt3_engine_transcribe: could not create a poll event");
+    MT3_HIP_CHECK(hipMemcpyAsync(e->h_pinned + r.slot + kMaxGroups * parity, e->n_done + r.slot, 4, hipMemcpyDeviceToHost, r.s));
+    MT3_HIP_CHECK(hipEventRecord(ev, r.s));
+    pending = true;
+    parity ^= 1;
   }
   MT3_HIP_CHECK(wait_stream(e, r.slot, r.s));
   feed_release(f, held);

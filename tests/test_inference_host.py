@@ -63,3 +63,33 @@ def test_trim_eos():
     assert np.array_equal(inference.trim_eos([4, 5, 6]), [4, 5, 6])
     assert inference.trim_eos([eos]).size == 0 and inference.trim_eos([]).size == 0
     assert inference.InferenceModel._trim_eos([9, eos]).dtype == np.int32
+
+
+def test_the_engine_is_sized_to_the_job_while_batch_size_stays_the_references_8(monkeypatch):
+    """`batch_size` is what `input_shapes` reports (NB:190); the engine behind `predict_tokens` grows to the job in
+    powers of two up to `max_slots` and never shrinks (VERDICT r4 #3).  A stub stands in for the engine: no GPU."""
+    from mt3_amd import network
+    built = []
+
+    class StubEngine:
+        def __init__(self, cfg, input_length, max_decode_length, max_batch):
+            self.max_batch = max_batch
+            built.append(max_batch)
+
+        def load_params(self, params):
+            self.params = params
+
+    monkeypatch.setattr(network, "Transformer", StubEngine)
+    m = inference.InferenceModel({"w": 0}, "mt3", max_slots=256)
+    assert built == [8] and m.batch_size == 8 and m.engine_slots == 8
+    assert m.input_shapes == {"encoder_input_tokens": (8, 256), "decoder_input_tokens": (8, 1024)}
+    for n, want in ((3, 8), (8, 8), (9, 16), (12, 16), (293, 256), (40, 256), (5000, 256)):
+        m._ensure_slots(n)
+        assert m.engine_slots == want and m.batch_size == 8, (n, m.engine_slots)
+    assert built == [8, 16, 256] and m.model.params == {"w": 0}
+    small = inference.InferenceModel({"w": 0}, "mt3", max_slots=4, batch_size=8)        # max_slots below batch_size: ignored
+    small._ensure_slots(100)
+    assert small.engine_slots == 8
+    import pytest
+    with pytest.raises(ValueError):
+        inference.InferenceModel({"w": 0}, "mt3", schedule="nope")
