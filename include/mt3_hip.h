@@ -160,13 +160,12 @@ enum {
    * of 16 decode steps enqueued ahead of the device and sleeps on a blocking-sync event for the older one, and the polls of
    * MT3_DECODE_EARLY_EXIT / mt3_engine_transcribe sleep the same way */
   MT3_OPT_SPIN_WAITS = 64,
-  /* engines of >= 512 slots (max_batch): keep the DECODE step's dense layers on the decode-sized latency tiles with the
-   * folded projections, as smaller engines run it.  By default such an engine sends them to the encoder-sized tiles -- f32:
-   * on the bf16 pipes with three exact bf16 planes per f32 operand, as its encoder does; bf16: the LDS-DMA staged tile --
-   * and runs without the folded projections: at >= 128 rows per row group those launches are compute, not latency
-   * (DESIGN.md section 3).  The choice follows the ENGINE's size, never a call's batch or a group's live rows: a
-   * segment's ids do not depend on how full the engine is */
-  MT3_OPT_DECODE_LATENCY_TILES = 128
+  /* f32 engine of >= 512 slots (max_batch): keep the DECODE step's dense layers on the f32 matrix instruction with the
+   * folded projections, as smaller engines run it.  By default such an engine multiplies the step's dense layers on the
+   * bf16 pipes (three exact bf16 planes per f32 operand, as its encoder does; no folded projections): at >= 128 rows
+   * per row group those launches are compute, not latency.  The choice follows the ENGINE's size,
+   * never a call's batch: a segment's ids do not depend on how full the engine is */
+  MT3_OPT_DECODE_F32_MFMA = 128
 };
 
 typedef struct mt3_engine mt3_engine;

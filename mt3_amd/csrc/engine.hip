@@ -181,11 +181,6 @@ struct mt3_engine {
   // per step: a row's numbers do not change when its group shrinks.
   bool dec_x6 = false;
   void* logits_p[3] = {};
-  // The same switch for bf16 operands: an engine of >= kDecodeX6MinBatch slots sends the step's dense layers to the
-  // encoder-sized LDS-DMA tile (gemm_glds_kernel, 128 x 128 x 32) instead of the 32 x 32 whole-K latency tile, and runs
-  // without the folded projections (that tile has no epilogue for them, and at this M their extra flops cost more than
-  // the launches they save); the split residual form stays -- it is what feeds that tile.
-  bool dec_big = false;
   float* enc_norm = nullptr;     // [emb] f32
   float* embedding = nullptr;    // [V][emb] f32
   void* logits_w = nullptr;      // [V][emb] (decoder_norm folded)
@@ -657,7 +652,7 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   const int dt = c.compute_dtype, emb = c.emb_dim, hd = e->HD(), H = c.num_heads, T = c.input_length;
   const int Lmax = c.max_decode_len;
   const size_t es = e->esize, kes = e->kv_esize;
-  const bool small = !e->dec_big;                // a large engine's step takes the encoder-sized tiles (mt3_engine::dec_big)
+  const bool small = true;
   const int nl = c.num_decoder_layers;
   const bool split = e->y_split, fold = e->qkv_fold;
   // row retirement: the step's slots [row0, row0 + rows) reach their cache rows / id rows through e->slot_row, so the
@@ -961,7 +956,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
   if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM |
-                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_ENCODER_F32_MFMA | MT3_OPT_SPIN_WAITS | MT3_OPT_DECODE_LATENCY_TILES))
+                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_ENCODER_F32_MFMA | MT3_OPT_SPIN_WAITS | MT3_OPT_DECODE_F32_MFMA))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -973,9 +968,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   e->dense_fp8 = cfg->dense_dtype == MT3_FP8_E4M3;
   e->x6 = cfg->compute_dtype == MT3_F32 && !(cfg->options & MT3_OPT_ENCODER_F32_MFMA);
   e->spin_waits = (cfg->options & MT3_OPT_SPIN_WAITS) != 0;
-  e->dec_big = cfg->max_batch >= kDecodeX6MinBatch && !(cfg->options & MT3_OPT_DECODE_LATENCY_TILES) &&
-               (cfg->compute_dtype == MT3_BF16 || e->x6);
-  e->dec_x6 = e->dec_big && e->x6;
+  e->dec_x6 = e->x6 && cfg->max_batch >= kDecodeX6MinBatch && !(cfg->options & MT3_OPT_DECODE_F32_MFMA);
   e->esize = cfg->compute_dtype == MT3_BF16 ? 2 : 4;
   e->kv_fp8 = cfg->kv_cache_dtype == MT3_FP8_E4M3;
   e->kv_esize = e->kv_fp8 ? 1 : e->esize;
@@ -1060,7 +1053,7 @@ int mt3_engine_finalize(mt3_engine* e) {
   e->dec.resize(c.num_decoder_layers);
   // (a large f32 engine's decode step runs on the three-plane tiles: single residual stream, no folded projections)
   const bool single_stream = (c.options & MT3_OPT_SINGLE_RESIDUAL_STREAM) != 0 || e->dec_x6;
-  const bool q_fold = emb % 64 == 0 && (emb <= 512 || emb == 768) && !single_stream && !e->dec_big &&
+  const bool q_fold = emb % 64 == 0 && (emb <= 512 || emb == 768) && !single_stream &&
                       !(c.options & MT3_OPT_SEPARATE_PROJECTIONS);
   e->q_fold = q_fold;
   for (int l = 0; l < c.num_decoder_layers; ++l) {

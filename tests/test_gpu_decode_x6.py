@@ -1,5 +1,5 @@
 """The DECODE step of a large f32 engine on the bf16 pipes (round 5; mt3_engine::dec_x6, include/mt3_hip.h
-MT3_OPT_DECODE_LATENCY_TILES).  An f32 engine of >= 512 slots multiplies the step's dense layers (network.Decoder's DenseGeneral
+MT3_OPT_DECODE_F32_MFMA).  An f32 engine of >= 512 slots multiplies the step's dense layers (network.Decoder's DenseGeneral
 calls, mt3/network.py:88-155, mt3/layers.py:373-418) with every f32 operand as three exact bf16 planes -- the tiles its
 encoder already uses -- because at >= 128 rows per row group those launches are compute-bound, not latency-bound
 (profiles/r5_refill_f32_kernel_stats.csv).  Not a reduced-precision mode (tests/test_three_plane_arithmetic.py): here the
@@ -28,7 +28,7 @@ def test_large_f32_engine_decodes_on_three_planes_and_matches_the_oracle():
         ids_ref, logits_ref = orc.greedy_decode(enc_ref, S, return_logits=True)
     logits_ref = logits_ref.numpy()                               # [B, S, V]
     got = {}
-    for name, opt in (("three bf16 planes", 0), ("f32 instruction", _lib.OPT_DECODE_LATENCY_TILES)):
+    for name, opt in (("three bf16 planes", 0), ("f32 instruction", _lib.OPT_DECODE_F32_MFMA)):
         eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=512, options=opt)
         eng.load_params(params)
         assert eng.status(_lib.STATUS_QKV_FOLD) == (0 if opt == 0 else 1)      # the large engine runs without the folds
@@ -47,42 +47,11 @@ def test_large_f32_engine_decodes_on_three_planes_and_matches_the_oracle():
     assert d.max() < 1e-5
 
 
-def test_large_bf16_engine_decodes_on_the_lds_dma_tiles():
-    """bf16 operands: an engine of >= 512 slots sends the step's dense layers to the encoder-sized LDS-DMA tile (no folded
-    projections).  Same operands, same f32 accumulation as the latency tiles: teacher-forced logits within the bf16 bound
-    of the f32 oracle at every position and within rounding of the small engine's evaluation."""
-    cfg = network.T5Config(dtype="bfloat16", num_encoder_layers=2, num_decoder_layers=3)
-    params = network.init_random_params(cfg, seed=9, norm_scale_jitter=0.2)
-    B, S = 12, 96
-    lm = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(B, seed=14), None)
-    orc = ON.Oracle(params, ON.T5Config(num_encoder_layers=2, num_decoder_layers=3))
-    torch.set_num_threads(16)
-    with torch.no_grad():
-        ids_ref, logits_ref = orc.greedy_decode(orc.encode(lm.cpu().numpy()), S, return_logits=True)
-    logits_ref = logits_ref.numpy()
-    got = {}
-    for name, opt in (("LDS-DMA tiles", 0), ("latency tiles", _lib.OPT_DECODE_LATENCY_TILES)):
-        eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=512, options=opt)
-        eng.load_params(params)
-        assert eng.status(_lib.STATUS_QKV_FOLD) == (0 if opt == 0 else 1)
-        eng.encode(lm)
-        _, logits = eng.decode_forced(ids_ref, num_steps=S)
-        logits = logits.cpu().numpy().transpose(1, 0, 2)
-        rel = np.linalg.norm(logits - logits_ref, axis=-1) / np.linalg.norm(logits_ref, axis=-1)
-        print(f"large bf16 engine [{name}]: teacher-forced logits vs the f32 oracle, max rel-L2 {rel.max():.3e}")
-        assert rel.max() < 3e-2, (name, float(rel.max()))
-        got[name] = logits
-        del eng
-    d = np.linalg.norm(got["LDS-DMA tiles"] - got["latency tiles"], axis=-1) / np.linalg.norm(got["latency tiles"], axis=-1)
-    print(f"large bf16 engine: LDS-DMA tiles vs latency tiles, max rel-L2 {d.max():.3e}")
-    assert d.max() < 1.5e-2
-
-
-@pytest.mark.parametrize("dtype", ["float32", "bfloat16"])
-def test_large_engine_full_width_row_groups_retirement_and_refill_agree(dtype):
-    """512 slots in use: row groups on the encoder-sized tiles; the every-row schedule, early exit with retirement (the
-    groups shrink below one 128-row tile: the same kernels, the same bits) and in-flight batching return the same ids."""
-    cfg = network.T5Config(dtype=dtype, num_encoder_layers=1, num_decoder_layers=2)
+def test_large_f32_engine_full_width_row_groups_retirement_and_refill_agree():
+    """512 slots in use: four row groups of 128 rows on the three-plane tiles; the every-row schedule, early exit with
+    retirement (the groups shrink below one 128-row tile: the same kernels, the same bits) and in-flight batching return
+    the same ids."""
+    cfg = network.T5Config(dtype="float32", num_encoder_layers=1, num_decoder_layers=2)
     params = network.init_random_params(cfg, seed=10, norm_scale_jitter=0.1)
     k = params["decoder/logits_dense/kernel"].copy()
     k[:, 1] *= 3.0
@@ -101,7 +70,7 @@ def test_large_engine_full_width_row_groups_retirement_and_refill_agree(dtype):
             if a == 0:
                 assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 1
                 groups = eng.decode(num_steps=S)
-                assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 4 and torch.equal(groups, full)      # (both dtypes: 4 from 512 rows)
+                assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 4 and torch.equal(groups, full)
                 early = eng.decode(num_steps=S, early_exit=True)
                 assert torch.equal(early, full) and eng.status(_lib.STATUS_LAST_DECODE_COMPACTIONS) >= 1
             ref.append(full)

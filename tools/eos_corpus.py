@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--single-stream", action="store_true")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--spin-waits", action="store_true", help="MT3_OPT_SPIN_WAITS: the workers spin as in round 4")
-    ap.add_argument("--options", type=int, default=0, help="mt3_engine_config.options bits (e.g. 128 = MT3_OPT_DECODE_LATENCY_TILES)")
+    ap.add_argument("--options", type=int, default=0, help="mt3_engine_config.options bits (e.g. 128 = MT3_OPT_DECODE_F32_MFMA)")
     ap.add_argument("--decode-probe", action="store_true",
                     help="also time one canonical full-length decode of `--slots` rows (ms, host CPU seconds)")
     ap.add_argument("--polls", default="0", help="refill mode: comma list of poll intervals to try (0 = the product's)")
