@@ -159,13 +159,7 @@ enum {
    * the runtime's own queue back-pressure) as they did up to round 4.  By default a worker keeps at most two windows
    * of 16 decode steps enqueued ahead of the device and sleeps on a blocking-sync event for the older one, and the polls of
    * MT3_DECODE_EARLY_EXIT / mt3_engine_transcribe sleep the same way */
-  MT3_OPT_SPIN_WAITS = 64,
-  /* f32 engine of >= 512 slots (max_batch): keep the DECODE step's dense layers on the f32 matrix instruction with the
-   * folded projections, as smaller engines run it.  By default such an engine multiplies the step's dense layers on the
-   * bf16 pipes (three exact bf16 planes per f32 operand, as its encoder does; no folded projections): at >= 128 rows
-   * per row group those launches are compute, not latency.  The choice follows the ENGINE's size,
-   * never a call's batch: a segment's ids do not depend on how full the engine is */
-  MT3_OPT_DECODE_F32_MFMA = 128
+  MT3_OPT_SPIN_WAITS = 64
 };
 
 typedef struct mt3_engine mt3_engine;

@@ -21,7 +21,6 @@ DECODE_NO_GRAPH, DECODE_EARLY_EXIT, DECODE_BEAM1, DECODE_SINGLE_STREAM, DECODE_A
  OPT_SEPARATE_QKV_PROJECTION, OPT_NO_ROW_GROUPS) = 1, 2, 4, 8, 16              # mt3_engine_config.options
 OPT_ENCODER_F32_MFMA = 32
 OPT_SPIN_WAITS = 64
-OPT_DECODE_F32_MFMA = 128
 # include/mt3_hip_debug.h (measurement / fault injection; not the product ABI)
 DEBUG_SKIP_SELF_ATTN, DEBUG_SKIP_CROSS_ATTN = 1, 2
 (STATUS_GRAPH_FALLBACKS, STATUS_LAST_DECODE_USED_GRAPH, STATUS_RESIDUAL_SPLIT, STATUS_KV_FP8, STATUS_Q_FOLD,

@@ -91,8 +91,6 @@ struct LayerDev {
           *wo_mlp_q = nullptr, *wo_mlp_sc = nullptr, *wkv_x_q = nullptr, *wkv_x_sc = nullptr;
   // f32 engine, encoder-sized launches (gemm_x6_kernel): the same matrices as three bf16 planes (hi / mid / lo) [N][K]
   void *wqkv_p[3] = {}, *wo_p[3] = {}, *wi_p[3] = {}, *wo_mlp_p[3] = {}, *wkv_x_p[3] = {};
-  // ... and, for the decode step of a LARGE f32 engine (mt3_engine::dec_x6), the decoder's own matrices
-  void *wq_x_p[3] = {}, *wo_x_p[3] = {};
   // fp8 (e4m3) K/V caches only: {k_scale, v_scale} per cached row
   float2* self_scale = nullptr;    // [Bm][H][L]
   float2* cross_scale = nullptr;   // [B][H][T]
@@ -112,7 +110,6 @@ constexpr int kStreamPollSteps = 4;     // steps between two refill polls of a r
                                         // (a finished slot idles half an interval on average, a drained poll costs a bubble of
                                         // ~50 us, more when the host sleeps); the pipelined poll has no bubble and reacts one
                                         // interval later: a slot idles 1.5 intervals on average
-constexpr int kDecodeX6MinBatch = 512;  // slots from which an f32 engine's decode step multiplies on the bf16 pipes (mt3_engine::dec_x6)
 constexpr int kThrottleWindow = 16;     // steps per window of the sleeping enqueue throttle (mt3_engine::wait_ev)
 
 // One persistent host thread per row group (created with the first decode that needs it, joined at destroy): a
@@ -170,17 +167,6 @@ struct mt3_engine {
   void* enc_in = nullptr;        // [emb][input_depth]
   void* enc_in_p[3] = {};        // f32 engine: its three bf16 planes
   bool x6 = false;               // f32 engine: the encoder's dense layers multiply on the bf16 pipes (three planes per operand)
-  // f32 engine of >= kDecodeX6MinBatch slots (round 5): the DECODE step's dense layers take the same three-plane tiles.
-  // At 64 rows per row group the step is launch latency and the 32 x 32 whole-K tiles on the f32 instruction are the
-  // measured optimum; at 312 rows per group (1250 slots) those tiles are COMPUTE: rocprofv3 of the
-  // refilled corpus pass (profiles/r5_refill_f32_kernel_stats.csv) has the four dense launches of a layer at
-  // 68 + 67 + 38 + 28 us against 54 + 47 us of attention -- 95 GFLOP per step on a 157 TF/s instruction, with the folded
-  // projections' extra flops on top.  Such an engine therefore runs the step WITHOUT the folds and the split residual form
-  // (the launches the three-plane kernel has epilogues for: QKV, out-projection + residual, cross query, GEGLU, logits),
-  // six bf16 instructions per f32 product at 16x the rate.  The choice is per ENGINE (its max_batch), never per call or
-  // per step: a row's numbers do not change when its group shrinks.
-  bool dec_x6 = false;
-  void* logits_p[3] = {};
   float* enc_norm = nullptr;     // [emb] f32
   float* embedding = nullptr;    // [V][emb] f32
   void* logits_w = nullptr;      // [V][emb] (decoder_norm folded)
@@ -422,11 +408,9 @@ int build_attention(mt3_engine* e, const std::string& prefix, const float* scale
     put_transposed(t, emb, 2 * hd, *v, scale);
     if ((rc = upload_ct(e, t, &L->wqkv))) return rc;
     if ((rc = upload_ct(e, ot, &L->wo))) return rc;
-    if (encoder || e->dec_x6) {
+    if (encoder) {
       if ((rc = upload_planes(e, t, L->wqkv_p))) return rc;
       if ((rc = upload_planes(e, ot, L->wo_p))) return rc;
-    }
-    if (encoder) {
       if ((rc = upload_mx8(e, t, 3 * hd, emb, &L->wqkv_q, &L->wqkv_sc))) return rc;
       if ((rc = upload_mx8(e, ot, emb, hd, &L->wo_q, &L->wo_sc))) return rc;
     }
@@ -440,10 +424,6 @@ int build_attention(mt3_engine* e, const std::string& prefix, const float* scale
     if ((rc = upload_planes(e, tkv, L->wkv_x_p))) return rc;
     if ((rc = upload_mx8(e, tkv, 2 * hd, emb, &L->wkv_x_q, &L->wkv_x_sc))) return rc;
     if ((rc = upload_ct(e, ot, &L->wo_x))) return rc;
-    if (e->dec_x6) {
-      if ((rc = upload_planes(e, tq, L->wq_x_p))) return rc;
-      if ((rc = upload_planes(e, ot, L->wo_x_p))) return rc;
-    }
   }
   return MT3_OK;
 }
@@ -597,11 +577,9 @@ int build_mlp(mt3_engine* e, const std::string& prefix, const float* scale, Laye
   put_transposed(ot, mlp, 0, *wo, nullptr);
   int rc;
   if ((rc = upload_ct(e, t, &L->wi))) return rc;
-  if (encoder || e->dec_x6) {
+  if (encoder) {
     if ((rc = upload_planes(e, t, L->wi_p))) return rc;
     if ((rc = upload_planes(e, ot, L->wo_mlp_p))) return rc;
-  }
-  if (encoder) {
     if ((rc = upload_mx8(e, t, 2 * mlp, emb, &L->wi_q, &L->wi_sc))) return rc;
     if ((rc = upload_mx8(e, ot, emb, mlp, &L->wo_mlp_q, &L->wo_mlp_sc))) return rc;
   }
@@ -694,11 +672,6 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     return g;
   };
   const int nrm = split ? 2 : 1;
-  // mt3_engine::dec_x6: the same product on the bf16 pipes, f32 operands as three planes (no split form, no folds there)
-  auto x6 = [&](const void* A, int K, void* (&W)[3], void* out, int N, int ldo, bool norm, int epi) {
-    mt3k::GemmArgs g = gemm_args(A, W[0], out, rows, N, K, ldo);
-    return mt3k::launch_gemm_x6(g, W[1], W[2], norm, epi, s);
-  };
   char* qkv_d = static_cast<char*>(e->qkv_d) + static_cast<size_t>(row0) * 3 * hd * es;
   char* attn_d = static_cast<char*>(e->attn_d) + static_cast<size_t>(row0) * hd * es;
   char* q_d = static_cast<char*>(e->q_d) + static_cast<size_t>(row0) * hd * es;
@@ -708,7 +681,6 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
   int* step = e->step + row0;                    // per-row position counters
   if (op == 8 * nl) {
     if (fold) return MT3_OK;                  // the logits projection rode in the last layer's MLP out-projection launch
-    if (e->dec_x6) return x6(y, emb, e->logits_p, logits, c.vocab_size, c.vocab_size, true, MT3_EPI_STORE);
     return mt3k::launch_gemm(dt, normed(e->logits_w, logits, c.vocab_size, c.vocab_size), !split, nrm, MT3_EPI_F32,
                              small, s);
   }
@@ -738,7 +710,6 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
         g.n_split = 3 * hd;
         return mt3k::launch_gemm(dt, g, false, 2, mt3k::kEpiStoreQ, small, s);
       }
-      if (e->dec_x6) return x6(y, emb, L.wqkv_p, qkv_d, 3 * hd, 3 * hd, true, MT3_EPI_STORE);
       return mt3k::launch_gemm(dt, normed(L.wqkv, qkv_d, 3 * hd, 3 * hd), !split, nrm, MT3_EPI_STORE, small, s);
     case 1: {
       if (skip & 1) return MT3_OK;
@@ -780,11 +751,9 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
         g.n_split = emb;
         return mt3k::launch_gemm(dt, g, false, 0, mt3k::kEpiResidQ, small, s);
       }
-      if (e->dec_x6) return x6(attn_d, hd, L.wo_p, y, emb, emb, false, MT3_EPI_RESID);
       return mt3k::launch_gemm(dt, resid(attn_d, L.wo, hd), false, 0, MT3_EPI_RESID, small, s);
     case 3:
       if (e->q_fold) return MT3_OK;           // folded into ops 0 and 2
-      if (e->dec_x6) return x6(y, emb, L.wq_x_p, q_d, hd, hd, true, MT3_EPI_STORE);
       return mt3k::launch_gemm(dt, normed(L.wq_x, q_d, hd, hd), !split, nrm, MT3_EPI_STORE, small, s);
     case 4: {
       if (skip & 2) return MT3_OK;
@@ -812,10 +781,8 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
       return mt3k::launch_decode_attention(dt, x, s);
     }
     case 5:
-      if (e->dec_x6) return x6(attn_d, hd, L.wo_x_p, y, emb, emb, false, MT3_EPI_RESID);
       return mt3k::launch_gemm(dt, resid(attn_d, L.wo_x, hd), false, 0, MT3_EPI_RESID, small, s);
     case 6:
-      if (e->dec_x6) return x6(y, emb, L.wi_p, h_d, 2 * c.mlp_dim, c.mlp_dim, true, MT3_EPI_GEGLU);
       return mt3k::launch_gemm(dt, normed(L.wi, h_d, 2 * c.mlp_dim, c.mlp_dim), !split, nrm, MT3_EPI_GEGLU, small, s);
     default:
       if (fold) {
@@ -837,7 +804,6 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
         g.k_split = c.mlp_dim;
         return mt3k::launch_gemm(dt, g, false, 0, mt3k::kEpiResidS, small, s);
       }
-      if (e->dec_x6) return x6(h_d, c.mlp_dim, L.wo_mlp_p, y, emb, emb, false, MT3_EPI_RESID);
       return mt3k::launch_gemm(dt, resid(h_d, L.wo_mlp, c.mlp_dim), false, 0, MT3_EPI_RESID, small, s);
   }
 }
@@ -956,7 +922,7 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   if (cfg->dense_dtype == MT3_FP8_E4M3 && (cfg->compute_dtype != MT3_BF16 || cfg->emb_dim > 1024))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: the MXFP8 dense path goes with compute_dtype MT3_BF16 and emb_dim <= 1024");
   if (cfg->options & ~(MT3_OPT_SINGLE_RESIDUAL_STREAM | MT3_OPT_SEPARATE_PROJECTIONS | MT3_OPT_ENCODER_SINGLE_RESIDUAL_STREAM |
-                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_ENCODER_F32_MFMA | MT3_OPT_SPIN_WAITS | MT3_OPT_DECODE_F32_MFMA))
+                       MT3_OPT_SEPARATE_QKV_PROJECTION | MT3_OPT_NO_ROW_GROUPS | MT3_OPT_ENCODER_F32_MFMA | MT3_OPT_SPIN_WAITS))
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_create: unknown bit in options");
   mt3_engine* e = new (std::nothrow) mt3_engine();
   if (!e) return mt3::fail(MT3_ERR_INVALID, "out of host memory");
@@ -968,7 +934,6 @@ int mt3_engine_create(const mt3_engine_config* cfg, mt3_engine** out) {
   e->dense_fp8 = cfg->dense_dtype == MT3_FP8_E4M3;
   e->x6 = cfg->compute_dtype == MT3_F32 && !(cfg->options & MT3_OPT_ENCODER_F32_MFMA);
   e->spin_waits = (cfg->options & MT3_OPT_SPIN_WAITS) != 0;
-  e->dec_x6 = e->x6 && cfg->max_batch >= kDecodeX6MinBatch && !(cfg->options & MT3_OPT_DECODE_F32_MFMA);
   e->esize = cfg->compute_dtype == MT3_BF16 ? 2 : 4;
   e->kv_fp8 = cfg->kv_cache_dtype == MT3_FP8_E4M3;
   e->kv_esize = e->kv_fp8 ? 1 : e->esize;
@@ -1051,8 +1016,7 @@ int mt3_engine_finalize(mt3_engine* e) {
     if ((rc = upload_f32(e, w->data, &e->embedding))) return rc;
   }
   e->dec.resize(c.num_decoder_layers);
-  // (a large f32 engine's decode step runs on the three-plane tiles: single residual stream, no folded projections)
-  const bool single_stream = (c.options & MT3_OPT_SINGLE_RESIDUAL_STREAM) != 0 || e->dec_x6;
+  const bool single_stream = (c.options & MT3_OPT_SINGLE_RESIDUAL_STREAM) != 0;
   const bool q_fold = emb % 64 == 0 && (emb <= 512 || emb == 768) && !single_stream &&
                       !(c.options & MT3_OPT_SEPARATE_PROJECTIONS);
   e->q_fold = q_fold;
@@ -1093,7 +1057,6 @@ int mt3_engine_finalize(mt3_engine* e) {
     std::vector<float> t(static_cast<size_t>(c.vocab_size) * emb);
     put_transposed(t, emb, 0, *w, sn);
     if ((rc = upload_ct(e, t, &e->logits_w))) return rc;
-    if (e->dec_x6 && (rc = upload_planes(e, t, e->logits_p))) return rc;
   }
   // ---- sinusoidal table (layers.py:51-82): [sin | cos] halves, scale = -ln(10000)/(emb/2 - 1)
   {

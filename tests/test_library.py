@@ -35,7 +35,7 @@ def test_argument_errors_are_reported_not_swallowed():
     assert b"hop_width" in lib.mt3_last_error()
     cfg = _lib.EngineConfig(1536, 512, 6, 32, 1024, 8, 8, 512, 256, 1024, 8, _lib.MT3_BF16, 1)   # head_dim 32
     assert lib.mt3_engine_create(C.byref(cfg), C.byref(h)) == _lib.MT3_ERR_INVALID
-    cfg = _lib.EngineConfig(1536, 512, 6, 64, 1024, 8, 8, 512, 256, 1024, 8, _lib.MT3_BF16, 1, 0, 0, 1 << 8)      # unknown option
+    cfg = _lib.EngineConfig(1536, 512, 6, 64, 1024, 8, 8, 512, 256, 1024, 8, _lib.MT3_BF16, 1, 0, 0, 1 << 7)      # unknown option
     assert lib.mt3_engine_create(C.byref(cfg), C.byref(h)) == _lib.MT3_ERR_INVALID
     assert not hasattr(lib, "mt3_debug_set_knob") and not hasattr(lib, "mt3_debug_engine_decode_split")   # pruned in r4
     assert lib.mt3_engine_decode_wait(None, None) == _lib.MT3_ERR_INVALID
