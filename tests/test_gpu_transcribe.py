@@ -112,6 +112,24 @@ def test_natural_eos_only_and_small_engines():
             assert bool((ref == 1).any()), "the case should contain rows that emit EOS"
 
 
+def test_mxfp8_encoder_and_e4m3_caches_through_the_staging_ring():
+    """BASELINE configs[4]'s ingredients together: the MXFP8 encoder writes a chunk's cross-K/V as bf16 into the landing
+    buffer, the quantiser turns them into e4m3 rows + power-of-two scales IN THE STAGING CHUNK, and the refill copies rows
+    and scales into the slot's caches.  Same ids as plain calls of the same engine."""
+    B, N, S = 24, 100, 96
+    eng = _engine("bfloat16", B, kv="fp8_e4m3", dense="fp8_e4m3", dec_layers=2)
+    lm = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(N, seed=41), None)
+    lens = _lengths(N, 30, 12, S, seed=9)
+    try:
+        ref = _reference(eng, lm, S, lens, False, B)
+        eng.debug_set_eos_schedule(lens)
+        got = eng.transcribe(lm, num_steps=S)
+    finally:
+        eng.debug_set_eos_schedule(None)
+    assert torch.equal(got, ref), ((got != ref).any(1).nonzero().flatten().tolist()[:8], eng.transcribe_stats)
+    assert eng.status(_lib.STATUS_DENSE_FP8) == 1 and eng.status(_lib.STATUS_KV_FP8) == 1
+
+
 def test_a_long_queue_through_few_slots_keeps_the_ring_turning():
     """More segments than the staging ring holds (8 chunks): chunks are reused many times, consumers give them back at the
     poll after they took them.  24 slots, chunks of 24, 700 short segments."""
