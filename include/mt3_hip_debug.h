@@ -38,8 +38,10 @@ int mt3_debug_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int
 int mt3_debug_engine_set_eos_schedule(mt3_engine* e, const int32_t* h_lengths, int32_t n);
 
 /* mt3_engine_transcribe with the two schedule parameters the product fixes, for A/B measurements: poll_steps = decode
- * steps between two refill polls of a row group (0: the product's 32), row_groups = 1 .. 4 (0: the product's rule).  Same
- * ids whatever the values (tests/test_gpu_transcribe.py). */
+ * steps between two refill polls of a row group (0: the product's 4), row_groups = 1 .. 4 (0: the product's rule).  Same
+ * ids whatever the values (tests/test_gpu_transcribe.py).  row_groups + 16: the encoder passes of the refill chunks are
+ * LEFT OUT -- differential timing only, the ids of refilled segments are garbage (under an imposed EOS schedule the
+ * decode does the same work, so the difference of two runs is what those passes cost the job). */
 int mt3_debug_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
                                 int32_t poll_steps, int32_t row_groups, int32_t* d_ids, mt3_transcribe_stats* h_stats,
                                 void* stream);

@@ -2072,7 +2072,7 @@ static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out,
 }
 
 // the producer side of the feed (calling thread, caller's stream)
-static int produce_chunks(mt3_engine* e, Feed& f, const float* d_inputs, hipStream_t s) {
+static int produce_chunks(mt3_engine* e, Feed& f, const float* d_inputs, hipStream_t s, bool skip_encoder) {
   const mt3_engine_config& c = e->cfg;
   const size_t seg_floats = static_cast<size_t>(c.input_length) * c.input_depth;
   const size_t row = static_cast<size_t>(c.num_heads) * c.input_length * 64;
@@ -2102,7 +2102,9 @@ static int produce_chunks(mt3_engine* e, Feed& f, const float* d_inputs, hipStre
     CrossDst dst;
     dst.kv = kv.data();
     dst.scale = e->kv_fp8 ? sc.data() : nullptr;
-    rc = encode_impl(e, d_inputs + static_cast<size_t>(first - pad) * seg_floats, pad + n, nullptr, dst, s);
+    // (skip_encoder: mt3_debug_engine_transcribe's differential timing -- the chunk goes on offer with whatever the staging
+    // ring holds; under an imposed EOS schedule the decode does exactly the same work)
+    if (!skip_encoder) rc = encode_impl(e, d_inputs + static_cast<size_t>(first - pad) * seg_floats, pad + n, nullptr, dst, s);
     if (rc == MT3_OK && wait_stream(e, kMaxGroups, s) != hipSuccess) rc = mt3::fail(MT3_ERR_HIP, "mt3_engine_transcribe: encoder pass failed");
     if (rc != MT3_OK) break;
     {
@@ -2128,7 +2130,8 @@ static int produce_chunks(mt3_engine* e, Feed& f, const float* d_inputs, hipStre
 
 // poll_steps / groups_override: 0 = the product's choice (mt3_debug_engine_transcribe sets them for A/B runs)
 static int transcribe_impl(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
-                           int32_t* d_ids, mt3_transcribe_stats* h_stats, void* stream, int poll_steps, int groups_override) {
+                           int32_t* d_ids, mt3_transcribe_stats* h_stats, void* stream, int poll_steps, int groups_override,
+                           bool skip_encoder = false) {
   if (!e || !e->finalized) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: engine not finalized");
   if (e->pending.active)
     return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: a decode is in flight (MT3_DECODE_ASYNC): call mt3_engine_decode_wait first");
@@ -2224,7 +2227,7 @@ static int transcribe_impl(mt3_engine* e, const float* d_inputs, int32_t n_segme
     feed_fail(feed);
     rc = mt3::fail(MT3_ERR_HIP, "mt3_engine_transcribe: could not start a row group's worker thread");
   } else if (n_segments > S) {
-    rc = produce_chunks(e, feed, d_inputs, s);
+    rc = produce_chunks(e, feed, d_inputs, s, skip_encoder);
   }
   const std::string producer_err = rc != MT3_OK ? mt3_last_error() : "";
   for (int g = 0; g < p.posted; ++g) worker_wait(e, g);
@@ -2263,9 +2266,13 @@ int mt3_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segmen
 int mt3_debug_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
                                 int32_t poll_steps, int32_t row_groups, int32_t* d_ids, mt3_transcribe_stats* h_stats,
                                 void* stream) {
+  // row_groups + 16: the encoder passes of the refill chunks are LEFT OUT (ids of refilled segments are garbage; under an
+  // imposed EOS schedule the decode does the same work, so the difference of two runs is what the passes cost the job)
+  const bool skip_encoder = row_groups >= 16;
+  if (skip_encoder) row_groups -= 16;
   if (poll_steps < 0 || poll_steps > 1024 || row_groups < 0 || row_groups > kMaxGroups)
-    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_transcribe: poll_steps in [0, 1024], row_groups in [0, 4]");
-  return transcribe_impl(e, d_inputs, n_segments, num_steps, flags, d_ids, h_stats, stream, poll_steps, row_groups);
+    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_transcribe: poll_steps in [0, 1024], row_groups in [0, 4] (+ 16)");
+  return transcribe_impl(e, d_inputs, n_segments, num_steps, flags, d_ids, h_stats, stream, poll_steps, row_groups, skip_encoder);
 }
 
 int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t* d_ids,

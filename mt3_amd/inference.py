@@ -196,6 +196,30 @@ class InferenceModel(object):
                                                        encoding_spec=self.encoding_spec)
         return result["est_ns"]
 
+    def transcribe_many(self, audios: Sequence[Any]) -> List[Any]:
+        """Several files as ONE job (no counterpart in the notebook, which loops `model(audio)` over files): the segments of
+        all files go through the engine's decode slots in one refilled call -- a finished slot restarts on the next
+        segment, whichever file it belongs to -- and every file's tokens then become notes on their own (the note state
+        machine is sequential within a file and independent across files, mt3/metrics_utils.py:92-116).  Returns one
+        NoteSequence per file, each identical to `self(audio)`."""
+        import torch
+        per_file, feats = [], []
+        for audio in audios:
+            examples = self.preprocess(self.audio_to_dataset(audio))
+            per_file.append(examples)
+            feats.append(self._logmel_dev)
+        self._logmel_dev = None
+        if not per_file:
+            return []
+        tokens = self.predict_tokens({"encoder_input_tokens": torch.cat(feats, 0)})
+        out, at = [], 0
+        for examples in per_file:
+            preds = [self.postprocess(t, ex) for t, ex in zip(tokens[at:at + len(examples)], examples)]
+            at += len(examples)
+            out.append(metrics_utils.event_predictions_to_ns(preds, codec=self.codec,
+                                                             encoding_spec=self.encoding_spec)["est_ns"])
+        return out
+
     # ------------------------------------------------------------------ host preprocessing
     def audio_to_dataset(self, audio):
         frames, frame_times = self._audio_to_frames(audio)

@@ -86,3 +86,21 @@ def test_one_file_gives_the_same_notes_in_one_refilled_call_and_in_the_reference
     assert b.engine_slots == 8 and b.rows_per_engine_call == [8, 8, 8, 8, 8, 3]
     assert len(na.notes) >= 20
     assert _tuples(na) == _tuples(nb) and na.total_time == nb.total_time
+
+
+def test_several_files_as_one_job_give_each_file_its_own_notes():
+    """`transcribe_many`: the segments of five files of different lengths share the engine's slots in one refilled call;
+    every file's notes equal what `model(audio)` returns for it alone."""
+    cfg = network.T5Config(dtype="float32", **CFG)
+    params = synthetic.boost_note_events(network.init_random_params(cfg, seed=1, norm_scale_jitter=0.1), eos=3.0)
+    audio = synthetic.synth_audio(30, seed=6, device="cpu").reshape(-1).numpy()
+    cuts = [0, 5 * 32768 + 100, 5 * 32768 + 100 + 40000, 17 * 32768, 17 * 32768 + 128, 29 * 32768 + 5555]
+    files = [audio[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    m = inference.InferenceModel(params, "mt3", config=cfg, max_slots=16)
+    together = m.transcribe_many(files)
+    assert m.rows_per_engine_call == [sum(-(-(len(f) // 128 + 1) // 256) for f in files)] and m.engine_slots == 16
+    assert len(together) == len(files) and sum(len(ns.notes) for ns in together) >= 20
+    for f, ns in zip(files, together):
+        alone = m(f)
+        assert _tuples(ns) == _tuples(alone) and ns.total_time == alone.total_time
+    assert m.transcribe_many([]) == []
