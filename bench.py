@@ -54,13 +54,18 @@ FRONTEND_SOURCES = ("frontend.hip", "frontend_core.h", "frontend_tables.h")
 
 
 def kernel_source_hash(files=("attention.hip", "device.h", "kernels.h")):
-    """Identity of the kernel a PMC file was collected from: sha256 over the sources the decode-attention kernels
-    (default) are compiled from (a change to any of them invalidates a committed traffic ratio)."""
+    """Identity of the kernel a PMC file was collected from: sha256 over the CODE of the sources the decode-attention
+    kernels (default) are compiled from -- comments and white space removed, so that rewording a comment does not throw a
+    measured traffic ratio away while any change to the code does."""
+    import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mt3_amd", "csrc")
     for f in files:
-        with open(os.path.join(d, f), "rb") as fh:
-            h.update(f.encode() + b"\0" + fh.read())
+        with open(os.path.join(d, f), "r", errors="replace") as fh:
+            src = fh.read()
+        src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)          # block comments
+        src = re.sub(r"//[^\n]*", " ", src)                         # line comments
+        h.update(f.encode() + b"\0" + " ".join(src.split()).encode())
     return h.hexdigest()[:16]
 
 

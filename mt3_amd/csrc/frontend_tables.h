@@ -11,8 +11,8 @@
 // Table arithmetic (round 5).  TensorFlow builds both the Hann window and the mel matrix in FLOAT32 -- tf.signal.stft's
 // window_fn and linear_to_mel_weight_matrix default to dtype=tf.float32 and the reference passes none
 // (mt3/spectral_ops.py:42-47,69-71) -- so `tf32 = true` (the default of mt3_frontend_config.table_dtype) evaluates them
-// in float32 in TF's op order [restated from the TF sources from memory, as oracle/frontend.py:mel_weight_matrix_tf32 /
-// hann_periodic_tf32 do]: linspace as start + delta * i, _hertz_to_mel as 1127 * log(1 + f / 700) with a plain log,
+// in float32 in TF's op order [restated from the TF sources from memory; the test oracle's mel_weight_matrix_tf32 /
+// hann_periodic_tf32 are the same rule in numpy]: linspace as start + delta * i, _hertz_to_mel as 1127 * log(1 + f / 700) with a plain log,
 // the slopes as f32 quotients, the window as 0.5 - 0.5 * cos(2 pi f32 * k / N) -- every +, -, *, / one IEEE float32
 // operation, and the two transcendental functions CORRECTLY ROUNDED to float32 (evaluated in double, rounded once).  That
 // last choice is deliberate: float32 `log` is not correctly rounded in any of the libraries at hand (numpy's differs
