@@ -422,7 +422,9 @@ def test_row_group_counts_follow_operand_type_and_batch(dtype, B, groups, option
         assert torch.equal(a, b), kw
     full = eng.decode(num_steps=L, single_stream=True)
     ee = eng.decode(num_steps=L, early_exit=True)
-    assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == groups and torch.equal(ee, full)
+    # under early exit f32 follows the bf16 rule since round 5 (two groups below 512 rows: the ragged regime is latency)
+    ee_groups = groups if dtype == "bfloat16" or B < 256 else 2
+    assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == ee_groups and torch.equal(ee, full)
 
 
 def test_bench_batch_256_bf16_against_the_f32_engine_at_all_1024_positions():
