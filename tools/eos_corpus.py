@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--single-stream", action="store_true")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--spin-waits", action="store_true", help="MT3_OPT_SPIN_WAITS: the workers spin as in round 4")
+    ap.add_argument("--options", type=int, default=0, help="mt3_engine_config.options bits")
     ap.add_argument("--decode-probe", action="store_true",
                     help="also time one canonical full-length decode of `--slots` rows (ms, host CPU seconds)")
     ap.add_argument("--polls", default="0", help="refill mode: comma list of poll intervals to try (0 = the product's)")
@@ -49,7 +50,7 @@ def main():
     N, S, L = args.segments, args.slots, 1024
     cfg = network.T5Config(dtype=args.dtype, kv_dtype=args.kv_dtype)
     eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=S,
-                              options=_lib.OPT_SPIN_WAITS if args.spin_waits else 0)
+                              options=(_lib.OPT_SPIN_WAITS if args.spin_waits else 0) | args.options)
     eng.load_params(network.init_random_params(cfg, seed=0))
     vocab = vocabularies.vocabulary_from_codec(vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1)))
     audio = torch.cat([synthetic.synth_audio(min(1024, N - s), seed=1000 + s) for s in range(0, N, 1024)])
@@ -108,7 +109,7 @@ def main():
     ll = np.minimum(lens, args.decode_steps).astype(np.float64)
     live_bytes = nl * float((kv1 * (ll * (ll + 1) / 2) + (kv1 + qo) * ll).sum() + ((kv1 * 256 + qo) * ll).sum())
     out = {"segments": N, "slots": S, "dtype": args.dtype + ("+fp8kv" if args.kv_dtype else ""),
-           "spin_waits": args.spin_waits,
+           "spin_waits": args.spin_waits, "options": args.options,
            "lengths": {"mean": float(ll.mean()), "max": int(ll.max())}, "live_row_kv_bytes": live_bytes,
            "single_stream": args.single_stream}
     hosts = {}
