@@ -41,6 +41,7 @@
 #include <vector>
 
 #include "common.h"
+#include "feed.h"
 #include "kernels.h"
 
 namespace mt3k {
@@ -104,7 +105,7 @@ constexpr int kVarBeam = 4, kVarForced = 8, kVarRetire = 16, kVarEos = 32, kVarS
 constexpr int kMaxGroups = 4;
 // staging ring of mt3_engine_transcribe: cross-attention K/V of segments that wait for a slot, kStageChunks chunks of up
 // to kStageChunkCap segments each (one encoder pass per chunk)
-constexpr int kStageChunks = 8, kStageChunkCap = 64, kStageMinBatch = 8;
+constexpr int kStageChunks = mt3feed::kStageChunks, kStageChunkCap = 64, kStageMinBatch = 8;
 constexpr int kStreamPollSteps = 4;     // steps between two refill polls of a row group.  Drained polls, f32, 10,000 ragged segments:
                                         // 32 / 16 / 8 steps -> 2395 / 2417 / 2423 audio-s/s at 1250 slots, 1861 / 1889 / 1905 at 256
                                         // (a finished slot idles half an interval on average, a drained poll costs a bubble of
@@ -1824,93 +1825,14 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
 }
 
 // ------------------------------------------------------------------------------------------- in-flight batching
-// mt3_engine_transcribe (mt3_hip.h): the engine's max_batch decode slots stay full while there are segments left.
-//
-//   producer  the CALLING thread, on the caller's stream: encoder passes over chunks of up to stage_cap segments, each
-//             into one chunk of the staging ring; a chunk is on offer once its pass has finished on the device
-//   consumers the row groups' worker threads: at every poll (32 steps; the stream is drained there as under
-//             MT3_DECODE_EARLY_EXIT) a group takes as many encoded segments off the ring as it has finished slots and
-//             issues the refill launches (decode_ops.hip) on its own stream; what it took at one poll it gives back to
-//             the producer at the NEXT poll, when the drain has proven the copies done
-// Everything the two sides share is host state under one mutex -- no cross-stream events, nobody waits on the device
-// for the other side.  The ring is sized so that a poll's demand is normally on offer (8 chunks of 64 segments).
-struct StageChunk {
-  int first_seg = 0;   // first segment on offer in this chunk
-  int n = 0;           // segments on offer
-  int pad = 0;         // entries in front of them: a short last chunk is encoded together with the `pad` segments before
-                       // it (already handed out earlier), so that every pass is one of >= kStageMinBatch segments and takes
-                       // the same tiles as a full one -- a segment's numbers do not depend on where the corpus ends
-  int batch = 0;       // encoder batch of the pass = pad + n = the plane stride of the chunk's [2][batch][H][T][64] blocks
-  int taken = 0, released = 0;
-};
-
-struct FeedRange {
-  int seq, first_seg, entry0, n, batch;
-};
-
-struct Feed {
-  std::mutex mu;
-  std::condition_variable cv;
-  int n_total = 0;
-  int next_seg = 0;          // first segment not yet handed to an encoder pass
-  int produced = 0;          // chunks on offer so far: sequence numbers [0, produced); sequence q lives in chunk[q % kStageChunks]
-  int head = 0;              // sequence number the consumers take from
-  bool finished = false;     // the producer is done: nothing will be added
-  bool failed = false;       // a group or the producer failed: everybody leaves
-  StageChunk chunk[kStageChunks];
-  int polls = 0, refills = 0, starved = 0;
-};
-
-// up to `want` encoded segments off the ring (whole runs of one chunk each); *dry: nothing is left and nothing will come
-static int feed_pop(Feed& f, int want, FeedRange* out, int max_out, bool* dry) {
-  std::lock_guard<std::mutex> lk(f.mu);
-  int n_out = 0;
-  ++f.polls;
-  while (f.head < f.produced) {
-    StageChunk& c = f.chunk[f.head % kStageChunks];
-    if (c.taken == c.n) {
-      ++f.head;
-      continue;
-    }
-    if (want <= 0 || n_out >= max_out) break;
-    const int avail = c.n - c.taken, take = avail < want ? avail : want;
-    out[n_out++] = FeedRange{f.head, c.first_seg + c.taken, c.pad + c.taken, take, c.batch};
-    c.taken += take;
-    want -= take;
-    f.refills += take;
-  }
-  *dry = f.finished && f.head == f.produced;
-  if (want > 0 && !*dry) ++f.starved;
-  return n_out;
-}
-
-static void feed_release(Feed& f, const std::vector<FeedRange>& held) {
-  if (held.empty()) return;
-  {
-    std::lock_guard<std::mutex> lk(f.mu);
-    for (const FeedRange& r : held) f.chunk[r.seq % kStageChunks].released += r.n;
-  }
-  f.cv.notify_all();
-}
-
-static void feed_fail(Feed& f) {
-  {
-    std::lock_guard<std::mutex> lk(f.mu);
-    f.failed = true;
-  }
-  f.cv.notify_all();
-}
-
-// a group with nothing live sleeps here until the encoder delivers (or there is nothing left to wait for)
-static void feed_wait(Feed& f) {
-  std::unique_lock<std::mutex> lk(f.mu);
-  f.cv.wait(lk, [&] {
-    if (f.failed || f.finished) return true;
-    for (int q = f.head; q < f.produced; ++q)
-      if (f.chunk[q % kStageChunks].taken < f.chunk[q % kStageChunks].n) return true;
-    return false;
-  });
-}
+// mt3_engine_transcribe (mt3_hip.h): the engine's max_batch decode slots stay full while there are segments left.  The
+// queue between the encoder passes (producer: the calling thread) and the row groups (consumers) is csrc/feed.h.
+using mt3feed::Feed;
+using mt3feed::FeedRange;
+using mt3feed::feed_fail;
+using mt3feed::feed_pop;
+using mt3feed::feed_release;
+using mt3feed::feed_wait;
 
 static int ensure_stage(mt3_engine* e) {
   if (e->stage_cap) return MT3_OK;
@@ -2024,10 +1946,7 @@ static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out,
       int n_fin = e->h_pinned[r.slot + kMaxGroups * (parity ^ 1)];   // finished slots among the group's r.rows (dropped ones included)
       bool dry = false;
       for (;;) {
-        {
-          std::lock_guard<std::mutex> lk(f.mu);
-          if (f.failed) return MT3_OK;           // somebody else reports the error
-        }
+        if (mt3feed::feed_failed(f)) return MT3_OK;           // somebody else reports the error
         const int refillable = n_fin - (r.rows - cur);
         const int nr = feed_pop(f, refillable, got.data(), static_cast<int>(got.size()), &dry);
         for (int i = 0; i < nr; ++i) {
@@ -2081,19 +2000,8 @@ static int produce_chunks(mt3_engine* e, Feed& f, const float* d_inputs, hipStre
   std::vector<float2*> sc(c.num_decoder_layers, nullptr);
   int rc = MT3_OK;
   for (int q = 0; rc == MT3_OK; ++q) {
-    int first, n;
-    {
-      std::unique_lock<std::mutex> lk(f.mu);
-      if (f.next_seg >= f.n_total) break;
-      StageChunk& ch = f.chunk[q % kStageChunks];          // still holds sequence q - kStageChunks
-      f.cv.wait(lk, [&] { return f.failed || q < kStageChunks || ch.released == ch.n; });
-      if (f.failed) break;
-      first = f.next_seg;
-      n = f.n_total - first < e->stage_cap ? f.n_total - first : e->stage_cap;
-      f.next_seg += n;
-    }
-    int pad = n < min_batch ? min_batch - n : 0;
-    if (pad > first) pad = first;
+    int first, n, pad;
+    if (!mt3feed::feed_claim(f, q, e->stage_cap, min_batch, &first, &n, &pad)) break;
     const size_t chunk = static_cast<size_t>(q % kStageChunks);
     for (int l = 0; l < c.num_decoder_layers; ++l) {
       kv[l] = static_cast<char*>(e->stage_kv[l]) + chunk * 2 * e->stage_cap * row * e->kv_esize;
@@ -2107,24 +2015,9 @@ static int produce_chunks(mt3_engine* e, Feed& f, const float* d_inputs, hipStre
     if (!skip_encoder) rc = encode_impl(e, d_inputs + static_cast<size_t>(first - pad) * seg_floats, pad + n, nullptr, dst, s);
     if (rc == MT3_OK && wait_stream(e, kMaxGroups, s) != hipSuccess) rc = mt3::fail(MT3_ERR_HIP, "mt3_engine_transcribe: encoder pass failed");
     if (rc != MT3_OK) break;
-    {
-      std::lock_guard<std::mutex> lk(f.mu);
-      StageChunk& ch = f.chunk[q % kStageChunks];
-      ch = StageChunk();
-      ch.first_seg = first;
-      ch.n = n;
-      ch.pad = pad;
-      ch.batch = pad + n;
-      ++f.produced;
-    }
-    f.cv.notify_all();
+    mt3feed::feed_publish(f, q, first, n, pad);
   }
-  {
-    std::lock_guard<std::mutex> lk(f.mu);
-    f.finished = true;
-    if (rc != MT3_OK) f.failed = true;
-  }
-  f.cv.notify_all();
+  mt3feed::feed_finish(f, rc != MT3_OK);
   return rc;
 }
 
