@@ -18,7 +18,10 @@
 using namespace mt3feed;
 
 // returns 0 on success, a positive error code otherwise
-extern "C" int feed_stress(int n_total, int slots, int cap, int min_batch, int consumers, unsigned seed, int fail_after_chunks) {
+// prod_us / cons_us: upper bounds of the random delays of an encoder pass / between two polls; max_want: most finished slots a
+// poll reports (0: cap + 2).  Slow consumers fill the ring, so that the producer has to WAIT for chunks to be given back.
+extern "C" int feed_stress(int n_total, int slots, int cap, int min_batch, int consumers, unsigned seed, int fail_after_chunks,
+                           int prod_us, int cons_us, int max_want) {
   Feed f;
   f.n_total = n_total;
   f.next_seg = slots < n_total ? slots : n_total;
@@ -38,7 +41,7 @@ extern "C" int feed_stress(int n_total, int slots, int cap, int min_batch, int c
       if (!feed_claim(f, q, cap, min_batch, &first, &n, &pad)) break;
       if (pad + n > cap && n >= min_batch) bad(1);
       // the "encoder pass": overwrite the chunk's entries (it must have been given back completely by now)
-      std::this_thread::sleep_for(std::chrono::microseconds(rng() % 300));
+      std::this_thread::sleep_for(std::chrono::microseconds(rng() % (prod_us + 1)));
       const size_t base = static_cast<size_t>(q % kStageChunks) * cap;
       for (int i = 0; i < pad + n && i < cap; ++i) ring[base + i] = first - pad + i;
       if (fail_after_chunks > 0 && ++chunks == fail_after_chunks) {
@@ -58,7 +61,7 @@ extern "C" int feed_stress(int n_total, int slots, int cap, int min_batch, int c
       std::vector<FeedRange> held, got(kStageChunks + 2);
       for (;;) {
         // the previous poll's entries are read (the copy kernels) and only then given back
-        std::this_thread::sleep_for(std::chrono::microseconds(rng() % 200));
+        std::this_thread::sleep_for(std::chrono::microseconds(rng() % (cons_us + 1)));
         for (const FeedRange& r : held)
           for (int i = 0; i < r.n; ++i)
             if (ring[static_cast<size_t>(r.seq % kStageChunks) * cap + r.entry0 + i] != r.first_seg + i) bad(2);   // overwritten early
@@ -66,7 +69,7 @@ extern "C" int feed_stress(int n_total, int slots, int cap, int min_batch, int c
         held.clear();
         if (feed_failed(f)) return;
         bool dry = false;
-        const int want = static_cast<int>(rng() % (cap + 3));          // finished slots at this poll (sometimes none)
+        const int want = static_cast<int>(rng() % ((max_want > 0 ? max_want : cap + 2) + 1));   // finished slots at this poll (sometimes none)
         const int nr = feed_pop(f, want, got.data(), static_cast<int>(got.size()), &dry);
         int total = 0;
         for (int i = 0; i < nr; ++i) {
