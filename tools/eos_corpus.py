@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--slots", type=int, default=1250)
     ap.add_argument("--dtype", default="float32", choices=["float32", "bfloat16"])
     ap.add_argument("--kv-dtype", default="", choices=["", "fp8_e4m3"])
+    ap.add_argument("--dense-dtype", default="", choices=["", "fp8_e4m3"])
+    ap.add_argument("--model", default="mt3", choices=["mt3", "base"], help="base = gin/ismir2022/base.gin shape (BASELINE configs[4])")
     ap.add_argument("--mode", default="both", choices=["both", "batch", "refill"])
     ap.add_argument("--eos-mean", type=float, default=300.0)
     ap.add_argument("--eos-sd", type=float, default=100.0)
@@ -48,7 +50,9 @@ def main():
     from mt3_amd import _lib, network, spectrograms, synthetic, vocabularies
 
     N, S, L = args.segments, args.slots, 1024
-    cfg = network.T5Config(dtype=args.dtype, kv_dtype=args.kv_dtype)
+    import dataclasses
+    cfg = dataclasses.replace(network.MT3_BASE if args.model == "base" else network.MT3_SMALL, dtype=args.dtype,
+                              kv_dtype=args.kv_dtype, dense_dtype=args.dense_dtype)
     eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=S,
                               options=(_lib.OPT_SPIN_WAITS if args.spin_waits else 0) | args.options)
     eng.load_params(network.init_random_params(cfg, seed=0))
@@ -108,7 +112,8 @@ def main():
     qo = 2.0 * H * 64 * esz
     ll = np.minimum(lens, args.decode_steps).astype(np.float64)
     live_bytes = nl * float((kv1 * (ll * (ll + 1) / 2) + (kv1 + qo) * ll).sum() + ((kv1 * 256 + qo) * ll).sum())
-    out = {"segments": N, "slots": S, "dtype": args.dtype + ("+fp8kv" if args.kv_dtype else ""),
+    out = {"segments": N, "slots": S, "model": args.model,
+           "dtype": args.dtype + ("+fp8kv" if args.kv_dtype else "") + ("+mxfp8 encoder" if args.dense_dtype else ""),
            "spin_waits": args.spin_waits, "options": args.options,
            "lengths": {"mean": float(ll.mean()), "max": int(ll.max())}, "live_row_kv_bytes": live_bytes,
            "single_stream": args.single_stream}
