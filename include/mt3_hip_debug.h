@@ -39,12 +39,12 @@ int mt3_debug_engine_set_eos_schedule(mt3_engine* e, const int32_t* h_lengths, i
 
 /* mt3_engine_transcribe with the two schedule parameters the product fixes, for A/B measurements: poll_steps = decode
  * steps between two refill polls of a row group (0: the product's 4), row_groups = 1 .. 4 (0: the product's rule).  Same
- * ids whatever the values (tests/test_gpu_transcribe.py).  row_groups + 16: the encoder passes of the refill chunks are
- * LEFT OUT -- differential timing only, the ids of refilled segments are garbage (under an imposed EOS schedule the
- * decode does the same work, so the difference of two runs is what those passes cost the job). */
+ * ids whatever the values (tests/test_gpu_transcribe.py).  skip_encoder_passes != 0: the encoder passes of the refill
+ * chunks are LEFT OUT -- differential timing only, the ids of refilled segments are garbage (under an imposed EOS
+ * schedule the decode does the same work, so the difference of two runs is what those passes cost the job). */
 int mt3_debug_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
-                                int32_t poll_steps, int32_t row_groups, int32_t* d_ids, mt3_transcribe_stats* h_stats,
-                                void* stream);
+                                int32_t poll_steps, int32_t row_groups, int32_t skip_encoder_passes, int32_t* d_ids,
+                                mt3_transcribe_stats* h_stats, void* stream);
 
 /* Fill the engine's self-attention K/V caches (and, with fp8 caches, their scale arrays) with the byte `pattern`
  * (0xFF = NaN in bf16 / f32 / e4m3; 0x7F.. etc.), and with cross != 0 also the cross-attention K/V buffers

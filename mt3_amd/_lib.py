@@ -90,7 +90,7 @@ SIGNATURES = {
     "mt3_engine_decode_forced": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "mt3_engine_status": (C.c_int, [_P, C.c_int32]),
     "mt3_debug_engine_decode": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
-    "mt3_debug_engine_transcribe": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
+    "mt3_debug_engine_transcribe": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P,
                                               C.POINTER(TranscribeStats), _P]),
     "mt3_debug_engine_poison_caches": (C.c_int, [_P, C.c_int32, C.c_int32, _P]),
     "mt3_debug_engine_set_eos_schedule": (C.c_int, [_P, _P, C.c_int32]),

@@ -242,7 +242,6 @@ struct mt3_engine {
   int stage_cap = 0;             // segments per staging chunk (0: staging not allocated yet)
   std::vector<void*> stage_kv;       // per decoder layer: [kStageChunks][2][stage_cap][H][T][64] cache elements
   std::vector<float2*> stage_scale;  // e4m3 caches: [kStageChunks][stage_cap][H][T]
-  mt3_transcribe_stats last_stats{};
   float* cs_y = nullptr;         // compaction scratch: same shapes as y / y_ct / y_ss / qkvf, 4 ints + 2 floats per slot
   void* cs_y_ct = nullptr;
   float* cs_y_ss = nullptr;
@@ -2145,7 +2144,6 @@ static int transcribe_impl(mt3_engine* e, const float* d_inputs, int32_t n_segme
   st.encoder_chunks = feed.produced;
   st.compactions = e->compactions;
   st.used_graph = e->last_used_graph;
-  e->last_stats = st;
   if (h_stats) *h_stats = st;
   if (rc != MT3_OK && !producer_err.empty()) return mt3::fail(rc, producer_err);
   return rc;
@@ -2157,15 +2155,12 @@ int mt3_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segmen
 }
 
 int mt3_debug_engine_transcribe(mt3_engine* e, const float* d_inputs, int32_t n_segments, int32_t num_steps, int32_t flags,
-                                int32_t poll_steps, int32_t row_groups, int32_t* d_ids, mt3_transcribe_stats* h_stats,
-                                void* stream) {
-  // row_groups + 16: the encoder passes of the refill chunks are LEFT OUT (ids of refilled segments are garbage; under an
-  // imposed EOS schedule the decode does the same work, so the difference of two runs is what the passes cost the job)
-  const bool skip_encoder = row_groups >= 16;
-  if (skip_encoder) row_groups -= 16;
+                                int32_t poll_steps, int32_t row_groups, int32_t skip_encoder_passes, int32_t* d_ids,
+                                mt3_transcribe_stats* h_stats, void* stream) {
   if (poll_steps < 0 || poll_steps > 1024 || row_groups < 0 || row_groups > kMaxGroups)
-    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_transcribe: poll_steps in [0, 1024], row_groups in [0, 4] (+ 16)");
-  return transcribe_impl(e, d_inputs, n_segments, num_steps, flags, d_ids, h_stats, stream, poll_steps, row_groups, skip_encoder);
+    return mt3::fail(MT3_ERR_INVALID, "mt3_debug_engine_transcribe: poll_steps in [0, 1024], row_groups in [0, 4]");
+  return transcribe_impl(e, d_inputs, n_segments, num_steps, flags, d_ids, h_stats, stream, poll_steps, row_groups,
+                         skip_encoder_passes != 0);
 }
 
 int mt3_engine_decode(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t flags, int32_t* d_ids,

@@ -231,7 +231,7 @@ class Transformer:
 
     def transcribe(self, encoder_input_tokens, num_steps: Optional[int] = None, beam1: bool = False,
                    use_graph: bool = True, single_stream: bool = False, debug_poll_steps: int = 0,
-                   debug_row_groups: int = 0):
+                   debug_row_groups: int = 0, debug_skip_encoder_passes: bool = False):
         """mt3_engine_transcribe: encode + decode of ANY number of segments through the engine's `max_batch` decode slots
         with in-flight batching -- a slot whose segment has finished restarts on the next one (the reference's loop over
         `.batch(8)` calls of predict_batch_with_aux, NB:295-301, without its batch-synchronous wait for the longest row).
@@ -247,9 +247,10 @@ class Transformer:
         flags = (0 if use_graph else _lib.DECODE_NO_GRAPH) | (_lib.DECODE_BEAM1 if beam1 else 0) | \
             (_lib.DECODE_SINGLE_STREAM if single_stream else 0)
         st = _lib.TranscribeStats()
-        if debug_poll_steps or debug_row_groups:      # mt3_debug_engine_transcribe (A/B measurements only)
+        if debug_poll_steps or debug_row_groups or debug_skip_encoder_passes:      # mt3_debug_engine_transcribe (A/B measurements only)
             _lib.check(self._lib.mt3_debug_engine_transcribe(self._h, x.data_ptr(), N, num_steps or L, flags,
-                                                             debug_poll_steps, debug_row_groups, ids.data_ptr(),
+                                                             debug_poll_steps, debug_row_groups,
+                                                             1 if debug_skip_encoder_passes else 0, ids.data_ptr(),
                                                              C.byref(st), torch.cuda.current_stream().cuda_stream))
         else:
             _lib.check(self._lib.mt3_engine_transcribe(self._h, x.data_ptr(), N, num_steps or L, flags, ids.data_ptr(),

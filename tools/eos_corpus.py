@@ -42,7 +42,8 @@ def main():
     ap.add_argument("--decode-probe", action="store_true",
                     help="also time one canonical full-length decode of `--slots` rows (ms, host CPU seconds)")
     ap.add_argument("--polls", default="0", help="refill mode: comma list of poll intervals to try (0 = the product's)")
-    ap.add_argument("--groups", default="0", help="refill mode: comma list of row-group counts to try (0 = the product's)")
+    ap.add_argument("--groups", default="0", help="refill mode: comma list of row-group counts to try (0 = the product's; "
+                                                  "+ 16: the refill chunks' encoder passes left out, differential timing)")
     args = ap.parse_args()
 
     import numpy as np
@@ -86,7 +87,8 @@ def main():
         with torch.cuda.stream(stream):
             eng.debug_set_eos_schedule(lens)
             ids = eng.transcribe(logmel_all(), num_steps=args.decode_steps, single_stream=args.single_stream,
-                                 debug_poll_steps=variant["poll"], debug_row_groups=variant["groups"])
+                                 debug_poll_steps=variant["poll"], debug_row_groups=variant["groups"] % 16,
+                                 debug_skip_encoder_passes=variant["groups"] >= 16)
             host = vocab.decode_tf(ids).cpu().numpy()
         return host, dict(eng.transcribe_stats)
 
