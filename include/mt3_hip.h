@@ -177,7 +177,12 @@ int64_t mt3_engine_device_bytes(const mt3_engine* e);
 
 /* Transformer.encode (network.py:275-301) + cross-attention K/V of every decoder
  * layer (layers.py:239-240, hoisted out of the decode loop).
- * d_inputs [batch, T, input_depth] f32.  d_encoded_f32 [batch, T, emb] f32 or NULL. */
+ * d_inputs [batch, T, input_depth] f32.  d_encoded_f32 [batch, T, emb] f32 or NULL.
+ * Reproducibility across batch sizes: the f32 engine gives a segment the SAME bits whatever batch it is encoded in (one
+ * tile family at every size since round 5).  The bf16 engine has two tile families -- passes of fewer than 2048 rows
+ * (8 segments at T = 256) take the decode-sized tiles, whose f32 sums are rounded to bf16 in other places -- so a
+ * segment's bf16 encoder output can differ in the last bf16 bit between a pass of < 8 and one of >= 8 segments (both within
+ * the bf16 bounds of DESIGN.md section 4); mt3_engine_transcribe pads its chunks to 8 segments for that reason. */
 int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch,
                       float* d_encoded_f32, void* stream);
 
