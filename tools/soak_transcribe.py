@@ -1,5 +1,5 @@
 """Robustness soak of mt3_engine_transcribe (in-flight batching; round 5): for `--seconds` of wall time, random jobs --
-1 .. 2,500 segments through a 96-slot engine (24-segment... no: 64-segment chunks through the 8-chunk ring), random output
+1 .. 2,500 segments through a `--slots`-slot engine (64-segment chunks through the 8-chunk ring), random output
 lengths (the synthetic EOS schedule per segment, mixed with rows that emit EOS of their own accord and rows that hit the
 step cap), greedy / beam-1, 1 / 2 / 3 / 4 row groups, poll intervals 1 .. 16, graph replay / direct launches, NaN-poisoned
 caches every few jobs -- every job's ids compared with plain batch-synchronous calls of the same engine.  Prints one
