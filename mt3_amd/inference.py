@@ -180,16 +180,11 @@ class InferenceModel(object):
     def __call__(self, audio):
         """1-d numpy array of 16 kHz samples -> NoteSequence."""
         ds = self.audio_to_dataset(audio)
-        examples = self.preprocess(ds)
+        examples = self.preprocess(ds, host_inputs=False)
         # the frontend kernel has already written the feature converter's form of every segment -- [T, 512] rows, 0.0
         # after a short last segment's frames (mt3/models.py:48-98 via models.convert_features) -- and it is still on the
         # device: no host round trip between preprocess and predict_tokens
-        dev = getattr(self, "_logmel_dev", None)
-        if dev is not None and dev.shape[0] == len(examples):
-            batch = {"encoder_input_tokens": dev}
-        else:
-            batch = models.convert_features(examples, self.sequence_length)     # pad/trim to [T, 512] / [1024]
-        self._logmel_dev = None
+        batch, self._logmel_dev = {"encoder_input_tokens": self._logmel_dev}, None
         tokens = self.predict_tokens(batch)
         predictions = [self.postprocess(t, ex) for t, ex in zip(tokens, examples)]
         result = metrics_utils.event_predictions_to_ns(predictions, codec=self.codec,
@@ -205,7 +200,7 @@ class InferenceModel(object):
         import torch
         per_file, feats = [], []
         for audio in audios:
-            examples = self.preprocess(self.audio_to_dataset(audio))
+            examples = self.preprocess(self.audio_to_dataset(audio), host_inputs=False)
             per_file.append(examples)
             feats.append(self._logmel_dev)
         self._logmel_dev = None
@@ -235,9 +230,11 @@ class InferenceModel(object):
         times = np.arange(num_frames) / self.spectrogram_config.frames_per_second
         return frames, times
 
-    def preprocess(self, ds) -> List[Dict[str, Any]]:
+    def preprocess(self, ds, host_inputs: bool = True) -> List[Dict[str, Any]]:
         """split_tokens_to_inputs_length + add_dummy_targets + compute_spectrograms
-        (preprocessors.py:53-57,613-618), batched over all segments in one kernel launch."""
+        (preprocessors.py:53-57,613-618), batched over all segments in one kernel launch.
+        host_inputs=False (what `__call__` / `transcribe_many` pass): the log-mel is left on the device only -- the examples'
+        'inputs' are None -- because the engine reads it there and nothing on that path looks at the host copy."""
         import torch
         frames, times = ds["inputs"], ds["input_times"]
         T, hop = self.inputs_length, self.spectrogram_config.hop_width
@@ -250,8 +247,9 @@ class InferenceModel(object):
             counts.append(len(chunk))
         self._logmel_dev = spectrograms.compute_spectrogram_batch(torch.from_numpy(audio).cuda(), counts,
                                                                   self.spectrogram_config)     # stays on the device
-        logmel = self._logmel_dev.cpu().numpy()             # the examples the reference's preprocess returns are host arrays
-        return [{"inputs": logmel[s, : counts[s]], "input_times": times[s * T:(s + 1) * T],
+        # (the examples the reference's preprocess returns are host arrays)
+        logmel = self._logmel_dev.cpu().numpy() if host_inputs else None
+        return [{"inputs": logmel[s, : counts[s]] if host_inputs else None, "input_times": times[s * T:(s + 1) * T],
                  "raw_inputs": audio[s, : counts[s] * hop], "targets": np.zeros((0,), np.int32)}
                 for s in range(n_seg)]
 
