@@ -33,7 +33,6 @@ from typing import Any, Dict, List, Optional, Sequence
 import numpy as np
 
 from . import metrics_utils
-from . import models
 from . import network
 from . import note_sequences
 from . import spectrograms
