@@ -22,7 +22,10 @@
  *     waits for the device at every poll, and (b) on the row-group schedule
  *     (batches of >= 128 rows, see "Schedule" there) returns only when the decode
  *     has FINISHED on the device, unless the caller passes MT3_DECODE_ASYNC and
- *     joins with mt3_engine_decode_wait (the caller's thread is free in between).
+ *     joins with mt3_engine_decode_wait (the caller's thread is free in between);
+ *     and mt3_engine_transcribe, which returns when the whole job is done (the
+ *     calling thread drives the encoder passes meanwhile).  While they wait for the
+ *     device the engine's threads SLEEP (event polls between naps), they do not spin.
  *   - one engine per (device, stream); an engine is not thread-safe, distinct
  *     engines are independent.  An engine owns up to four worker threads (one
  *     per row group; created with the first decode that needs them, joined by
