@@ -1,0 +1,62 @@
+"""The credited configuration against the ORACLE directly (round 5; VERDICT r4 "next" #2): BASELINE configs[2] -- batch 256,
+float32, the product schedule (four row groups, one captured step graph each) -- with 8 rows sampled across the groups
+and compared token for token with the oracle's own greedy loop on the same log-mel; and the ragged variant: output lengths
+imposed on the engine (synthetic EOS schedule, early exit + row retirement: two row groups, compactions) AND on the
+oracle's greedy loop (`greedy_decode(eos_lengths=...)`, the same rule).  Until round 4 this configuration was tied to the
+oracle only through a chain of engine-vs-engine tests (row groups == one stream == no retirement) hanging off a 32-row
+oracle comparison."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+from mt3_amd import _lib, network, spectrograms, synthetic  # noqa: E402
+from oracle import network as ON  # noqa: E402
+
+ROWS = [0, 37, 63, 64, 127, 128, 200, 255]           # two from each of the four 64-row groups (both ends of a group)
+
+
+def test_batch_256_f32_product_schedule_rows_against_the_oracle():
+    B, S = 256, 256
+    cfg = network.T5Config(dtype="float32")
+    params = network.init_random_params(cfg, seed=0)
+    eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=B)
+    eng.load_params(params)
+    lm = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(B, seed=1000), None)       # bench.py's first batch
+    eng.encode(lm)
+    ids = eng.decode(num_steps=S)
+    assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 4 and eng.status(_lib.STATUS_LAST_DECODE_USED_GRAPH) == 1
+    assert eng.status(_lib.STATUS_GRAPH_FALLBACKS) == 0
+    got = ids[ROWS, :S].cpu().numpy()
+    torch.set_num_threads(16)
+    orc = ON.Oracle(params, ON.T5Config())
+    with torch.no_grad():
+        enc = orc.encode(lm[ROWS].cpu().numpy())
+        ref, logits = orc.greedy_decode(enc, S, return_logits=True)
+    for i, r in enumerate(ROWS):
+        d = np.nonzero(got[i] != ref[i])[0]
+        if d.size:                                    # excusable only on an oracle tie (< 2e-4 sigma)
+            lg = logits[i, int(d[0])].double()
+            top = torch.topk(lg, 2).values
+            assert float((top[0] - top[1]) / lg.std()) < 2e-4, (r, int(d[0]), float((top[0] - top[1]) / lg.std()))
+    assert sum(np.array_equal(got[i], ref[i]) for i in range(len(ROWS))) >= len(ROWS) - 1
+
+    # ---- the ragged variant: the same lengths imposed on both sides
+    lens = np.clip(np.rint(np.random.default_rng(5).normal(90, 40, B)), 1, S).astype(np.int32)
+    lens[ROWS[0]], lens[ROWS[3]], lens[ROWS[5]] = 1, S, 2
+    eng.debug_set_eos_schedule(lens)
+    try:
+        ragged = eng.decode(num_steps=S, early_exit=True)
+        assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 2 and eng.status(_lib.STATUS_LAST_DECODE_COMPACTIONS) >= 1
+    finally:
+        eng.debug_set_eos_schedule(None)
+    got = ragged[ROWS, :S].cpu().numpy()
+    with torch.no_grad():
+        ref = orc.greedy_decode(enc, S, eos_lengths=lens[ROWS])
+    for i, r in enumerate(ROWS):
+        n = int(lens[r])
+        assert ref[i, n - 1] == 1 and not ref[i, n:].any()                   # the oracle's loop obeys the schedule
+        if np.array_equal(got[i, : n - 1], ref[i, : n - 1]):                 # (a tie flip before the EOS is reported above)
+            assert np.array_equal(got[i], ref[i]), r
+    assert sum(np.array_equal(got[i], ref[i]) for i in range(len(ROWS))) >= len(ROWS) - 1
