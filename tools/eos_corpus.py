@@ -147,6 +147,7 @@ def main():
             out[mode] = {"audio_s_per_s": N * SEG_SECONDS / dt, "seconds": dt, "host_cpu_s": cpu,
                          "hbm_frac_on_live_bytes_whole_pass": live_bytes / dt / 1e9 / HBM_PEAK_GBS,
                          "decoded_mean_len": float(got_len.mean()), "row_groups": eng.status(_lib.STATUS_LAST_DECODE_GROUPS),
+                         "tokens_sha16": __import__("hashlib").sha256(np.ascontiguousarray(host).tobytes()).hexdigest()[:16],
                          "graph_fallbacks": eng.status(_lib.STATUS_GRAPH_FALLBACKS), **info}
     finally:
         eng.debug_set_eos_schedule(None)
