@@ -56,7 +56,8 @@ FRONTEND_SOURCES = ("frontend.hip", "frontend_core.h", "frontend_tables.h")
 def kernel_source_hash(files=("attention.hip", "device.h", "kernels.h")):
     """Identity of the kernel a PMC file was collected from: sha256 over the CODE of the sources the decode-attention
     kernels (default) are compiled from -- comments and white space removed, so that rewording a comment does not throw a
-    measured traffic ratio away while any change to the code does."""
+    measured traffic ratio away while any change to the code does.  Of kernels.h (the launcher interface of ALL kernels)
+    only what those kernels see counts: the text of `struct DecAttnArgs`."""
     import re
     h = hashlib.sha256()
     d = os.path.join(ROOT, "mt3_amd", "csrc")
@@ -65,6 +66,9 @@ def kernel_source_hash(files=("attention.hip", "device.h", "kernels.h")):
             src = fh.read()
         src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)          # block comments
         src = re.sub(r"//[^\n]*", " ", src)                         # line comments
+        if f == "kernels.h":
+            m = re.search(r"struct DecAttnArgs\s*\{.*?\n\};", src, flags=re.S)
+            src = m.group(0) if m else src
         h.update(f.encode() + b"\0" + " ".join(src.split()).encode())
     return h.hexdigest()[:16]
 

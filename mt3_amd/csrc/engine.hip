@@ -665,10 +665,12 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     g.a_ss = y_ss;
     return g;
   };
+  const int beside = rows < B_total ? 1 : 0;     // this step belongs to one of several row groups (GemmArgs::concurrent)
   auto resid = [&](const void* A, const void* Wt, int K) {
     mt3k::GemmArgs g = gemm_args(A, Wt, y, rows, emb, K, emb);
     g.out_ct = y_copy;
     g.out_ss = y_ss;
+    g.concurrent = beside;
     return g;
   };
   const int nrm = split ? 2 : 1;
@@ -782,8 +784,11 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     }
     case 5:
       return mt3k::launch_gemm(dt, resid(attn_d, L.wo_x, hd), false, 0, MT3_EPI_RESID, small, s);
-    case 6:
-      return mt3k::launch_gemm(dt, normed(L.wi, h_d, 2 * c.mlp_dim, c.mlp_dim), !split, nrm, MT3_EPI_GEGLU, small, s);
+    case 6: {
+      mt3k::GemmArgs g = normed(L.wi, h_d, 2 * c.mlp_dim, c.mlp_dim);
+      g.concurrent = beside;
+      return mt3k::launch_gemm(dt, g, !split, nrm, MT3_EPI_GEGLU, small, s);
+    }
     default:
       if (fold) {
         // MLP out-projection + residual, and -- as extra output columns with a two-source K = mlp + emb -- what consumes
@@ -802,6 +807,7 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
         g.A2 = y_ct;
         g.lda2 = emb;
         g.k_split = c.mlp_dim;
+        g.concurrent = beside;
         return mt3k::launch_gemm(dt, g, false, 0, mt3k::kEpiResidS, small, s);
       }
       return mt3k::launch_gemm(dt, resid(h_d, L.wo_mlp, c.mlp_dim), false, 0, MT3_EPI_RESID, small, s);

@@ -1099,16 +1099,18 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
     }
     if constexpr (KG == 16 && !NORM && !A_F32 &&
                   (EPI == kEpiResidS || EPI == MT3_EPI_GEGLU || EPI == kEpiResidQ || EPI == MT3_EPI_RESID)) {
-      // f32 operands, the four dense launches of a decoder layer for a LARGE row block (>= 256 rows: the row groups of an
-      // engine of 1024+ slots, or a one-stream decode of 256+ rows): 64 x 32 tiles with K slices of 128 -- half the
+      // f32 operands, the four dense launches of a decoder layer for a LARGE row group (>= 256 rows per group: engines of
+      // 1024+ slots) that runs BESIDE other groups (GemmArgs::concurrent): 64 x 32 tiles with K slices of 128 -- half the
       // workgroups of the 32-row tiles, a 64-row block fetches each weight byte once, and 51 KB of LDS let three
       // workgroups share a CU (four waves stacked along M, 16 x 32 outputs each).  Outputs are BIT-IDENTICAL to the
-      // 32-row tiles' (the K order of every output element is the tile-independent MFMA chain; the tests that hold row
-      // groups against one stream at 259 rows compare exactly these two tile families).  Measured (round 5,
+      // 32-row tiles' (the K order of every output element is the tile-independent MFMA chain;
+      // tests/test_gpu_parity_r5.py holds 256-row groups against one stream).  Measured (round 5,
       // profiles/r5_ab_refill_schedule.txt part 9; refilled ragged corpus, f32): 312 rows per group 2,419 -> 2,603
       // audio-s/s (the fold launch alone: 2,532; with slices of 256: 2,471), canonical 1250-row decode 4,759 -> 4,575 ms;
-      // 256 rows per group 2,382 -> 2,541; 128 rows per group 2,298 -> 2,225 (slower: hence the threshold)
-      if (g.M >= 256 && g.K % (8 * KG) == 0) return launch_cfg<CT, 64, 32, 8 * KG, 4, 1, A_F32, NORM, EPI>(g, s);
+      // 256 rows per group 2,382 -> 2,541; 128 rows per group 2,298 -> 2,225 (slower: hence the threshold); ONE stream of
+      // 256 rows alone on the chip 1,178 -> 1,214 ms per decode (slower: hence `concurrent` -- under contention the
+      // bytes through the L1s decide, alone the latency of a workgroup does)
+      if (g.concurrent && g.M >= 256 && g.K % (8 * KG) == 0) return launch_cfg<CT, 64, 32, 8 * KG, 4, 1, A_F32, NORM, EPI>(g, s);
     }
     if constexpr (EPI == MT3_EPI_GEGLU) {
       if (deep) return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI>(g, s);

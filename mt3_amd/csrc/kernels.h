@@ -41,6 +41,9 @@ struct GemmArgs {
   // tile -> XCD dealing: 0 = an XCD owns a run of row blocks (all weight columns pass through its L2), 1 = an XCD
   // owns a run of weight-column tiles for ALL row blocks (its L2 sees 1/8 of the weights; set by launch_gemm)
   int n_major;
+  // decode-sized f32 launches: this launch is one of several row groups running side by side (set by the engine), so
+  // a row block of >= 256 rows takes the 64 x 32 tiles (gemm.hip: launch_tile); alone on the chip the 32-row tiles win
+  int concurrent;
 };
 // internal epilogues (not part of the C ABI): STORE / RESID with a second f32 output region, see GemmArgs::out2
 constexpr int kEpiStoreQ = 6, kEpiResidQ = 7, kEpiResidS = 8;

@@ -60,3 +60,36 @@ def test_batch_256_f32_product_schedule_rows_against_the_oracle():
         if np.array_equal(got[i, : n - 1], ref[i, : n - 1]):                 # (a tie flip before the EOS is reported above)
             assert np.array_equal(got[i], ref[i]), r
     assert sum(np.array_equal(got[i], ref[i]) for i in range(len(ROWS))) >= len(ROWS) - 1
+
+
+def test_256_row_groups_on_the_64_row_tiles_equal_one_stream_on_the_32_row_tiles():
+    """Round 5: the f32 dense launches of a row group of >= 256 rows that runs beside other groups take 64 x 32 tiles
+    (gemm.hip: launch_tile, GemmArgs::concurrent); one stream over the whole batch keeps the 32-row tiles.  The K order of
+    every output element is the same MFMA chain in both, so the ids must agree bit for bit: 1024 slots = four groups of
+    256 rows against one stream, greedy and beam-1, and with early exit (the groups shrink through 224, 192, ... rows:
+    back on the 32-row tiles below 256)."""
+    B, S = 1024, 72
+    cfg = network.T5Config(dtype="float32", num_encoder_layers=1, num_decoder_layers=2)
+    params = network.init_random_params(cfg, seed=12, norm_scale_jitter=0.1)
+    k = params["decoder/logits_dense/kernel"].copy()
+    k[:, 1] *= 3.0
+    params["decoder/logits_dense/kernel"] = k
+    eng = network.Transformer(cfg, input_length=256, max_decode_length=1024, max_batch=B)
+    eng.load_params(params)
+    lm = spectrograms.compute_spectrogram_batch(synthetic.synth_audio(B, seed=77), None)
+    eng.encode(lm)
+    for beam1 in (False, True):
+        one = eng.decode(num_steps=S, single_stream=True, beam1=beam1)
+        assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 1
+        four = eng.decode(num_steps=S, beam1=beam1)
+        assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 4 and eng.status(_lib.STATUS_GRAPH_FALLBACKS) == 0
+        assert torch.equal(one, four), (beam1, (one != four).any(1).nonzero().flatten().tolist()[:8])
+    lens = np.clip(np.rint(np.random.default_rng(2).normal(30, 15, B)), 1, S).astype(np.int32)
+    eng.debug_set_eos_schedule(lens)
+    try:
+        ref = eng.decode(num_steps=S, single_stream=True)
+        ee = eng.decode(num_steps=S, early_exit=True)
+        assert eng.status(_lib.STATUS_LAST_DECODE_GROUPS) == 4 and eng.status(_lib.STATUS_LAST_DECODE_COMPACTIONS) >= 1
+        assert torch.equal(ee, ref)
+    finally:
+        eng.debug_set_eos_schedule(None)
