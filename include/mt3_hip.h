@@ -212,7 +212,8 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch,
  * to the schedule without EARLY_EXIT (rows are independent; tests/test_gpu_retire.py).  Without EARLY_EXIT every row
  * runs all `num_steps` steps (the canonical full-length workload bench.py's headline is quoted on).
  * Schedule: a batch of >= 128 rows is decoded as 2 or 4 ROW GROUPS (bf16 operands: 2 from 128 rows, 4 from 512; f32:
- * 2 from 128, 4 from 256), each on an engine-owned stream with a hardware queue of its own (created with
+ * 2 from 128, 4 from 256 -- with MT3_DECODE_EARLY_EXIT the bf16 rule in f32 as well: the ragged regime is launch latency,
+ * two groups measure faster there), each on an engine-owned stream with a hardware queue of its own (created with
  * hipExtStreamCreateWithCUMask and a mask of all compute units: two plain HIP streams serialise)
  * and driven by one of the engine's worker threads (one captured step graph per group, replayed per step;
  * MT3_DECODE_NO_GRAPH: direct launches), so that one group's HBM-bound attention runs beside the other groups'
