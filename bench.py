@@ -80,7 +80,7 @@ def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int, small_se
     bounded sample: (a) the full path on `n_segments` segments as ONE batch (reduced configs[2]; 8 = the reference
     InferenceModel's batch size, NB:190), (b) a batch-scaling probe at `small_segments` segments (first 48 decode steps
     only), (c) configs[1]: log-mel + encoder only on `enc_segments` segments.
-    parity_file (written by the GPU leg): the audio of the FIRST `n_segments` rows of the headline batch, the product's
+    parity_file (written by the GPU leg): the audio of `n_segments` rows of the headline batch (`parity_rows`: spread over all row groups), the product's
     log-mel, ids and notes of those rows as the headline's own schedule produced them -- the timed sample then runs on
     that audio and its tokens / notes are COMPARED with the product's (`parity`): the driver-run line carries parity at
     the credited configuration."""
@@ -167,9 +167,11 @@ def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int, small_se
         parity = {"rows": int(n_segments), "steps": int(decode_steps), "token_exact_rows": exact, "first_divergence": div,
                   "notes_equal": got_notes == ref_notes, "notes": len(ref_notes),
                   "logmel_max_abs_diff_where_mel_above_1e-2": float(np.abs(lm_gpu - lm_cpu)[sig].max()),
+                  "batch_rows": [int(r) for r in par["rows"]] if "rows" in par else list(range(int(n_segments))),
                   "what": "oracle (numpy frontend -> torch-CPU f32 network -> greedy loop -> pure-Python note decoding) "
-                          "on the audio of the first %d rows of the headline batch, against the ids / notes the "
-                          "headline engine produced for those rows inside its %d-row batch (%s)"
+                          "on the audio of %d rows of the headline batch spread over all its row groups (batch_rows), "
+                          "against the ids / notes the headline engine produced for those rows inside its %d-row batch "
+                          "(%s); the rows are taken as consecutive segments of one track on both sides"
                           % (n_segments, int(par["batch"]), str(par["schedule"]))}
         if div and time.perf_counter() - t_begin < 120.0:
             # rows that differ end to end: is it the frontend's 1e-4 or the network?  the oracle's network alone, fed the
@@ -223,14 +225,34 @@ def cpu_baseline(n_segments: int, decode_steps: int, enc_segments: int, small_se
     return out
 
 
+def parity_rows(batch: int, n: int, groups: int):
+    """Which rows of the headline batch the oracle is compared on: `n` rows spread over ALL row groups of the decode
+    schedule (group g decodes rows [g * batch / groups, (g + 1) * batch / groups): csrc/engine.hip), first / interior /
+    last rows of the groups included -- at batch 256, 4 groups, n = 8: 0, 37, 64, 100, 128, 191, 200, 255."""
+    if n >= batch:
+        return list(range(batch))
+    if batch == 256 and n == 8:
+        return [0, 37, 64, 100, 128, 191, 200, 255]
+    groups = max(1, min(groups, n))
+    per = batch // groups
+    rows = []
+    for i in range(n):
+        g = i % groups
+        k = i // groups                                   # k-th pick inside group g: first row, then last, then interior
+        lo, hi = g * per, (batch if g == groups - 1 else (g + 1) * per) - 1
+        rows.append(lo if k == 0 else hi if k == 1 else lo + ((2 * k - 3) * (hi - lo)) // (2 * max(1, n // groups)))
+    return sorted(set(rows))[:n]
+
+
 # ----------------------------------------------------------------------------------------- rank spawning
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher: run N ranks (one per GPU) under torch.distributed.run."""
-    import torch
-    have = torch.cuda.device_count()
-    if have < n:
-        sys.stderr.write("bench.py: --gpus %d but this node exposes %d GPU(s); not faking a multi-GPU line\n" % (n, have))
-        return 3
+    if "--dry-run" not in sys.argv:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but this node exposes %d GPU(s); not faking a multi-GPU line\n" % (n, have))
+            return 3
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -280,6 +302,11 @@ def main():
     ap.add_argument("--cpu-segments", type=int, default=8)
     ap.add_argument("--cpu-small-segments", type=int, default=32, help="batch of the CPU batch-scaling probe (0: skip)")
     ap.add_argument("--cpu-enc-segments", type=int, default=64)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing check WITHOUT GPUs (tests/test_bench_dry_run.py): the same rank spawning, shard "
+                         "arithmetic, ONE gather per pass (gloo instead of RCCL), host note decoding, max-over-ranks timing "
+                         "and JSON assembly, with a stub in place of frontend + engine; the line says dry_run: true and "
+                         "its value measures nothing")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-parity-file", default="", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -299,12 +326,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+    dry = args.dry_run
+    dev = "cpu" if dry else "cuda"
+    if dry:
+        args.no_extras = args.no_cpu_baseline = True
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        if world > 1:
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from mt3_amd import _lib, distributed, metrics_utils, network, note_sequences, spectrograms, synthetic, vocabularies
@@ -321,13 +356,16 @@ def main():
     import dataclasses
     shape = network.MT3_BASE if args.model == "base" else network.MT3_SMALL
     cfg = dataclasses.replace(shape, dtype=args.dtype, kv_dtype=args.kv_dtype, dense_dtype=args.dense_dtype)
-    eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, decode_chains=args.chains)
-    eng.load_params(network.init_random_params(cfg, seed=0))
     codec = vocabularies.build_codec(vocabularies.VocabularyConfig(num_velocity_bins=1))
     vocab = vocabularies.vocabulary_from_codec(codec)
-    # this rank's shard of the synthetic corpus, resident in HBM before the clock starts
-    audio = torch.cat([synthetic.synth_audio(min(1024, n_local - s), seed=1000 + lo + s) for s in range(0, n_local, 1024)])
-    stream = torch.cuda.Stream()                                          # a real (capturable) stream
+    if dry:
+        eng = audio = stream = None
+    else:
+        eng = network.Transformer(cfg, input_length=256, max_decode_length=L, max_batch=B, decode_chains=args.chains)
+        eng.load_params(network.init_random_params(cfg, seed=0))
+        # this rank's shard of the synthetic corpus, resident in HBM before the clock starts
+        audio = torch.cat([synthetic.synth_audio(min(1024, n_local - s), seed=1000 + lo + s) for s in range(0, n_local, 1024)])
+        stream = torch.cuda.Stream()                                      # a real (capturable) stream
     start_times = [s * SEG_SECONDS - (s * SEG_SECONDS) % 0.01 for s in range(n_global)]
 
     # rank 0's host stage (EOS trim + run-length / note decoding in libmt3hip.so) runs on worker threads, so the
@@ -340,22 +378,34 @@ def main():
     gather_events = []
 
     def notes_of_file(rows, first):
-        eos = rows == vocabularies.DECODED_EOS_ID
-        n_tok = np.where(eos.any(1), eos.argmax(1), rows.shape[1])
-        ns, inv, drop = metrics_utils._run(codec, note_sequences.NoteEncodingWithTiesSpec.spec_id,
-                                           [r[:n] for r, n in zip(rows, n_tok)], start_times[first: first + len(rows)])
-        return len(ns.notes)
+        """EOS trim + run-length / note decoding of one file's token rows (C++ in libmt3hip.so; notes as a record array:
+        no Python object per note on the job's host stage)"""
+        rec, inv, drop, total = metrics_utils.decode_token_rows(codec, note_sequences.NoteEncodingWithTiesSpec, rows,
+                                                                start_times[first: first + len(rows)])
+        return len(rec)
 
     def transcribe(first, count, engine=None):
         """frontend -> encode -> decode -> ids -> tokens for global segments [first, first + count): CUDA int32 [count, L]"""
+        if dry:
+            return torch.from_numpy(synthetic.stub_token_rows(first, count, L))
         chunk = audio[first - lo: first - lo + count]
         e = engine or eng
         e.encode(spectrograms.compute_spectrogram_batch(chunk, None))
         return vocab.decode_tf(e.decode(num_steps=args.decode_steps, beam1=args.decoding == "beam1"))
 
+    class _HostEvent:                                   # dry run: wall-clock stand-in for a HIP event
+        def __init__(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
     def on_gather(phase):
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(stream)
+        if dry:
+            ev = _HostEvent()
+        else:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
         if phase == 0:
             gather_events.append([ev, None])
         else:
@@ -370,17 +420,23 @@ def main():
                                                                                                    args.file_segments)]
 
     def step():
+        if dry:
+            return job.step()
         with torch.cuda.stream(stream):
             job.step()
 
     def drain():
         return sum(job.drain())
 
+    def device_sync():
+        if not dry:
+            torch.cuda.synchronize()
+
     def sync_all():
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     for _ in range(args.warmup):
         step()
@@ -391,24 +447,26 @@ def main():
     for _ in range(args.steps):
         step()
     n_notes = drain()
-    torch.cuda.synchronize()
+    device_sync()
     dt_own = time.perf_counter() - t0                 # this rank's own time to finish its K steps
     sync_all()
     dt = time.perf_counter() - t0
     per_rank_ms, gather_ms = [dt_own * 1e3 / args.steps], None
     if world > 1:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        mine = torch.tensor([dt_own * 1e3 / args.steps], device="cuda", dtype=torch.float64)
+        mine = torch.tensor([dt_own * 1e3 / args.steps], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank_ms = [float(t.item()) for t in allr]
         gather_ms = sum(a.elapsed_time(b) for a, b in gather_events) / max(1, len(gather_events))
-    graph_fallbacks = eng.status(_lib.STATUS_GRAPH_FALLBACKS)
-    used_graph = eng.status(_lib.STATUS_LAST_DECODE_USED_GRAPH)
-    decode_groups = eng.status(_lib.STATUS_LAST_DECODE_GROUPS)
-    partition_fallbacks = eng.status(_lib.STATUS_PARTITION_FALLBACKS)
+    graph_fallbacks = used_graph = decode_groups = partition_fallbacks = 0
+    if not dry:
+        graph_fallbacks = eng.status(_lib.STATUS_GRAPH_FALLBACKS)
+        used_graph = eng.status(_lib.STATUS_LAST_DECODE_USED_GRAPH)
+        decode_groups = eng.status(_lib.STATUS_LAST_DECODE_GROUPS)
+        partition_fallbacks = eng.status(_lib.STATUS_PARTITION_FALLBACKS)
 
     # ---- roofline of the dominant kernel (decode self-attention: HBM streaming of the K/V cache).
     # In-situ and live: HIP events (recorded on the stream the graphs are launched on) around the whole
@@ -416,7 +474,7 @@ def main():
     # graph (mt3_debug_engine_decode, include/mt3_hip_debug.h); the difference / launches = the kernel's average
     # duration inside the real decode loop.
     roof, extras = None, {}
-    if rank == 0:
+    if rank == 0 and not dry:
         Br = min(B, n_local)
 
         def timed(fn, reps=1):
@@ -962,7 +1020,8 @@ def main():
             "vs_baseline": None,
             "dtype": ("bf16" if args.dtype == "bfloat16" else "f32") + ("+fp8kv" if args.kv_dtype else "") +
                      ("+mxfp8 encoder" if args.dense_dtype else ""),
-            "data": "synthetic",
+            "data": "synthetic" if not dry else "stub token rows (DRY RUN: no GPU work, the value measures nothing)",
+            "dry_run": bool(dry),
             "config": {"workload": workload,
                        "segments_per_gpu": n_local, "segments_total": n_global, "decode_steps": args.decode_steps,
                        "segment_seconds": SEG_SECONDS, "decode_chains": args.chains, "decoding": args.decoding,
@@ -994,11 +1053,13 @@ def main():
                 try:
                     import tempfile
                     n8 = min(args.cpu_segments, B)
+                    rows8 = parity_rows(B, n8, eng.status(_lib.STATUS_LAST_DECODE_GROUPS))
+                    sel = torch.as_tensor(rows8, device="cuda", dtype=torch.long)
                     with torch.cuda.stream(stream):
                         lm_all = spectrograms.compute_spectrogram_batch(audio[:B], None)
                         eng.encode(lm_all)
                         ids_all = eng.decode(num_steps=args.decode_steps, beam1=False)
-                        tok8 = vocab.decode_tf(ids_all[:n8]).cpu().numpy()
+                        tok8 = vocab.decode_tf(ids_all[sel]).cpu().numpy()
                     eos8 = tok8 == vocabularies.DECODED_EOS_ID
                     n_tok = np.where(eos8.any(1), eos8.argmax(1), tok8.shape[1])
                     ns8, _, _ = metrics_utils._run(codec, note_sequences.NoteEncodingWithTiesSpec.spec_id,
@@ -1008,8 +1069,9 @@ def main():
                     sched = "%d row groups, %s" % (eng.status(_lib.STATUS_LAST_DECODE_GROUPS),
                                                    "graph replay" if eng.status(_lib.STATUS_LAST_DECODE_USED_GRAPH) else "direct launches")
                     pf = os.path.join(tempfile.mkdtemp(prefix="mt3_parity_"), "rows.npz")
-                    np.savez(pf, audio=audio[:n8].cpu().numpy(), logmel=lm_all[:n8].cpu().numpy(),
-                             ids=ids_all[:n8].cpu().numpy(), notes=notes8, batch=np.int64(B), schedule=np.str_(sched))
+                    np.savez(pf, audio=audio[sel].cpu().numpy(), logmel=lm_all[sel].cpu().numpy(),
+                             ids=ids_all[sel].cpu().numpy(), notes=notes8, batch=np.int64(B), schedule=np.str_(sched),
+                             rows=np.asarray(rows8, np.int64))
                     parity_args = ["--cpu-parity-file", pf]
                 except Exception as ex:
                     out["cpu_parity_error"] = repr(ex)[:300]

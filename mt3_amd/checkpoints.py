@@ -254,3 +254,48 @@ def is_t5x_checkpoint_dir(path: str) -> bool:
     if os.path.isfile(os.path.join(path, "checkpoint")):
         return True
     return any(e.startswith(_TARGET_PREFIX) for e in os.listdir(path))
+
+
+# ---------------------------------------------------------------------------------------- compact .npz (repo fixtures)
+def save_compact_npz(path: str, params: Dict[str, np.ndarray], meta: Optional[Dict[str, Any]] = None) -> Dict[str, np.ndarray]:
+    """A checkpoint small enough to live in the repository (tests/golden/): every matrix as int8 with one f32 scale per
+    OUTPUT column (embedding: per row), vectors (norm scales) as f32, zlib-compressed -- 1 byte per weight.  The weights of
+    the checkpoint ARE the de-quantised values (`load_compact_npz` returns them as f32; every engine precision starts
+    from those same f32 numbers).  Not a t5x format: `save_t5x_checkpoint(load_compact_npz(p))` writes that.
+    Returns the de-quantised dict."""
+    out, deq = {}, {}
+    for name, w in params.items():
+        w = np.asarray(w, np.float32)
+        if w.ndim != 2:
+            out[name + "|f"] = w
+            deq[name] = w
+            continue
+        axis = 1 if name.endswith("/embedding") else 0            # reduce over `axis`: one scale per column (per row)
+        s = np.abs(w).max(axis=axis, keepdims=True) / 127.0
+        s = np.where(s > 0, s, 1.0).astype(np.float32)
+        q = np.clip(np.rint(w / s), -127, 127).astype(np.int8)
+        out[name + "|q"], out[name + "|s"] = q, s
+        deq[name] = q.astype(np.float32) * s
+    if meta:
+        out["__meta__"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
+    np.savez_compressed(path, **out)
+    return deq
+
+
+def load_compact_npz(path: str) -> Dict[str, np.ndarray]:
+    """{'a/b/c': f32 array} of a file written by `save_compact_npz`."""
+    params: Dict[str, np.ndarray] = {}
+    with np.load(path) as z:
+        for key in z.files:
+            if key.endswith("|f"):
+                params[key[:-2]] = np.asarray(z[key], np.float32)
+            elif key.endswith("|q"):
+                params[key[:-2]] = z[key].astype(np.float32) * z[key[:-2] + "|s"]
+    if not params:
+        raise CheckpointError("%s: not a compact checkpoint (no '|q' / '|f' entries)" % path)
+    return params
+
+
+def compact_npz_meta(path: str) -> Dict[str, Any]:
+    with np.load(path) as z:
+        return json.loads(bytes(z["__meta__"]).decode()) if "__meta__" in z.files else {}

@@ -102,6 +102,10 @@ struct LayerDev {
 // in use), 32 = the synthetic EOS schedule (mt3_debug_engine_set_eos_schedule)
 // 64 = in-flight batching (mt3_engine_transcribe: finished slots restart on new segments, the slot -> segment map is in use)
 constexpr int kVarBeam = 4, kVarForced = 8, kVarRetire = 16, kVarEos = 32, kVarStream = 64, kNumVariants = 128;
+// not a step variant of its own (never an index into graph_exec): set in GroupRun::variant when the decode runs as SEVERAL
+// row groups, so that a step knows it runs beside other groups' launches (GemmArgs::concurrent) and the group-graph cache
+// keeps such steps apart from a lone stream's steps of the same shape
+constexpr int kVarBeside = 128;
 constexpr int kMaxGroups = 4;
 // staging ring of mt3_engine_transcribe: cross-attention K/V of segments that wait for a slot, kStageChunks chunks of up
 // to kStageChunkCap segments each (one encoder pass per chunk)
@@ -274,6 +278,7 @@ struct mt3_engine {
   // device and waits for the older one on a BLOCKING-SYNC event -- the thread sleeps until the interrupt instead of
   // spinning in the runtime's queue back-pressure / hipStreamSynchronize (round 4: five cores busy for the length of a
   // decode).  Index kMaxGroups = the caller's stream (single-stream schedule, the encoder passes of transcribe).
+  // events the workers NAP-POLL (sleep_until: hipEventQuery between 20..200 us naps; not blocking-sync waits):
   hipEvent_t wait_ev[kMaxGroups + 1][4] = {};     // [0] waits, [1] throttle, [2], [3] the two poll snapshots of transcribe
   bool spin_waits = false;       // MT3_OPT_SPIN_WAITS: round 4's behaviour
   int part_failed = 0;           // partitioned decodes that fell back to the single-stream schedule (stream creation failed)
@@ -665,7 +670,9 @@ int enqueue_chain_op(mt3_engine* e, int row0, int rows, int B_total, int skip, i
     g.a_ss = y_ss;
     return g;
   };
-  const int beside = rows < B_total ? 1 : 0;     // this step belongs to one of several row groups (GemmArgs::concurrent)
+  // this step belongs to one of several row groups / graph chains (GemmArgs::concurrent).  Under row retirement
+  // rows < B_total also holds for a LONE stream after a compaction, hence the explicit bit
+  const int beside = ((skip & kVarBeside) || (!retire && rows < B_total)) ? 1 : 0;
   auto resid = [&](const void* A, const void* Wt, int K) {
     mt3k::GemmArgs g = gemm_args(A, Wt, y, rows, emb, K, emb);
     g.out_ct = y_copy;
@@ -1023,7 +1030,9 @@ int mt3_engine_finalize(mt3_engine* e) {
   }
   e->dec.resize(c.num_decoder_layers);
   const bool single_stream = (c.options & MT3_OPT_SINGLE_RESIDUAL_STREAM) != 0;
-  const bool q_fold = emb % 64 == 0 && (emb <= 512 || emb == 768) && !single_stream &&
+  // (emb = 768, the ismir2022/base.gin shape: the split residual form exists for the bf16 tiles only -- their 48 partial
+  // sums fit the NPV = 16 registers; an f32 engine of that shape keeps the single f32 stream with in-kernel statistics)
+  const bool q_fold = emb % 64 == 0 && (emb <= 512 || (emb == 768 && c.compute_dtype == MT3_BF16)) && !single_stream &&
                       !(c.options & MT3_OPT_SEPARATE_PROJECTIONS);
   e->q_fold = q_fold;
   for (int l = 0; l < c.num_decoder_layers; ++l) {
@@ -1108,7 +1117,7 @@ int mt3_engine_finalize(mt3_engine* e) {
   // the split residual form in the decode loop.  bf16: f32 rows + bf16 copy + per-16-column sums of squares; f32 (round
   // 3): the compute-type rows ARE the f32 rows, so only the sums travel with them (y_ct aliases y and is never written
   // as a copy) -- the norm-fused GEMMs then need no statistics pass and the folded projections work as in bf16
-  e->y_split = emb % 64 == 0 && (emb <= 512 || emb == 768) && !single_stream;
+  e->y_split = emb % 64 == 0 && (emb <= 512 || (emb == 768 && c.compute_dtype == MT3_BF16)) && !single_stream;
   if (e->y_split) {
     if (c.compute_dtype == MT3_BF16) {
       if ((rc = dmalloc(e, &e->y_ct, static_cast<size_t>(Bm) * emb * 2))) return rc;
@@ -1734,7 +1743,7 @@ static int decode_impl(mt3_engine* e, int32_t batch, int32_t num_steps, int32_t 
           GroupRun r{};
           chain_rows(batch, groups, g, &r.row0, &r.rows);
           r.batch = batch;
-          r.variant = variant;
+          r.variant = variant | kVarBeside;            // groups > 1 here
           r.num_steps = num_steps;
           r.slot = g;
           r.early = early;
@@ -1911,7 +1920,7 @@ static int refill_group(mt3_engine* e, const GroupRun& r, int cur, const FeedRan
 
 // One row group's loop of mt3_engine_transcribe: as run_group, but a finished slot restarts on the next staged segment
 // at the poll, and the loop ends when the queue is empty for good and every slot of the group has finished.
-static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out, long max_steps, int kPoll) {
+static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out, int kPoll) {
   int cur = r.rows;
   hipGraphExec_t exec = nullptr;
   int exec_rows = -1, flushed_at = -1;
@@ -1928,8 +1937,16 @@ static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out,
   // out: it may be an interval stale, never wrong (finished slots stay finished until a refill restarts them).
   int parity = 0;
   bool pending = false;
+  // Watchdog on PROGRESS, not on the step count (a group that is starved by a slow encoder keeps stepping its live
+  // slots, so its counter grows with wall time): a live slot finishes within num_steps steps of its (re)start and a
+  // snapshot is at most two poll intervals old, so `stall_limit` steps without a refill, a newly finished slot or a
+  // compaction can only mean a slot that never terminates.
+  const long stall_limit = static_cast<long>(r.num_steps) + 4L * kPoll + 64;
+  long last_progress = 0;
+  int seen_fin = 0;
   for (long t = 0;; ++t) {
-    if (t >= max_steps) return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: a row group did not terminate");
+    if (t - last_progress > stall_limit)
+      return mt3::fail(MT3_ERR_INVALID, "mt3_engine_transcribe: a row group made no progress for num_steps + 4 polls");
     if (r.use_graph && exec_rows != cur) {
       exec = group_graph(e, r.variant, r.batch, r.row0, cur, r.slot);
       exec_rows = cur;
@@ -1949,6 +1966,7 @@ static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out,
       feed_release(f, held);                     // what was taken one snapshot ago was copied out in front of this one
       held.clear();
       int n_fin = e->h_pinned[r.slot + kMaxGroups * (parity ^ 1)];   // finished slots among the group's r.rows (dropped ones included)
+      if (n_fin != seen_fin) last_progress = t;
       bool dry = false;
       for (;;) {
         if (mt3feed::feed_failed(f)) return MT3_OK;           // somebody else reports the error
@@ -1958,6 +1976,7 @@ static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out,
           MT3_TRY(refill_group(e, r, cur, &got[i], d_out));
           held.push_back(got[i]);
           n_fin -= got[i].n;
+          last_progress = t;
         }
         if (dry || n_fin < r.rows) break;
         feed_wait(f);                            // nothing live and the encoder is behind: sleep, do not spin through empty steps
@@ -1979,8 +1998,10 @@ static int run_group_stream(mt3_engine* e, GroupRun& r, Feed& f, int32_t* d_out,
           MT3_TRY(compact_group(e, r, cur));
           cur = want;
           ++e->compactions_now;
+          last_progress = t;
         }
       }
+      seen_fin = n_fin;
     }
     // ---- this interval's snapshot
     hipEvent_t ev = wait_event(e, r.slot, 2 + parity);
@@ -2088,16 +2109,14 @@ static int transcribe_impl(mt3_engine* e, const float* d_inputs, int32_t n_segme
   p = PendingDecode();
   p.groups = groups;
   p.active = true;                                       // every other entry point of the engine refuses meanwhile
-  // a segment needs at most num_steps steps; rounds of refills are bounded by the segments a slot can see
-  const long max_steps = static_cast<long>(num_steps + 64) * (static_cast<long>(n_segments) / S + 2);
   bool posted_all = true;
   for (int g = 0; g < groups && posted_all; ++g) {
-    auto body = [e, g, groups, S, variant, num_steps, use_graph, &feed, d_ids, max_steps, poll]() {
+    auto body = [e, g, groups, S, variant, num_steps, use_graph, &feed, d_ids, poll]() {
       PendingDecode& q = e->pending;
       GroupRun r{};
       chain_rows(S, groups, g, &r.row0, &r.rows);
       r.batch = S;
-      r.variant = variant;
+      r.variant = variant | (groups > 1 ? kVarBeside : 0);
       r.num_steps = num_steps;
       r.slot = g;
       r.early = true;
@@ -2105,7 +2124,7 @@ static int transcribe_impl(mt3_engine* e, const float* d_inputs, int32_t n_segme
       r.s = e->part_stream[g];
       hipError_t he = hipStreamWaitEvent(r.s, e->part_begin, 0);
       if (he == hipSuccess) {
-        q.rcs[g] = run_group_stream(e, r, feed, d_ids, max_steps, poll);
+        q.rcs[g] = run_group_stream(e, r, feed, d_ids, poll);
         if (q.rcs[g] != MT3_OK) q.errs[g] = mt3_last_error();
         he = wait_stream(e, g, r.s);
       }

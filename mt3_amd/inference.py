@@ -111,7 +111,7 @@ class InferenceModel(object):
     def restore_from_checkpoint(self, checkpoint_path):
         """Weights: a t5x checkpoint DIRECTORY (what the reference restores: msgpack index + one zarr
         array per `target.*` parameter, read by mt3_amd.checkpoints), a flat `.npz` (names = the
-        reference's Flax tree joined by '/'), a dict of arrays, or 'random:<seed>' / None for the
+        reference's Flax tree joined by '/'; or the int8 form of checkpoints.save_compact_npz), a dict of arrays, or 'random:<seed>' / None for the
         reference's initialisers (no checkpoint ships with the repo)."""
         rnd = None if checkpoint_path is None or isinstance(checkpoint_path, dict) else \
             re.fullmatch(r"random(?::(\d+))?", str(checkpoint_path))
@@ -124,7 +124,11 @@ class InferenceModel(object):
         elif checkpoint_path is not None and str(checkpoint_path).endswith(".npz") and \
                 os.path.exists(str(checkpoint_path)):
             with np.load(str(checkpoint_path)) as z:
-                params = {k: z[k] for k in z.files}
+                compact = any(k.endswith("|q") for k in z.files)      # checkpoints.save_compact_npz: int8 + per-column scales
+                params = None if compact else {k: z[k] for k in z.files}
+            if compact:
+                from . import checkpoints
+                params = checkpoints.load_compact_npz(str(checkpoint_path))
         elif checkpoint_path is None or rnd:
             params = network.init_random_params(self.model_config, seed=int(rnd.group(1) or 0) if rnd else 0)
         else:
@@ -148,6 +152,9 @@ class InferenceModel(object):
         while slots < want:
             slots *= 2
         slots = min(slots, self.max_slots)
+        # the old engine goes FIRST: two engines' K/V caches must never be resident together (12.8 GB each in f32 at 256
+        # slots, MT3 shape) -- Transformer.__del__ destroys the engine as soon as the last reference is dropped
+        self.model = None
         self.model = network.Transformer(self.model_config, input_length=self.inputs_length,
                                          max_decode_length=self.outputs_length, max_batch=slots)
         self.model.load_params(self._params)
@@ -244,10 +251,11 @@ class InferenceModel(object):
             chunk = frames[s * T:(s + 1) * T]
             audio[s, : chunk.size] = chunk.reshape(-1)
             counts.append(len(chunk))
-        self._logmel_dev = spectrograms.compute_spectrogram_batch(torch.from_numpy(audio).cuda(), counts,
-                                                                  self.spectrogram_config)     # stays on the device
-        # (the examples the reference's preprocess returns are host arrays)
-        logmel = self._logmel_dev.cpu().numpy() if host_inputs else None
+        logmel_dev = spectrograms.compute_spectrogram_batch(torch.from_numpy(audio).cuda(), counts, self.spectrogram_config)
+        # host_inputs=False: the device tensor is kept for the predict_tokens call that follows (and dropped by it);
+        # otherwise the examples carry host arrays, as the reference's preprocess returns them, and nothing stays pinned
+        self._logmel_dev = None if host_inputs else logmel_dev
+        logmel = logmel_dev.cpu().numpy() if host_inputs else None
         return [{"inputs": logmel[s, : counts[s]] if host_inputs else None, "input_times": times[s * T:(s + 1) * T],
                  "raw_inputs": audio[s, : counts[s] * hop], "targets": np.zeros((0,), np.int32)}
                 for s in range(n_seg)]

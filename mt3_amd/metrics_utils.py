@@ -12,14 +12,18 @@ from . import event_codec
 from . import note_sequences
 
 
-def _run(codec, spec_id, tokens_list, start_times, max_times=None):
+# mt3_note of include/mt3_hip.h as a numpy record: the host stage's output without one Python object per note
+NOTE_DTYPE = np.dtype([("start_time", "<f8"), ("end_time", "<f8"), ("pitch", "<i4"), ("velocity", "<i4"),
+                       ("program", "<i4"), ("is_drum", "<i4"), ("instrument", "<i4"), ("reserved", "<i4")])
+assert NOTE_DTYPE.itemsize == C.sizeof(_lib.NoteStruct)
+
+
+def _decode(codec, spec_id, flat, offs, start_times, max_times=None):
+    """mt3_notes_decode on a flat token array: (notes as a NOTE_DTYPE array, invalid, dropped, total_time)"""
     lib = _lib.load()
-    n = len(tokens_list)
-    toks = [np.ascontiguousarray(np.asarray(t).reshape(-1), dtype=np.int32) for t in tokens_list]
-    offs = np.zeros(n + 1, np.int64)
-    for i, t in enumerate(toks):
-        offs[i + 1] = offs[i] + t.size
-    flat = np.concatenate(toks) if n and offs[-1] else np.zeros(1, np.int32)
+    n = len(offs) - 1
+    flat = np.ascontiguousarray(flat, np.int32) if n and offs[-1] else np.zeros(1, np.int32)
+    offs = np.ascontiguousarray(offs, np.int64)
     st = np.ascontiguousarray(np.asarray(start_times, np.float64).reshape(-1)) if n else np.zeros(1)
     has_p = mt_p = None
     if max_times is not None:
@@ -27,17 +31,50 @@ def _run(codec, spec_id, tokens_list, start_times, max_times=None):
         mts = np.array([0.0 if m is None else float(m) for m in max_times], np.float64)
         has_p, mt_p = has.ctypes.data, mts.ctypes.data
     cap = max(64, int(offs[-1]) + 8)          # a token emits at most one note
-    notes = (_lib.NoteStruct * cap)()
+    notes = np.empty(cap, NOTE_DTYPE)
     n_notes, inv, drop, total = C.c_int64(), C.c_int64(), C.c_int64(), C.c_double()
     _lib.check(lib.mt3_notes_decode(C.byref(codec.desc), spec_id, n, flat.ctypes.data, offs.ctypes.data,
-                                    st.ctypes.data, has_p, mt_p, C.cast(notes, C.c_void_p), cap, C.byref(n_notes),
+                                    st.ctypes.data, has_p, mt_p, C.c_void_p(notes.ctypes.data), cap, C.byref(n_notes),
                                     C.byref(inv), C.byref(drop), C.byref(total)))
-    ns = note_sequences.NoteSequence(total_time=total.value)
-    for i in range(n_notes.value):
-        s = notes[i]
-        ns.notes.append(note_sequences.Note(s.start_time, s.end_time, s.pitch, s.velocity, s.program,
-                                            bool(s.is_drum), s.instrument))
-    return ns, inv.value, drop.value
+    return notes[: n_notes.value], inv.value, drop.value, total.value
+
+
+def decode_token_rows(codec, encoding_spec, rows, start_times, lengths=None):
+    """The host stage of a JOB (bench.py, distributed.ShardedTranscriber): `decode_tf`-form token rows int32 [n, L] of the
+    consecutive segments of ONE file -> (notes as a NOTE_DTYPE record array, invalid events, dropped events, total_time),
+    with no per-row and no per-note Python work (event_predictions_to_ns builds a NoteSequence of Note objects: 2-3 us per
+    note under the GIL, which is what bounded rank 0 at N = 8 -- DESIGN.md section 6).  lengths: tokens per row; None = up
+    to the first -1 (`_trim_eos`, NB:346-352).  Same combiner rule as event_predictions_to_ns (max_time = the next
+    segment's start, mt3/metrics_utils.py:92-116); rows must be in start-time order."""
+    rows = np.ascontiguousarray(rows, np.int32)
+    if rows.ndim != 2:
+        raise ValueError("rows must be [segments, length]")
+    if lengths is None:
+        eos = rows == -1
+        lengths = np.where(eos.any(1), eos.argmax(1), rows.shape[1])
+    lengths = np.asarray(lengths, np.int64)
+    offs = np.zeros(len(rows) + 1, np.int64)
+    np.cumsum(lengths, out=offs[1:])
+    flat = rows[np.arange(rows.shape[1])[None, :] < lengths[:, None]]
+    return _decode(codec, encoding_spec.spec_id, flat, offs, start_times)
+
+
+def note_sequence_from_records(rec, total_time: float):
+    ns = note_sequences.NoteSequence(total_time=total_time)
+    Note = note_sequences.Note
+    ns.notes = [Note(a, b, p, v, g, bool(d), i) for a, b, p, v, g, d, i, _ in rec.tolist()]
+    return ns
+
+
+def _run(codec, spec_id, tokens_list, start_times, max_times=None):
+    n = len(tokens_list)
+    toks = [np.asarray(t, np.int32).reshape(-1) for t in tokens_list]
+    offs = np.zeros(n + 1, np.int64)
+    if n:
+        np.cumsum([t.size for t in toks], out=offs[1:])
+    flat = np.concatenate(toks) if n and offs[-1] else np.zeros(1, np.int32)
+    rec, inv, drop, total = _decode(codec, spec_id, flat, offs, start_times, max_times)
+    return note_sequence_from_records(rec, total), inv, drop
 
 
 def event_predictions_to_ns(predictions: Sequence[Mapping[str, Any]], codec: event_codec.Codec,
