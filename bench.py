@@ -740,10 +740,64 @@ def main():
                         k: metrics.token_stream_divergence(free_running["f32"], free_running[k], codec)
                         for k in ("bf16", "fp8_kv", "fp8_kv_mx8") if k in free_running}
                     extras["divergence_vs_f32"]["note"] = (
-                        "free-running greedy decode of the same %d segments x %d steps, reference = this repo's f32 "
-                        "engine (token-exact vs the oracle); random-init weights" % (Br, args.decode_steps))
+                        "top-level fields of a mode: free-running greedy decode of the same %d segments x %d steps, reference = "
+                        "this repo's f32 engine (token-exact vs the oracle); random-init weights (next to no notes: see "
+                        "<mode>.trained / <mode>.boosted for the note-level figures)" % (Br, args.decode_steps))
             except Exception as ex:
                 extras["divergence_vs_f32"] = {"error": repr(ex)[:300]}
+
+            # ---- NOTE-LEVEL tolerance of the reduced-precision engines (north_star: "decoded note onsets/offsets
+            # within a stated fp tolerance"; SURVEY.md 8(d): mir_eval's rule, mt3/metrics.py:255-290, F1 >= 0.99 bf16 / >= 0.97
+            # fp8).  One file through InferenceModel per engine configuration, every mode scored against the f32 engine's notes
+            # (token-exact vs the oracle: cpu_baseline.parity, tests/test_gpu_note_tolerance.py):
+            #   trained : tests/golden/mt3_synthetic_ckpt.npz -- this network TRAINED on synthetic music (tools/train_synthetic.py,
+            #             14 minutes on one MI355X): peaked distributions conditioned on the audio, and a piece whose ground-truth
+            #             notes are known (`vs_truth` = transcription accuracy of each engine)
+            #   boosted : random-init weights with boosted note-event logits -- tens of thousands of notes but FLAT distributions (a
+            #             flipped arg-max re-rolls the rest of a row): a worst case, published as measured; also at the
+            #             ismir2022/base.gin shape for the configuration `configs4` times
+            def note_tolerance():
+                from mt3_amd import checkpoints, evaluation
+                dv = extras.setdefault("divergence_vs_f32", {})
+                if not isinstance(dv, dict) or "error" in dv:
+                    dv = extras["divergence_vs_f32"] = {}
+
+                def spread(rep, label, modes=evaluation.REDUCED_MODES):
+                    dv.setdefault("f32_reference", {})[label] = rep.get("f32")
+                    for k in modes:
+                        if k in rep:
+                            dv.setdefault(k, {})[label] = rep[k]
+                t1 = time.perf_counter()
+                try:
+                    ck = os.path.join(ROOT, "tests", "golden", "mt3_synthetic_ckpt.npz")
+                    truth, wav = synthetic.synth_music(600.0, seed=77)
+                    spread(evaluation.compare_engines(checkpoints.load_compact_npz(ck), wav, network.MT3_SMALL, truth=truth), "trained")
+                    dv["trained_checkpoint"] = checkpoints.compact_npz_meta(ck)
+                except Exception as ex:
+                    dv["trained_error"] = repr(ex)[:300]
+                try:
+                    wav = synthetic.synth_audio(293, seed=77, tones=6).reshape(-1)[: 600 * 16000].cpu().numpy()
+                    prm = synthetic.boost_note_events(network.init_random_params(network.MT3_SMALL, seed=0), eos=4.0)
+                    spread(evaluation.compare_engines(prm, wav, network.MT3_SMALL), "boosted")
+                    prm = synthetic.boost_note_events(network.init_random_params(network.MT3_BASE, seed=0), eos=4.0)
+                    rep = evaluation.compare_engines(prm, wav[: 180 * 16000], network.MT3_BASE, modes=("fp8_kv_mx8",))
+                    dv["configs4"] = {"boosted": rep.get("fp8_kv_mx8"), "f32_reference": rep.get("f32"),
+                                      "what": "ismir2022/base.gin shape, e4m3 caches + MXFP8 encoder (what extra.configs4 times) "
+                                              "against the f32 engine of the same shape, 3-minute file"}
+                except Exception as ex:
+                    dv["boosted_error"] = repr(ex)[:300]
+                dv["note_level_what"] = (
+                    "<mode>.trained / <mode>.boosted: one 10-minute file through InferenceModel (beam-1, early exit) per engine "
+                    "configuration, notes scored against the f32 engine's notes of the same file with the reference's mir_eval rule "
+                    "(onset +-50 ms; offset max(50 ms, 20 %)); pitch as note numbers (the reference's call) and exact (hz); trained "
+                    "= tests/golden/mt3_synthetic_ckpt.npz (vs_truth = against the notes the audio was rendered from), boosted = "
+                    "random-init weights with boosted note-event logits (flat distributions: worst case)")
+                dv["note_level_wall_s"] = time.perf_counter() - t1
+            try:
+                with torch.cuda.stream(stream):
+                    note_tolerance()
+            except Exception as ex:
+                extras.setdefault("divergence_vs_f32", {})["note_level_error"] = repr(ex)[:300]
 
             # ---- SURVEY.md 8(d), second figure: a SYNTHETIC EOS SCHEDULE -- output lengths ~ clipped N(300, 100) imposed
             # through the bench-only hook of include/mt3_hip_debug.h (row r's distribution at step len[r] - 1 becomes a

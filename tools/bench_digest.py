@@ -31,7 +31,14 @@ for k, v in (d.get("extra") or {}).items():
     if k == "divergence_vs_f32":
         for kk, vv in v.items():
             if isinstance(vv, dict):
-                print("  DIVERGENCE %s:" % kk, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in vv.items()})
+                print("  DIVERGENCE %s:" % kk, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in vv.items()
+                                                 if not isinstance(b, dict)})
+                for lab in ("trained", "boosted"):
+                    w = vv.get(lab)
+                    if isinstance(w, dict):
+                        print("      %s: " % lab + ", ".join("%s=%s" % (a, round(b, 4) if isinstance(b, float) else b)
+                                                             for a, b in w.items() if not isinstance(b, dict)) +
+                              ("  | vs truth onset F1 %.4f" % w["vs_truth"]["onset_f1_note_number"] if "vs_truth" in w else ""))
         continue
     rr = v.get("roofline") or {}
     s = "  %s: " % k + ", ".join("%s=%s" % (a, round(b, 4) if isinstance(b, float) else b) for a, b in v.items()

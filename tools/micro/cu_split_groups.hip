@@ -9,12 +9,21 @@
 //   D  one stream per group again, the split done INSIDE the kernels: both kinds claim their work items from a counter,
 //      attention-like workgroups leave at once when HW_ID says they sit on one of the two last CUs of a shader engine,
 //      GEMM-like workgroups when they do not (profiles/r4_cu_mask_map.txt: that is the 6/8 - 2/8 split of B)
+//   E  (round 6, VERDICT r5 #3c) ONE launch per layer and group: 384 attention-like workgroups followed by the 3 x 104
+//      GEMM-like workgroups of the three dependent dense stages in the same grid; a dense workgroup waits on a ready
+//      counter in memory (stage 0: the 384 attention-like workgroups of its layer; stage d: the 104 tiles of stage d - 1 --
+//      workgroups are dispatched in blockIdx order, so a waiting consumer's producers are always resident or done), reads a
+//      4 KB slice of its producer's output, combines it with its 64 KB of weights and bumps the next counter.  E0 loads the
+//      weights AFTER the wait (what removing three launch boundaries per layer buys by itself), E1 BEFORE it, into
+//      registers (what a dense stage costs when its weight fetch hides behind the attention phase)
+//   A' = A with the same dependent read added to the GEMM-like launches (the like-for-like baseline of E)
 // Prints microseconds per group step for each.   hipcc --offload-arch=gfx950 -O3 cu_split_groups.hip -o cu_split_groups -lpthread
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 #define CK(x)                                                            \
@@ -44,6 +53,74 @@ __global__ __launch_bounds__(256) void k_gemm_like(const f32x4_t* __restrict__ w
   for (int i = threadIdx.x; i < 64 * 1024 / 16; i += 256) acc += src[i];
   float* o = out + blockIdx.x * 1024 + threadIdx.x * 4;
   o[0] += acc[0], o[1] += acc[1], o[2] += acc[2], o[3] += acc[3];
+}
+
+// A': the GEMM-like launch of A that also consumes 4 KB of its producer's output (what E's stages do)
+__global__ __launch_bounds__(256) void k_gemm_dep(const f32x4_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ prev,
+                                                  int slice) {
+  const f32x4_t* src = w + (static_cast<size_t>(slice) * 104 + blockIdx.x) * (64 * 1024 / 16);
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int i = threadIdx.x; i < 64 * 1024 / 16; i += 256) acc += src[i];
+  const f32x4_t a = *reinterpret_cast<const f32x4_t*>(prev + ((blockIdx.x * 7) % 104) * 1024 + threadIdx.x * 4);
+  float* o = out + blockIdx.x * 1024 + threadIdx.x * 4;
+  o[0] = acc[0] * a[0], o[1] = acc[1] * a[1], o[2] = acc[2] * a[2], o[3] = acc[3] * a[3];
+}
+
+// E: one launch per layer and group.  flags[0] counts finished attention-like workgroups, flags[1 + d] the finished tiles of
+// dense stage d; bufs[d] is the output of stage d (stage 0 reads `attn_out`, which the attention-like workgroups touch).
+template <bool PREFETCH>
+__global__ __launch_bounds__(256) void k_layer_fused(const f32x4_t* __restrict__ kv, float* __restrict__ sink,
+                                                     const f32x4_t* __restrict__ w, float* __restrict__ b0, float* __restrict__ b1,
+                                                     float* __restrict__ b2, float* __restrict__ b3, int slice, int* flags) {
+  constexpr int kAttn = 384, kTiles = 104;
+  if (blockIdx.x < kAttn) {
+    if (threadIdx.x < 192) {
+      const f32x4_t* src = kv + static_cast<size_t>(blockIdx.x) * (512 * 1024 / 16);
+      float acc = 0.f;
+      for (int i = threadIdx.x; i < 512 * 1024 / 16; i += 192) {
+        const f32x4_t v = __builtin_nontemporal_load(src + i);
+        acc += v[0] + v[1] + v[2] + v[3];
+      }
+      if (acc == 123.456f) sink[blockIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      atomicAdd(flags, 1);
+    }
+    return;
+  }
+  const int d = (blockIdx.x - kAttn) / kTiles, tile = (blockIdx.x - kAttn) % kTiles;
+  const f32x4_t* src = w + (static_cast<size_t>(slice + d) % 14 * 104 + tile) * (64 * 1024 / 16);
+  f32x4_t wr[16];
+  if (PREFETCH) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wr[i] = src[threadIdx.x + i * 256];
+  }
+  if (threadIdx.x == 0) {
+    const int need = d == 0 ? kAttn : kTiles;
+    while (__hip_atomic_load(flags + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(4);
+    __threadfence();
+  }
+  __syncthreads();
+  if (!PREFETCH) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wr[i] = src[threadIdx.x + i * 256];
+  }
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc += wr[i];
+  const float* prev = d == 0 ? b0 : d == 1 ? b1 : b2;
+  float* out = d == 0 ? b1 : d == 1 ? b2 : b3;
+  const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(prev + ((tile * 7) % 104) * 1024 + threadIdx.x * 4));
+  float* o = out + tile * 1024 + threadIdx.x * 4;
+  o[0] = acc[0] * a[0], o[1] = acc[1] * a[1], o[2] = acc[2] * a[2], o[3] = acc[3] * a[3];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(flags + 1 + d, 1);
+  }
 }
 
 // this wave's CU is one of the two reserved for the dense launches (hardware CU ids run 0..7 or, with CU 0 harvested, 1..8)
@@ -96,7 +173,7 @@ static int make_stream(hipStream_t* s, int lo8, int hi8) {
   return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
   constexpr int G = 4, kSteps = 100, kLayers = 8, kDense = 3;
   f32x4_t *kv[G], *weights;
   float *out[G], *sink;
@@ -109,22 +186,37 @@ int main() {
     CK(hipMalloc(&out[g], 104 * 1024 * 4));
     CK(hipMemset(out[g], 0, 104 * 1024 * 4));
   }
-  const char* names[4] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
+  const char* names[7] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
                           "C two streams per group, both on all CUs",
-                          "D one stream per group, work-claiming kernels that keep to 6/8 (attention) and 2/8 (dense) of the CUs"};
+                          "D one stream per group, work-claiming kernels that keep to 6/8 (attention) and 2/8 (dense) of the CUs",
+                          "A' = A with a dependent 4 KB read in every GEMM-like launch",
+                          "E0 one launch per layer and group, dense stages wait on ready counters, weights loaded AFTER the wait",
+                          "E1 as E0, weights prefetched into registers BEFORE the wait"};
+  float* bufs[G][4];
+  int* flags[G];
+  for (int g = 0; g < G; ++g) {
+    for (int b = 0; b < 4; ++b) {
+      CK(hipMalloc(&bufs[g][b], 104 * 1024 * 4));
+      CK(hipMemset(bufs[g][b], 0, 104 * 1024 * 4));
+    }
+    CK(hipMalloc(&flags[g], (kSteps + 10) * kLayers * 4 * 4));
+  }
+  const int only = argc > 1 ? atoi(argv[1]) : -1;          // run one variant only (0..6); default: A, A', E0, E1
   // one claim counter per launch of variant D
   constexpr int kLaunches = (kSteps + 10) * kLayers * (1 + kDense);
   int* counters[G];
   for (int g = 0; g < G; ++g) CK(hipMalloc(&counters[g], kLaunches * 4));
-  for (int variant = 0; variant < 4; ++variant) {
+  for (int variant = 0; variant < 7; ++variant) {
+    if (only >= 0 ? variant != only : (variant >= 1 && variant <= 3)) continue;     // B, C, D: round 4's results stand
     for (int g = 0; g < G; ++g) CK(hipMemset(counters[g], 0, kLaunches * 4));
+    for (int g = 0; g < G; ++g) CK(hipMemset(flags[g], 0, (kSteps + 10) * kLayers * 4 * 4));
     hipStream_t sa[G], sd[G];
     hipEvent_t e1[G], e2[G];
     // creation order: the four attention streams first, then the four dense streams
     for (int g = 0; g < G; ++g)
       if (make_stream(&sa[g], 0, variant == 1 ? 6 : 8)) return 1;
     for (int g = 0; g < G; ++g) {
-      if (variant == 0 || variant == 3) sd[g] = sa[g];
+      if (variant == 0 || variant >= 3) sd[g] = sa[g];
       else if (make_stream(&sd[g], variant == 1 ? 6 : 0, 8)) return 1;
       CK(hipEventCreateWithFlags(&e1[g], hipEventDisableTiming));
       CK(hipEventCreateWithFlags(&e2[g], hipEventDisableTiming));
@@ -133,8 +225,29 @@ int main() {
       (void)hipSetDevice(0);
       int slice = g * 3;
       int* ctr = counters[g] + c0;
+      int* fl = flags[g] + c0;                       // (c0 counts 4 launches per layer: also 4 flags per fused launch)
       for (int t = 0; t < steps; ++t)
         for (int l = 0; l < kLayers; ++l) {
+          if (variant >= 5) {
+            const f32x4_t* kvl = kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16);
+            if (variant == 5)
+              hipLaunchKernelGGL(k_layer_fused<false>, dim3(384 + 3 * 104), dim3(256), 0, sa[g], kvl, sink, weights, bufs[g][0],
+                                 bufs[g][1], bufs[g][2], bufs[g][3], slice % 14, fl);
+            else
+              hipLaunchKernelGGL(k_layer_fused<true>, dim3(384 + 3 * 104), dim3(256), 0, sa[g], kvl, sink, weights, bufs[g][0],
+                                 bufs[g][1], bufs[g][2], bufs[g][3], slice % 14, fl);
+            fl += 4;
+            slice += 3;
+            continue;
+          }
+          if (variant == 4) {
+            hipLaunchKernelGGL(k_attn_like, dim3(384), dim3(192), 0, sa[g], kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16), sink);
+            for (int d = 0; d < kDense; ++d) {
+              hipLaunchKernelGGL(k_gemm_dep, dim3(104), dim3(256), 0, sa[g], weights, bufs[g][d + 1], bufs[g][d], slice % 14);
+              ++slice;
+            }
+            continue;
+          }
           if (variant == 3) {
             // 512 workgroups: about three quarters of them land on allowed CUs and claim the 384 items
             hipLaunchKernelGGL(k_attn_claim, dim3(512), dim3(192), 0, sa[g], kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16), sink, ctr++, 384);

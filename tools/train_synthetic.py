@@ -65,11 +65,15 @@ def make_batch(args):
     rng = np.random.default_rng(seed)
     on, off, pitch, amp, fidx = [], [], [], [], []
     tgt = np.zeros((files * FILE_SEGMENTS, MAX_TARGET), np.int64)
-    seconds = FILE_SEGMENTS * SEG_FRAMES * HOP / 16000.0
+    counts = np.full(files * FILE_SEGMENTS, SEG_FRAMES, np.int32)           # audio frames per segment (the last may be short)
     for f in range(files):
-        ns = synthetic.random_music(seconds, seed=int(rng.integers(1 << 62)),
+        # one file in six ends inside its last segment, as real files do (NB:318-335: the last segment is short, its
+        # log-mel rows are 0 after the audio): the model has to stop there
+        n_frames = FILE_SEGMENTS * SEG_FRAMES if rng.random() > 1.0 / 6.0 else int(rng.integers(3 * SEG_FRAMES + 8, 4 * SEG_FRAMES))
+        counts[f * FILE_SEGMENTS + FILE_SEGMENTS - 1] = n_frames - (FILE_SEGMENTS - 1) * SEG_FRAMES
+        ns = synthetic.random_music(n_frames * HOP / 16000.0, seed=int(rng.integers(1 << 62)),
                                     notes_per_second=float(rng.uniform(2.0, 9.0)))
-        for i, t in enumerate(file_targets(ns, _CODEC, FILE_SEGMENTS * SEG_FRAMES)):
+        for i, t in enumerate(file_targets(ns, _CODEC, n_frames)):
             t = t[:MAX_TARGET]
             tgt[f * FILE_SEGMENTS + i, : len(t)] = t
         on += [n.start_time for n in ns.notes]
@@ -78,7 +82,7 @@ def make_batch(args):
         fidx += [f] * len(ns.notes)
     amp = rng.uniform(0.3, 1.0, len(on))
     return {"on": np.array(on), "off": np.array(off), "pitch": np.array(pitch), "amp": amp,
-            "file": np.array(fidx, np.int64), "targets": tgt, "seed": seed}
+            "file": np.array(fidx, np.int64), "targets": tgt, "seed": seed, "counts": counts}
 
 
 # ------------------------------------------------------------------------------------------------ network (torch)
@@ -196,7 +200,9 @@ def main():
                                        seed=int(b["seed"]) & 0x7FFFFFFF, device=dev)
         audio = audio.reshape(args.files * FILE_SEGMENTS, SEG_FRAMES * HOP)
         if dev == "cuda":
-            logmel = spectrograms.compute_spectrogram_batch(audio, None)                     # the product's frontend kernel
+            for i in np.nonzero(b["counts"] < SEG_FRAMES)[0]:
+                audio[i, int(b["counts"][i]) * HOP:] = 0.0                                  # nothing after the end of a file
+            logmel = spectrograms.compute_spectrogram_batch(audio, b["counts"])              # the product's frontend kernel
         else:                                                                               # CPU dry run of the script only
             spec = torch.stft(audio, 2048, 128, window=torch.hann_window(2048), center=False, return_complex=True)
             logmel = torch.log(spec.abs().transpose(1, 2)[:, :, :512].clamp_min(1e-5))
