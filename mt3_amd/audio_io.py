@@ -2,9 +2,24 @@
 
 The notebook uses `note_seq.audio_io.wav_data_to_samples_librosa` and `librosa.resample`
 (mt3/preprocessors.py:139-144); neither is available here.  This module decodes PCM WAV with the
-standard library / scipy and resamples with a polyphase Kaiser filter (`scipy.signal.resample_poly`).
-The resampling filter differs from librosa's -- PARITY UNPINNED (inputs already at 16 kHz are
-bit-identical).
+standard library / scipy and resamples by band-limited sinc interpolation with resampy's
+"kaiser_best" filter -- librosa's default `res_type` in the releases of the reference's time --
+evaluated exactly on the polyphase grid (`resample(..., res_type="kaiser_best")`, the default since
+round 6).  Filter parameters are from memory of resampy: PARITY UNPINNED against librosa itself
+(inputs already at 16 kHz are bit-identical, no filter runs).
+
+What the choice of filter is worth, MEASURED (tests/test_io_and_metrics.py::test_resampling_filters_measured,
+44.1 kHz -> 16 kHz): scipy's default polyphase low-pass (`res_type="polyphase"`, rounds 3-5's ingest:
+Kaiser(5.0), 10 zero crossings a side, cut-off AT the new Nyquist rate) passes a 8.2 kHz tone at
+-8.7 dB and a 9 kHz tone at -30.6 dB -- they alias to 7.8 / 7.0 kHz, inside the mel range (20 Hz ..
+7.6 kHz, mt3/spectrograms.py:27-28) -- where kaiser_best is below -150 dB from 8.2 kHz on; kaiser_best
+in turn rolls off earlier (-3.1 dB at 7.5 kHz, -22.6 dB at 7.8 kHz; polyphase -1.8 / -4.0 dB).  Both are
+flat to 0.01 dB up to 7 kHz.  On a fixture with partials up to 20 kHz the two 16 kHz signals differ at
+29.7 dB SNR and their log-mels by up to 5.7 (natural log; mean 0.07) -- aliased partials in the upper mel
+bands -- so the filter is NOT a detail for material with energy above 8 kHz.  On band-limited material
+(five steady partials up to 6 kHz) the partials themselves (mel > 0.1) agree to 0.004 in the log-mel; the
+floor between them (mel 1e-3 .. 1e-1, 40-70 dB below the partials) still moves by up to 1.8: that is the
+polyphase filter's -66 dB stop band, not a property of the material.
 """
 from __future__ import annotations
 
@@ -32,12 +47,41 @@ def wav_data_to_samples(wav_data, sample_rate: int = SAMPLE_RATE) -> np.ndarray:
     return resample(y, native_sr, sample_rate)
 
 
-def resample(y: np.ndarray, orig_sr: int, target_sr: int = SAMPLE_RATE) -> np.ndarray:
+# resampy's "kaiser_best" filter, which `librosa.resample` / `librosa.load` used by default in the librosa releases of the
+# reference's time (res_type='kaiser_best'; mt3/preprocessors.py:139-144, NB:165) [parameters from memory of resampy's
+# published filter: a Kaiser-windowed sinc with 64 zero crossings, beta 14.7697, roll-off 0.9476 of the lower Nyquist rate]
+KAISER_BEST = {"num_zeros": 64, "beta": 14.769656459379492, "rolloff": 0.9475937167399596}
+
+
+def kaiser_sinc_kernel(tau: np.ndarray, scale: float, num_zeros: int, beta: float, rolloff: float) -> np.ndarray:
+    """g(tau), tau in INPUT samples: y(t) = sum_n x[n] g(t - n).  scale = min(1, target_sr / orig_sr) stretches the filter
+    when downsampling (and carries the gain): g = scale * rolloff * sinc(rolloff * scale * tau) * kaiser(scale * |tau| / zeros)."""
+    t = scale * np.abs(np.asarray(tau, np.float64))
+    inside = t <= num_zeros
+    taper = np.i0(beta * np.sqrt(np.clip(1.0 - (t / num_zeros) ** 2, 0.0, 1.0))) / np.i0(beta)
+    return np.where(inside, scale * rolloff * np.sinc(rolloff * t) * taper, 0.0)
+
+
+def resample(y: np.ndarray, orig_sr: int, target_sr: int = SAMPLE_RATE, res_type: str = "kaiser_best") -> np.ndarray:
+    """res_type: "polyphase" = scipy.signal.resample_poly's own Kaiser(5.0) low-pass of 20 x max(up, down) + 1
+    taps; "kaiser_best" (default) = the band-limited sinc interpolation of resampy's kaiser_best filter (see KAISER_BEST), evaluated
+    EXACTLY on the polyphase grid (resampy itself interpolates a 512-per-zero-crossing table linearly: ~1e-6 relative).
+    Measured difference between the two on a 44.1 kHz fixture and its effect on the log-mel: module docstring,
+    tests/test_io_and_metrics.py::test_resampling_filters_measured."""
     if orig_sr == target_sr:
         return np.ascontiguousarray(y, np.float32)
     from scipy.signal import resample_poly
     frac = Fraction(int(target_sr), int(orig_sr))
-    return resample_poly(y.astype(np.float64), frac.numerator, frac.denominator).astype(np.float32)
+    up, down = frac.numerator, frac.denominator
+    if res_type == "polyphase":
+        return resample_poly(y.astype(np.float64), up, down).astype(np.float32)
+    if res_type != "kaiser_best":
+        raise ValueError("res_type must be 'polyphase' or 'kaiser_best'")
+    scale = min(1.0, up / down)
+    half = int(np.ceil(KAISER_BEST["num_zeros"] / scale * up))              # taps each side at the up-sampled rate
+    k = np.arange(-half, half + 1)
+    h = kaiser_sinc_kernel(k / up, scale, **KAISER_BEST) / up                 # (resample_poly multiplies the filter by `up`)
+    return resample_poly(y.astype(np.float64), up, down, window=h).astype(np.float32)
 
 
 def samples_to_wav_data(samples: np.ndarray, sample_rate: int = SAMPLE_RATE) -> bytes:

@@ -104,14 +104,31 @@ def read_zarr_array(path: str) -> np.ndarray:
     return _bf16_to_f32(out) if is_bf16 else out
 
 
+def _f32_to_bf16_bits(a: np.ndarray) -> np.ndarray:
+    """float32 -> bfloat16 bit patterns (round to nearest even), as a '<u2' array"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype("<u2")
+
+
 def write_zarr_array(path: str, arr: np.ndarray, chunks: Optional[Tuple[int, ...]] = None,
-                     compressor: Optional[str] = "gzip") -> None:
+                     compressor: Optional[str] = "gzip", store_dtype: Optional[str] = None,
+                     dimension_separator: Optional[str] = None) -> None:
+    """store_dtype="bfloat16": the values are rounded to bfloat16 and stored as 2-byte patterns under the zarr dtype
+    string "bfloat16" (what TensorStore writes for a bf16 parameter); dimension_separator "/" nests the chunk files."""
     arr = np.asarray(arr)
+    dtype_str = arr.dtype.str
+    if store_dtype == "bfloat16":
+        arr, dtype_str = _f32_to_bf16_bits(arr).reshape(arr.shape), "bfloat16"
+    elif store_dtype is not None:
+        arr = arr.astype(store_dtype)
+        dtype_str = arr.dtype.str
     chunks = tuple(chunks) if chunks is not None else tuple(max(1, s) for s in arr.shape)
     os.makedirs(path, exist_ok=True)
     meta = {"chunks": list(chunks), "compressor": {"id": compressor, "level": 1} if compressor else None,
-            "dtype": arr.dtype.str, "fill_value": None, "filters": None, "order": "C",
+            "dtype": dtype_str, "fill_value": None, "filters": None, "order": "C",
             "shape": list(arr.shape), "zarr_format": 2}
+    if dimension_separator:
+        meta["dimension_separator"] = dimension_separator
     with open(os.path.join(path, ".zarray"), "w") as f:
         json.dump(meta, f)
     grid = [()] if arr.ndim == 0 else np.ndindex(*[-(-s // c) for s, c in zip(arr.shape, chunks)])
@@ -127,7 +144,9 @@ def write_zarr_array(path: str, arr: np.ndarray, chunks: Optional[Tuple[int, ...
             raw = zlib.compress(raw, 1)
         elif compressor is not None:
             raise CheckpointError("unsupported compressor %r" % (compressor,))
-        with open(os.path.join(path, ".".join(str(i) for i in idx) if idx else "0"), "wb") as f:
+        cpath = os.path.join(path, (dimension_separator or ".").join(str(i) for i in idx) if idx else "0")
+        os.makedirs(os.path.dirname(cpath), exist_ok=True)
+        with open(cpath, "wb") as f:
             f.write(raw)
 
 
@@ -218,10 +237,15 @@ def load_t5x_checkpoint(ckpt_dir: str, dtype=np.float32, expected: Optional[Iter
 
 
 def save_t5x_checkpoint(ckpt_dir: str, params: Dict[str, np.ndarray], step: int = 0,
-                        inline_below: int = 0, chunk_rows: Optional[int] = None) -> None:
+                        inline_below: int = 0, chunk_rows: Optional[int] = None, store_dtype: Optional[str] = None,
+                        dimension_separator: Optional[str] = None, optimizer_state: Optional[Dict[str, Any]] = None) -> None:
     """Write `params` ({'a/b/c': array}) in the layout above.  Arrays with fewer than `inline_below`
     elements go inline into the msgpack index (t5x does this for leaves without partitioning axes);
-    `chunk_rows` splits the first axis into chunks of that many rows (t5x chunks per shard)."""
+    `chunk_rows` splits the first axis into chunks of that many rows (t5x chunks per shard: a parameter sharded over
+    the 'data' / 'model' mesh axes is one zarr array whose chunks are the shards); store_dtype="bfloat16" stores bf16
+    (a checkpoint saved with `dtype='bfloat16'`; the reader widens it, as restoring with dtype='float32' does, NB:255-256);
+    optimizer_state: extra entries of `optimizer.state` next to `step` (e.g. Adafactor's `param_states`: arrays inline) --
+    everything outside `optimizer.target` is ignored by `load_t5x_checkpoint`."""
     import msgpack
     os.makedirs(ckpt_dir, exist_ok=True)
     tree: Dict[str, Any] = {}
@@ -239,11 +263,22 @@ def save_t5x_checkpoint(ckpt_dir: str, params: Dict[str, np.ndarray], step: int 
         chunks = None
         if chunk_rows and arr.ndim >= 1:
             chunks = (min(chunk_rows, max(1, arr.shape[0])),) + tuple(max(1, s) for s in arr.shape[1:])
-        write_zarr_array(os.path.join(ckpt_dir, sub), arr, chunks=chunks)
+        write_zarr_array(os.path.join(ckpt_dir, sub), arr, chunks=chunks, store_dtype=store_dtype,
+                         dimension_separator=dimension_separator)
         node[keys[-1]] = {"driver": "zarr", "kvstore": {"driver": "file", "path": sub},
-                          "metadata": {"shape": list(arr.shape), "dtype": arr.dtype.str,
+                          "metadata": {"shape": list(arr.shape), "dtype": store_dtype or arr.dtype.str,
                                        "chunks": list(chunks or arr.shape), "compressor": {"id": "gzip"}}}
-    index = {"version": 3, "optimizer": {"target": tree, "state": {"step": int(step)}}}
+
+    def pack_state(node):
+        if isinstance(node, dict):
+            return {k: pack_state(v) for k, v in node.items()}
+        if isinstance(node, np.ndarray):
+            return msgpack.ExtType(_FLAX_EXT_NDARRAY,
+                                   msgpack.packb((list(node.shape), node.dtype.name, node.tobytes()), use_bin_type=True))
+        return node
+    state = {"step": int(step)}
+    state.update(pack_state(optimizer_state or {}))
+    index = {"version": 3, "optimizer": {"target": tree, "state": state}}
     with open(os.path.join(ckpt_dir, "checkpoint"), "wb") as f:
         f.write(msgpack.packb(index, use_bin_type=True))
 

@@ -218,3 +218,36 @@ def test_hand_typed_checkpoint_directory(tmp_path):
     meta_ours = json.loads((tmp_path / "ours" / path / ".zarray").read_text())
     meta_hand = json.loads((d / path / ".zarray").read_text())
     assert set(meta_ours) == set(meta_hand) and meta_ours["dtype"] == "<f4" and meta_ours["shape"] == [4, 6]
+
+
+def test_train_state_shaped_checkpoint_bf16_sharded_with_optimizer_state(tmp_path):
+    """The shape of a checkpoint t5x writes for a TRAINED model (layout from t5x's documented structure,
+    unpinned against a real one): train state {'version', 'optimizer': {'target', 'state': {'step', 'param_states'}}},
+    every partitioned parameter a TensorStore zarr spec whose chunks are the shards (smaller than the array, along axis 0),
+    values stored as bfloat16, small leaves (norm scales) and ALL optimizer state inline; '/'-separated chunk keys as well.
+    `load_t5x_checkpoint` returns the model parameters only, widened to float32 (restore dtype='float32', NB:255-256)."""
+    cfg, params = _small_params(seed=9)
+    rng = np.random.default_rng(1)
+    adafactor = {"param_states": {"decoder": {"logits_dense": {"kernel": {
+        "v_row": rng.random(64).astype(np.float32), "v_col": rng.random(40).astype(np.float32), "m": np.zeros(1, np.float32)}}}}}
+    want = {k: (CK._bf16_to_f32(CK._f32_to_bf16_bits(v)).reshape(v.shape) if v.size >= 100 else v) for k, v in params.items()}
+    for sep in (None, "/"):
+        d = str(tmp_path / ("ck" + ("_slash" if sep else "")))
+        CK.save_t5x_checkpoint(d, params, step=400000, inline_below=100, chunk_rows=24, store_dtype="bfloat16",
+                               dimension_separator=sep, optimizer_state=adafactor)
+        wi = os.path.join(d, "target.encoder.layers_0.mlp.wi_0.kernel")                       # [64, 96] in shards of 24 rows
+        with open(os.path.join(wi, ".zarray")) as f:
+            meta = json.load(f)
+        assert meta["dtype"] == "bfloat16" and meta["chunks"] == [24, 96] and meta["shape"] == [64, 96]
+        assert meta["compressor"]["id"] == "gzip" and meta.get("dimension_separator") == sep
+        assert os.path.isfile(os.path.join(wi, "2/0" if sep else "2.0")) and not os.path.exists(os.path.join(wi, "3/0" if sep else "3.0"))
+        idx = CK.read_index(d)
+        assert idx["version"] == 3 and idx["optimizer"]["state"]["step"] == 400000
+        assert idx["optimizer"]["state"]["param_states"]["decoder"]["logits_dense"]["kernel"]["v_row"].shape == (64,)
+        got = CK.load_t5x_checkpoint(d, expected=network.param_shapes(cfg))
+        assert set(got) == set(params)                                                      # no optimizer state leaks in
+        for k in params:
+            assert got[k].dtype == np.float32 and np.array_equal(got[k], want[k]), k
+        # bf16 storage costs 2^-9 relative at most
+        k = "decoder/logits_dense/kernel"
+        assert 0 < np.abs(got[k] - params[k]).max() <= np.abs(params[k]).max() * 2.0 ** -8

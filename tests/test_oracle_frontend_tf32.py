@@ -63,3 +63,20 @@ def test_log_domain_distance_of_the_f32_leaves_from_the_f64_oracle(source):
     assert worst_lin < 1e-4
     assert worst_strong < 3e-3
     assert worst_mid < 6e-3
+
+
+def test_the_shipped_tables_are_frozen_by_hash():
+    """the default frontend tables are the float32-in-TF's-op-order construction, restated from memory and
+    still unpinned against TensorFlow itself.  Until a real `tf.signal.linear_to_mel_weight_matrix` / `hann_window` dump
+    exists (tests/golden/export_with_reference_stack.py writes one; tests/test_external_fixtures.py compares), the tables
+    are FROZEN here: the product's are bit-identical to these (tests/test_frontend_emulation.py::test_tables_match_oracle
+    on the CPU, tests/test_gpu_kernels.py on the device), so any change to either construction -- a libm with a different
+    log / cos rounding included -- fails this test instead of silently moving every log-mel by up to 2.8e-3."""
+    import hashlib
+    want = {"mel_tf32": "de2f07447c83dbe9b169809f7712267b", "hann_tf32": "6a99fe5c009c51e2818a8a26a5c7e941",
+            "mel_f64": "95ff654aa46513aced5b68fda793ab65", "hann_f64": "45e527e31152d8e3c95289e492e40f09"}
+    got = {"mel_tf32": F.mel_weight_matrix_tf32(), "hann_tf32": F.hann_periodic_tf32(),
+           "mel_f64": F.mel_weight_matrix(), "hann_f64": F.hann_periodic()}
+    for k, a in got.items():
+        assert hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:32] == want[k], k
+    assert got["mel_tf32"].dtype == np.float32 and got["mel_tf32"].shape == (1025, 512) and int((got["mel_tf32"] != 0).sum()) == 1934

@@ -6,6 +6,9 @@
 #   bench                the driver's bench command (BENCH_ARGS, default --gpus 1 --steps 20 --warmup 5) + digest
 #   prof                 rocprofv3 --kernel-trace --stats of the f32 bench command + trace digest
 #   tol                  tools/note_tolerance.py (TOL_ARGS)
+#   pmcdec               rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_decode.py -> per-kernel HBM bytes (PMC_STEPS)
+#   pmcattn              the same two passes over tools/pmc_attn.py -> <TAG>_pmc_summary.json (roofline.traffic)
+#   micro                tools/micro/<MICRO> (default cu_split_groups)
 #   run                  RUN_CMD verbatim (one-off probes)
 # Environment: TAG, TESTS, BENCH_ARGS, TOL_ARGS, RUN_CMD.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
@@ -41,6 +44,31 @@ for stage in "$@"; do
       timeout 900 python tools/note_tolerance.py ${TOL_ARGS} > "gpurun_out/${TAG}_note_tolerance_$(echo ${TOL_ARGS} | tr -c 'a-zA-Z0-9\n' '_').log" 2>&1
       echo "exit $? : note_tolerance ${TOL_ARGS} after $(( $(date +%s) - t0 )) s"
       grep -h '^NOTE_TOLERANCE' gpurun_out/${TAG}_note_tolerance_*.log | tail -1 | cut -c1-3000 ;;
+    pmcdec)
+      # FETCH_SIZE / WRITE_SIZE passes over the PRODUCT decode schedule, reduced per kernel name (VERDICT r5 #3a)
+      rm -rf gpurun_out/pmcdec; mkdir -p gpurun_out/pmcdec
+      for c in FETCH_SIZE WRITE_SIZE; do
+        ( cd /tmp && timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmcdec" -o $c -- \
+            python "$R/tools/pmc_decode.py" > "$R/gpurun_out/pmcdec/$c.log" 2>&1 )
+        echo "exit $? : pmc decode $c after $(( $(date +%s) - t0 )) s"
+      done
+      python tools/pmc_decode_summary.py gpurun_out/pmcdec "gpurun_out/${TAG}_pmc_decode_per_kernel.json" ${PMC_STEPS:-32} 2>&1 | tail -30
+      find gpurun_out/pmcdec -name "*.db" -delete; find gpurun_out/pmcdec -name "*.csv" -size +2M -delete ;;
+    pmcattn)
+      # the standalone decode-attention / frontend passes bench.py's roofline.traffic reads (tools/pmc_attn.py)
+      rm -rf gpurun_out/pmc; mkdir -p gpurun_out/pmc
+      for c in FETCH_SIZE WRITE_SIZE; do
+        ( cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$R/gpurun_out/pmc" -o $c -- \
+            python "$R/tools/pmc_attn.py" > "$R/gpurun_out/pmc/$c.log" 2>&1 )
+        echo "exit $? : pmc attn $c"
+      done
+      python tools/pmc_summary.py gpurun_out/pmc gpurun_out/pmc "${TAG}" > gpurun_out/pmc/summary.log 2>&1; tail -12 gpurun_out/pmc/summary.log
+      find gpurun_out/pmc -name "*.db" -delete; find gpurun_out/pmc -name "*kernel_trace.csv" -size +4M -delete ;;
+    micro)
+      # stand-alone micro-benchmarks under tools/micro (MICRO = binary [args]); built here if the binary did not travel
+      b=$(echo ${MICRO:-cu_split_groups} | cut -d' ' -f1)
+      [ -x "tools/micro/$b" ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 "tools/micro/$b.hip" -o "tools/micro/$b" -lpthread
+      ( cd tools/micro && timeout 600 ./${MICRO:-cu_split_groups} ) 2>&1 | tee "gpurun_out/${TAG}_micro_${b}.txt" | tail -20 ;;
     run)
       bash -c "$RUN_CMD"; echo "exit $? : run after $(( $(date +%s) - t0 )) s" ;;
     *) echo "unknown stage $stage" ;;

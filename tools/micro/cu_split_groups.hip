@@ -67,6 +67,35 @@ __global__ __launch_bounds__(256) void k_gemm_dep(const f32x4_t* __restrict__ w,
   o[0] = acc[0] * a[0], o[1] = acc[1] * a[1], o[2] = acc[2] * a[2], o[3] = acc[3] * a[3];
 }
 
+// F (VERDICT r5 #3b, the out-projection inside the attention epilogue): the attention-like workgroups are (row, head) pairs,
+// six per row; the LAST of a row's six to finish (a counter per row) projects the row itself -- a GEMV over the whole
+// 1.4 MB out-projection matrix (896 x 384 f32), read by every one of the 64 rows -- instead of a 22-workgroup GEMM-like
+// launch that reads the matrix once per 32-row tile.
+__global__ __launch_bounds__(192) void k_attn_gemv_tail(const f32x4_t* __restrict__ in, float* __restrict__ sink,
+                                                        const f32x4_t* __restrict__ w, float* __restrict__ out, int* row_cnt) {
+  const f32x4_t* src = in + static_cast<size_t>(blockIdx.x) * (512 * 1024 / 16);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < 512 * 1024 / 16; i += 192) {
+    const f32x4_t v = __builtin_nontemporal_load(src + i);
+    acc += v[0] + v[1] + v[2] + v[3];
+  }
+  if (acc == 123.456f) sink[blockIdx.x] = acc;
+  __shared__ int last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    last = atomicAdd(row_cnt + blockIdx.x / 6, 1) == 5;
+  }
+  __syncthreads();
+  if (!last) return;
+  // the row's projection: 896 x 384 f32 = 86,016 16-byte words, 448 per thread
+  f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+  for (int i = threadIdx.x; i < 896 * 384 / 4; i += 192) a += w[i];
+  float* o = out + (blockIdx.x / 6) * 1024 + threadIdx.x * 4;
+  o[0] = a[0], o[1] = a[1], o[2] = a[2], o[3] = a[3];
+}
+
 // E: one launch per layer and group.  flags[0] counts finished attention-like workgroups, flags[1 + d] the finished tiles of
 // dense stage d; bufs[d] is the output of stage d (stage 0 reads `attn_out`, which the attention-like workgroups touch).
 template <bool PREFETCH>
@@ -186,12 +215,16 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&out[g], 104 * 1024 * 4));
     CK(hipMemset(out[g], 0, 104 * 1024 * 4));
   }
-  const char* names[7] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
+  const char* names[9] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
                           "C two streams per group, both on all CUs",
                           "D one stream per group, work-claiming kernels that keep to 6/8 (attention) and 2/8 (dense) of the CUs",
                           "A' = A with a dependent 4 KB read in every GEMM-like launch",
                           "E0 one launch per layer and group, dense stages wait on ready counters, weights loaded AFTER the wait",
-                          "E1 as E0, weights prefetched into registers BEFORE the wait"};
+                          "E1 as E0, weights prefetched into registers BEFORE the wait",
+                          "A'' = A' with the FIRST dense launch of a layer at the out-projection's size (22 workgroups, 1.4 MB)",
+                          "F  = A'' with that launch replaced by a per-row GEMV in the tail of the attention-like kernel"};
+  int* row_cnt[G];
+  for (int g = 0; g < G; ++g) CK(hipMalloc(&row_cnt[g], (kSteps + 10) * kLayers * 64 * 4));
   float* bufs[G][4];
   int* flags[G];
   for (int g = 0; g < G; ++g) {
@@ -201,12 +234,13 @@ int main(int argc, char** argv) {
     }
     CK(hipMalloc(&flags[g], (kSteps + 10) * kLayers * 4 * 4));
   }
-  const int only = argc > 1 ? atoi(argv[1]) : -1;          // run one variant only (0..6); default: A, A', E0, E1
+  const int only = argc > 1 ? atoi(argv[1]) : -1;          // run one variant only (0..8); default: all but B, C, D
   // one claim counter per launch of variant D
   constexpr int kLaunches = (kSteps + 10) * kLayers * (1 + kDense);
   int* counters[G];
   for (int g = 0; g < G; ++g) CK(hipMalloc(&counters[g], kLaunches * 4));
-  for (int variant = 0; variant < 7; ++variant) {
+  for (int variant = 0; variant < 9; ++variant) {
+    for (int g = 0; g < G; ++g) CK(hipMemset(row_cnt[g], 0, (kSteps + 10) * kLayers * 64 * 4));
     if (only >= 0 ? variant != only : (variant >= 1 && variant <= 3)) continue;     // B, C, D: round 4's results stand
     for (int g = 0; g < G; ++g) CK(hipMemset(counters[g], 0, kLaunches * 4));
     for (int g = 0; g < G; ++g) CK(hipMemset(flags[g], 0, (kSteps + 10) * kLayers * 4 * 4));
@@ -238,6 +272,22 @@ int main(int argc, char** argv) {
                                  bufs[g][1], bufs[g][2], bufs[g][3], slice % 14, fl);
             fl += 4;
             slice += 3;
+            continue;
+          }
+          if (variant >= 7) {
+            const f32x4_t* kvl = kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16);
+            if (variant == 7) {
+              hipLaunchKernelGGL(k_attn_like, dim3(384), dim3(192), 0, sa[g], kvl, sink);
+              hipLaunchKernelGGL(k_gemm_dep, dim3(22), dim3(256), 0, sa[g], weights, bufs[g][1], bufs[g][0], slice % 14);
+            } else {
+              hipLaunchKernelGGL(k_attn_gemv_tail, dim3(384), dim3(192), 0, sa[g], kvl, sink, weights + (slice % 14) * (104 * 64 * 1024 / 16),
+                                 bufs[g][1], row_cnt[g] + (c0 / 4 + t * kLayers + l) * 64);
+            }
+            ++slice;
+            for (int d = 1; d < kDense; ++d) {
+              hipLaunchKernelGGL(k_gemm_dep, dim3(104), dim3(256), 0, sa[g], weights, bufs[g][d + 1], bufs[g][d], slice % 14);
+              ++slice;
+            }
             continue;
           }
           if (variant == 4) {
