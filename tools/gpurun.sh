@@ -8,6 +8,8 @@
 #   tol                  tools/note_tolerance.py (TOL_ARGS)
 #   pmcdec               rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/pmc_decode.py -> per-kernel HBM bytes (PMC_STEPS)
 #   pmcattn              the same two passes over tools/pmc_attn.py -> <TAG>_pmc_summary.json (roofline.traffic)
+#   pmcenc               SQ / MFMA counter passes over one 256-segment encoder pass (tools/pmc_encoder.py) -> <TAG>_pmc_encoder_summary.json
+#   pmcfe                SQ counter passes over the log-mel kernel (tools/pmc_frontend.py) -> <TAG>_pmc_frontend_counters.json
 #   micro                tools/micro/<MICRO> (default cu_split_groups)
 #   run                  RUN_CMD verbatim (one-off probes)
 # Environment: TAG, TESTS, BENCH_ARGS, TOL_ARGS, RUN_CMD.
@@ -64,6 +66,30 @@ for stage in "$@"; do
       done
       python tools/pmc_summary.py gpurun_out/pmc gpurun_out/pmc "${TAG}" > gpurun_out/pmc/summary.log 2>&1; tail -12 gpurun_out/pmc/summary.log
       find gpurun_out/pmc -name "*.db" -delete; find gpurun_out/pmc -name "*kernel_trace.csv" -size +4M -delete ;;
+    pmcenc)
+      # where the encoder waves' cycles go (sq) and matrix-pipe busy cycles / MFMA op counts (mfma), bf16 + MXFP8 + f32 engines
+      rm -rf gpurun_out/pmc_enc; mkdir -p gpurun_out/pmc_enc
+      ( cd /tmp && timeout 240 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+          --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_enc" -o sq -- python "$R/tools/pmc_encoder.py" > "$R/gpurun_out/pmc_enc/sq.log" 2>&1 )
+      echo "exit $? : encoder sq pass"
+      ( cd /tmp && timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVES \
+          --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_enc" -o mfma -- python "$R/tools/pmc_encoder.py" > "$R/gpurun_out/pmc_enc/mfma.log" 2>&1 )
+      echo "exit $? : encoder mfma pass"
+      python tools/pmc_encoder_summary.py gpurun_out/pmc_enc "gpurun_out/${TAG}_pmc_encoder_summary.json" 2>&1 | tail -30
+      find gpurun_out/pmc_enc -name "*.db" -delete; find gpurun_out/pmc_enc -name "*kernel_trace.csv" -size +4M -delete ;;
+    pmcfe)
+      rm -rf gpurun_out/pmc_fe; mkdir -p gpurun_out/pmc_fe
+      i=0
+      for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+                 "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_BUSY_CU_CYCLES" \
+                 "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES SQ_INST_CYCLES_VMEM" \
+                 "SQ_THREAD_CYCLES_VALU SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_UNALIGNED_STALL GRBM_GUI_ACTIVE"; do
+        ( cd /tmp && timeout 100 rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$R/gpurun_out/pmc_fe" -o p$i -- python "$R/tools/pmc_frontend.py" > "$R/gpurun_out/pmc_fe/p$i.log" 2>&1 )
+        echo "exit $? : frontend counter pass $i"
+        i=$((i + 1))
+      done
+      python tools/pmc_frontend_summary.py gpurun_out/pmc_fe "gpurun_out/${TAG}_pmc_frontend_counters.json" 2>&1 | tail -12
+      find gpurun_out/pmc_fe -name "*.db" -delete ;;
     micro)
       # stand-alone micro-benchmarks under tools/micro (MICRO = binary [args]); built here if the binary did not travel
       b=$(echo ${MICRO:-cu_split_groups} | cut -d' ' -f1)

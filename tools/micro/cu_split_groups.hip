@@ -9,13 +9,12 @@
 //   D  one stream per group again, the split done INSIDE the kernels: both kinds claim their work items from a counter,
 //      attention-like workgroups leave at once when HW_ID says they sit on one of the two last CUs of a shader engine,
 //      GEMM-like workgroups when they do not (profiles/r4_cu_mask_map.txt: that is the 6/8 - 2/8 split of B)
-//   E  (round 6, VERDICT r5 #3c) ONE launch per layer and group: 384 attention-like workgroups followed by the 3 x 104
-//      GEMM-like workgroups of the three dependent dense stages in the same grid; a dense workgroup waits on a ready
-//      counter in memory (stage 0: the 384 attention-like workgroups of its layer; stage d: the 104 tiles of stage d - 1 --
-//      workgroups are dispatched in blockIdx order, so a waiting consumer's producers are always resident or done), reads a
-//      4 KB slice of its producer's output, combines it with its 64 KB of weights and bumps the next counter.  E0 loads the
-//      weights AFTER the wait (what removing three launch boundaries per layer buys by itself), E1 BEFORE it, into
-//      registers (what a dense stage costs when its weight fetch hides behind the attention phase)
+//   E  (round 6, VERDICT r5 #3c) ONE PERSISTENT launch per layer and group (256 workgroups, one per CU and group, all four
+//      groups' workgroups resident): every workgroup streams its share of the layer's attention-like bytes, then 104 of
+//      them run the three dependent dense stages, each waiting on a ready counter in memory (stage 0: the 256 workgroups'
+//      attention shares; stage d: the 104 tiles of stage d - 1).  E0 loads a stage's 64 KB of weights AFTER its wait (what
+//      removing three launch boundaries per layer buys by itself), E1 BEFORE it, into registers (what a dense stage
+//      costs when its weight fetch hides behind the phase before it)
 //   A' = A with the same dependent read added to the GEMM-like launches (the like-for-like baseline of E)
 // Prints microseconds per group step for each.   hipcc --offload-arch=gfx950 -O3 cu_split_groups.hip -o cu_split_groups -lpthread
 #include <hip/hip_ext.h>
@@ -96,59 +95,73 @@ __global__ __launch_bounds__(192) void k_attn_gemv_tail(const f32x4_t* __restric
   o[0] = a[0], o[1] = a[1], o[2] = a[2], o[3] = a[3];
 }
 
-// E: one launch per layer and group.  flags[0] counts finished attention-like workgroups, flags[1 + d] the finished tiles of
-// dense stage d; bufs[d] is the output of stage d (stage 0 reads `attn_out`, which the attention-like workgroups touch).
+// E: one PERSISTENT launch per layer and group: 256 workgroups (one per CU and group: with four groups at once all 1024
+// workgroups are resident -- 16 waves per CU at <= 128 VGPRs -- so a waiting workgroup can never keep a producer from
+// being dispatched.  The first form of this variant, a 696-workgroup grid whose dense workgroups spun on their producers'
+// counters, DEADLOCKED with four groups in flight: dispatch is in order per XCD only, so consumers of group B fill XCD 5
+// while B's producers wait for slots on XCD 2 behind consumers of group A whose producers wait on XCD 5).
+// Every workgroup streams 3 of the layer's 768 attention-like half-items (256 KB each), then workgroups 0..103 run the
+// three dependent dense stages: wait on the ready counter (stage 0: 256 finished workgroups; stage d: 104 tiles of stage
+// d - 1), read a 4 KB slice of the producer's output, combine it with 64 KB of weights, publish.  PREFETCH: the weights
+// of stage 0 are requested BEFORE the attention phase and those of stage d + 1 before the wait for stage d's tiles.
 template <bool PREFETCH>
 __global__ __launch_bounds__(256) void k_layer_fused(const f32x4_t* __restrict__ kv, float* __restrict__ sink,
                                                      const f32x4_t* __restrict__ w, float* __restrict__ b0, float* __restrict__ b1,
                                                      float* __restrict__ b2, float* __restrict__ b3, int slice, int* flags) {
-  constexpr int kAttn = 384, kTiles = 104;
-  if (blockIdx.x < kAttn) {
-    if (threadIdx.x < 192) {
-      const f32x4_t* src = kv + static_cast<size_t>(blockIdx.x) * (512 * 1024 / 16);
-      float acc = 0.f;
-      for (int i = threadIdx.x; i < 512 * 1024 / 16; i += 192) {
-        const f32x4_t v = __builtin_nontemporal_load(src + i);
-        acc += v[0] + v[1] + v[2] + v[3];
+  constexpr int kTiles = 104, kWgs = 256;
+  const bool dense = blockIdx.x < kTiles;
+  f32x4_t wr[16];
+  auto load_weights = [&](int d) {
+    const f32x4_t* src = w + (static_cast<size_t>(slice + d) % 14 * 104 + blockIdx.x) * (64 * 1024 / 16);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wr[i] = src[threadIdx.x + i * 256];
+  };
+  if (PREFETCH && dense) load_weights(0);
+  float acc = 0.f;
+  for (int it = 0; it < 3; ++it) {
+    const f32x4_t* src = kv + (static_cast<size_t>(it) * kWgs + blockIdx.x) * (256 * 1024 / 16);
+    for (int i = threadIdx.x; i < 256 * 1024 / 16; i += 256) {
+      const f32x4_t v = __builtin_nontemporal_load(src + i);
+      acc += v[0] + v[1] + v[2] + v[3];
+    }
+  }
+  if (acc == 123.456f) sink[blockIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (!dense) return;
+  for (int d = 0; d < 3; ++d) {
+    if (threadIdx.x == 0) {
+      const int need = d == 0 ? kWgs : kTiles;
+      // bounded: a wait that does not end must not hang the GPU -- after ~50 ms the workgroup goes on and counts itself
+      long spins = 0;
+      while (__hip_atomic_load(flags + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > 400000) {
+          atomicAdd(flags + 7, 1);
+          break;
+        }
       }
-      if (acc == 123.456f) sink[blockIdx.x] = acc;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
+    if (!PREFETCH) load_weights(d);
+    f32x4_t a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a4 += wr[i];
+    const float* prev = d == 0 ? b0 : d == 1 ? b1 : b2;
+    float* out = d == 0 ? b1 : d == 1 ? b2 : b3;
+    const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(prev + ((blockIdx.x * 7) % 104) * 1024 + threadIdx.x * 4));
+    float* o = out + blockIdx.x * 1024 + threadIdx.x * 4;
+    o[0] = a4[0] * a[0], o[1] = a4[1] * a[1], o[2] = a4[2] * a[2], o[3] = a4[3] * a[3];
+    if (PREFETCH && d < 2) load_weights(d + 1);          // in flight while this stage is published and the next one awaited
+    __syncthreads();
     if (threadIdx.x == 0) {
-      __threadfence();
-      atomicAdd(flags, 1);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      __hip_atomic_fetch_add(flags + 1 + d, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return;
-  }
-  const int d = (blockIdx.x - kAttn) / kTiles, tile = (blockIdx.x - kAttn) % kTiles;
-  const f32x4_t* src = w + (static_cast<size_t>(slice + d) % 14 * 104 + tile) * (64 * 1024 / 16);
-  f32x4_t wr[16];
-  if (PREFETCH) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) wr[i] = src[threadIdx.x + i * 256];
-  }
-  if (threadIdx.x == 0) {
-    const int need = d == 0 ? kAttn : kTiles;
-    while (__hip_atomic_load(flags + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(4);
-    __threadfence();
-  }
-  __syncthreads();
-  if (!PREFETCH) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) wr[i] = src[threadIdx.x + i * 256];
-  }
-  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc += wr[i];
-  const float* prev = d == 0 ? b0 : d == 1 ? b1 : b2;
-  float* out = d == 0 ? b1 : d == 1 ? b2 : b3;
-  const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(prev + ((tile * 7) % 104) * 1024 + threadIdx.x * 4));
-  float* o = out + tile * 1024 + threadIdx.x * 4;
-  o[0] = acc[0] * a[0], o[1] = acc[1] * a[1], o[2] = acc[2] * a[2], o[3] = acc[3] * a[3];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    atomicAdd(flags + 1 + d, 1);
   }
 }
 
@@ -232,7 +245,7 @@ int main(int argc, char** argv) {
       CK(hipMalloc(&bufs[g][b], 104 * 1024 * 4));
       CK(hipMemset(bufs[g][b], 0, 104 * 1024 * 4));
     }
-    CK(hipMalloc(&flags[g], (kSteps + 10) * kLayers * 4 * 4));
+    CK(hipMalloc(&flags[g], (kSteps + 10) * kLayers * 8 * 4));
   }
   const int only = argc > 1 ? atoi(argv[1]) : -1;          // run one variant only (0..8); default: all but B, C, D
   // one claim counter per launch of variant D
@@ -243,7 +256,7 @@ int main(int argc, char** argv) {
     for (int g = 0; g < G; ++g) CK(hipMemset(row_cnt[g], 0, (kSteps + 10) * kLayers * 64 * 4));
     if (only >= 0 ? variant != only : (variant >= 1 && variant <= 3)) continue;     // B, C, D: round 4's results stand
     for (int g = 0; g < G; ++g) CK(hipMemset(counters[g], 0, kLaunches * 4));
-    for (int g = 0; g < G; ++g) CK(hipMemset(flags[g], 0, (kSteps + 10) * kLayers * 4 * 4));
+    for (int g = 0; g < G; ++g) CK(hipMemset(flags[g], 0, (kSteps + 10) * kLayers * 8 * 4));
     hipStream_t sa[G], sd[G];
     hipEvent_t e1[G], e2[G];
     // creation order: the four attention streams first, then the four dense streams
@@ -259,18 +272,18 @@ int main(int argc, char** argv) {
       (void)hipSetDevice(0);
       int slice = g * 3;
       int* ctr = counters[g] + c0;
-      int* fl = flags[g] + c0;                       // (c0 counts 4 launches per layer: also 4 flags per fused launch)
+      int* fl = flags[g] + 2 * c0;                   // (c0 counts 4 launches per layer; 8 flag words per fused launch)
       for (int t = 0; t < steps; ++t)
         for (int l = 0; l < kLayers; ++l) {
           if (variant >= 5) {
             const f32x4_t* kvl = kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16);
             if (variant == 5)
-              hipLaunchKernelGGL(k_layer_fused<false>, dim3(384 + 3 * 104), dim3(256), 0, sa[g], kvl, sink, weights, bufs[g][0],
+              hipLaunchKernelGGL(k_layer_fused<false>, dim3(256), dim3(256), 0, sa[g], kvl, sink, weights, bufs[g][0],
                                  bufs[g][1], bufs[g][2], bufs[g][3], slice % 14, fl);
             else
-              hipLaunchKernelGGL(k_layer_fused<true>, dim3(384 + 3 * 104), dim3(256), 0, sa[g], kvl, sink, weights, bufs[g][0],
+              hipLaunchKernelGGL(k_layer_fused<true>, dim3(256), dim3(256), 0, sa[g], kvl, sink, weights, bufs[g][0],
                                  bufs[g][1], bufs[g][2], bufs[g][3], slice % 14, fl);
-            fl += 4;
+            fl += 8;
             slice += 3;
             continue;
           }
@@ -337,8 +350,18 @@ int main(int argc, char** argv) {
     for (auto& t : th) t.join();
     CK(hipDeviceSynchronize());
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-    printf("%s: %.1f us per group step (%d layers of 1 attention-like + %d GEMM-like launches; four groups at once)\n",
-           names[variant], us / kSteps, kLayers, kDense);
+    long timed_out = 0;
+    if (variant == 5 || variant == 6) {
+      std::vector<int> h((kSteps + 10) * kLayers * 8);
+      for (int g = 0; g < G; ++g) {
+        CK(hipMemcpy(h.data(), flags[g], h.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 7; i < h.size(); i += 8) timed_out += h[i];
+      }
+    }
+    printf("%s: %.1f us per group step (%d layers of 1 attention-like + %d GEMM-like launches; four groups at once)%s\n",
+           names[variant], us / kSteps, kLayers, kDense, timed_out ? "  [WAITS TIMED OUT: result void]" : "");
+    if (timed_out) printf("   %ld waits gave up after ~50 ms\n", timed_out);
+    fflush(stdout);
     for (int g = 0; g < G; ++g) {
       (void)hipStreamDestroy(sa[g]);
       if (variant == 1 || variant == 2) (void)hipStreamDestroy(sd[g]);

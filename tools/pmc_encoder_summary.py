@@ -1,4 +1,4 @@
-"""Reduce the counter passes of tools/gpu_pmc_enc.sh to one JSON: per kernel of this library, the share of wave
+"""Reduce the counter passes of tools/gpurun.sh stage pmcenc to one JSON: per kernel of this library, the share of wave
 cycles parked / stalled / issuing, LDS activity, and the matrix-pipe utilisation.
 Usage: python tools/pmc_encoder_summary.py <dir with sq_/mfma_ csv> <out.json>"""
 import collections
@@ -55,7 +55,7 @@ def load(prefix):
 
 sq, nsq = load("sq")
 mf, nmf = load("mfma")
-res = {"source": "rocprofv3 --pmc (two passes, tools/gpu_pmc_enc.sh) over one encoder pass of 256 segments, MI355X",
+res = {"source": "rocprofv3 --pmc (two passes, tools/gpurun.sh stage pmcenc) over one encoder pass of 256 segments, MI355X",
        "note": "ratios of raw counters summed over all dispatches of the kernel; mfma_util = "
                "SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES): the busy counter adds up the 4 SIMDs of a CU (the "
                "gfx94x MfmaUtil formula); flops = SQ_INSTS_VALU_MFMA_MOPS_BF16 * 512",

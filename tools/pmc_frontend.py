@@ -1,5 +1,5 @@
 """Log-mel frontend launches (256 segments) for a rocprofv3 --pmc run: is the kernel bound by VALU issue, by LDS, or
-by memory?  (tools/gpu_pmc_fe.sh)"""
+by memory?  (tools/gpurun.sh stage pmcfe)"""
 import os
 import sys
 

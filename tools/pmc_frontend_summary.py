@@ -1,4 +1,4 @@
-"""Reduce the counter passes of tools/gpu_pmc_fe.sh to one JSON for the log-mel kernel.
+"""Reduce the counter passes of tools/gpurun.sh stage pmcfe to one JSON for the log-mel kernel.
 Usage: python tools/pmc_frontend_summary.py <dir with p*_counter_collection.csv / p*_kernel_trace.csv> <out.json>"""
 import collections
 import csv
@@ -24,7 +24,7 @@ for f in sorted(glob.glob(os.path.join(src, "**", "p*_kernel_trace.csv"), recurs
 n = max(disp.values()) if disp else 0
 per = {k: v / disp[k] for k, v in raw.items()}              # per dispatch (256 segments = 65,536 frames)
 frames = 256 * 256
-res = {"source": "rocprofv3 --pmc (tools/gpu_pmc_fe.sh) over logmel_kernel<4> launches of 256 segments, MI355X",
+res = {"source": "rocprofv3 --pmc (tools/gpurun.sh stage pmcfe) over logmel_kernel<4> launches of 256 segments, MI355X",
        "dispatches_per_pass": n, "per_dispatch": per,
        "kernel_us_under_counters": sorted(dur)[len(dur) // 2] if dur else None}
 g = per.get
