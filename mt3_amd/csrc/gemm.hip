@@ -51,6 +51,13 @@
 #ifndef MT3_GLDS_BK
 #define MT3_GLDS_BK 32     // K slice of the LDS-DMA tile: 32 (64-byte row pieces) or 64 (whole 128-byte lines)
 #endif
+// round-6 A/B builds (tools/ab_r6.py compiles the sources once per value; 0 in the product): bit 1 = the decode-sized
+// tile's waves do NOT raise their issue priority (the product before round 6).  Measured and removed again
+// (profiles/r6_ab_decode_gemm_variants.txt): weight slices loaded non-temporally (-4 %), the f32 two-source fold launch in
+// K slices of 512 -- three dependent trips instead of six (+-0: the dependent trips are not what the launch waits for).
+#ifndef MT3_EXP
+#define MT3_EXP 0
+#endif
 
 namespace mt3k {
 
@@ -341,6 +348,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   float* const gOutSs = g.out_ss;
 
   MT3_PROF_MARK(0);
+  // Decode-sized tiles run beside the other row groups' attention launches, whose waves share the CU's issue arbiter
+  // with this tile's four: at the default priority the latency-bound tile waits its turn behind HBM-bound waves that
+  // lose nothing by waiting.  Priority 3 for the whole (short) kernel: f32 headline 466-472 -> 482-484 audio-s/s, the
+  // 1024-step decode 1087-1103 -> 1061-1066 ms (profiles/r6_ab_decode_gemm_variants.txt); same instructions, same bits.
+  if constexpr ((MT3_EXP & 2) == 0 && BM <= 64) __builtin_amdgcn_s_setprio(3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = gN / BN;

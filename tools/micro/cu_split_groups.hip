@@ -275,7 +275,7 @@ int main(int argc, char** argv) {
       int* fl = flags[g] + 2 * c0;                   // (c0 counts 4 launches per layer; 8 flag words per fused launch)
       for (int t = 0; t < steps; ++t)
         for (int l = 0; l < kLayers; ++l) {
-          if (variant >= 5) {
+          if (variant == 5 || variant == 6) {
             const f32x4_t* kvl = kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16);
             if (variant == 5)
               hipLaunchKernelGGL(k_layer_fused<false>, dim3(256), dim3(256), 0, sa[g], kvl, sink, weights, bufs[g][0],
