@@ -384,6 +384,18 @@ __device__ __forceinline__ float row_rs_from_partials(const float* ss, int n, in
   return rsqrtf(tot / static_cast<float>(16 * n) + 1e-6f);
 }
 
+
+// Every field of DecAttnArgs in SGPRs behind ONE scalar-memory round trip (see gemm.hip: gemm_kernel): left to itself the
+// compiler sinks the s_loads next to their first use -- shape, then the retirement pointers, then the cache pointers,
+// each a dependent trip to the kernel-argument segment in front of the first K/V request.  (MT3_EXP bit 6: off, for A/B.)
+#if defined(MT3_EXP) && (MT3_EXP & 64)
+#define MT3_PIN_DEC_ATTN_ARGS(a)
+#else
+#define MT3_PIN_DEC_ATTN_ARGS(a)                                                                                        \
+  asm volatile("" ::"s"((a).q), "s"((a).q_stride), "s"((a).kcache), "s"((a).vcache), "s"((a).cap), "s"((a).new_k),       \
+               "s"((a).new_v), "s"((a).kv_stride), "s"((a).step), "s"((a).n_keys), "s"((a).out), "s"((a).B), "s"((a).H), \
+               "s"((a).kv_scale), "s"((a).q_f32), "s"((a).q_ss), "s"((a).q_ss_n), "s"((a).done), "s"((a).cache_row))
+#endif
 template <typename CT, bool APPEND, int NW, bool QF32 = false>
 __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
   constexpr int KPL = CTraits<CT>::KPL;
@@ -396,6 +408,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_kernel(DecAttnArgs a) {
 
   __shared__ float s_m[NW][LPK], s_l[NW][LPK], s_acc[NW][LPK][KPL];
 
+  MT3_PIN_DEC_ATTN_ARGS(a);
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane % LPK, slot = lane / LPK;
@@ -676,6 +689,7 @@ __global__ __launch_bounds__(NW * 64) void dec_attn_fp8_kernel(DecAttnArgs a) {
   // HBM peak is that fixed part on half the bytes, not residency, the tail merge or the conversions.
   __shared__ float s_new[APPEND ? 2 : 1][LPK][EPL];
 
+  MT3_PIN_DEC_ATTN_ARGS(a);
   const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sub = lane & 3, slot = lane >> 2;

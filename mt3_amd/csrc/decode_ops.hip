@@ -189,9 +189,6 @@ __global__ __launch_bounds__(256) void argmax_step_kernel(float* __restrict__ lo
   __shared__ int s_tok, s_t;
   __shared__ float s_rs;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#if defined(MT3_EXP) && (MT3_EXP & 8)
-  __builtin_amdgcn_s_setprio(3);      // round-6 A/B (tools/ab_r6.py): the step's last kernel at the dense tiles' priority
-#endif
   // row retirement: a finished slot is not touched again (its ids stay at the 0 they were initialised to, its
   // position counter stops: nothing reads it any more)
   if (rt.retire && done[b]) return;

@@ -33,6 +33,9 @@
 #ifndef MT3_PROF_MARK
 #define MT3_PROF_MARK(i)
 #endif
+#ifndef MT3_PROF_DECL
+#define MT3_PROF_DECL
+#endif
 // tools/micro/glds_probe.hip builds the LDS-DMA tile with parts left out to see what bounds it (0 in the product):
 // 1 = no fragment reads / MFMAs, 2 = no DMA after the prologue's DEPTH slices, 4 = no epilogue
 #ifndef MT3_GLDS_PROBE
@@ -52,11 +55,42 @@
 #define MT3_GLDS_BK 32     // K slice of the LDS-DMA tile: 32 (64-byte row pieces) or 64 (whole 128-byte lines)
 #endif
 // round-6 A/B builds (tools/ab_r6.py compiles the sources once per value; 0 in the product): bit 1 = the decode-sized
-// tile's waves do NOT raise their issue priority (the product before round 6).  Measured and removed again
+// tile's waves do NOT raise their issue priority (the product before round 6), bit 6 = its kernel arguments are NOT
+// pinned behind one scalar round trip.  Measured and removed again
 // (profiles/r6_ab_decode_gemm_variants.txt): weight slices loaded non-temporally (-4 %), the f32 two-source fold launch in
 // K slices of 512 -- three dependent trips instead of six (+-0: the dependent trips are not what the launch waits for).
 #ifndef MT3_EXP
 #define MT3_EXP 0
+#endif
+#if MT3_EXP & 32
+// bit 5 = IN-SITU phase accounting of the decode-sized tiles (tools/gemm_phases_in_situ.py): lane 0 of every workgroup
+// adds its 100 MHz wall-clock spans to g_ph[epilogue]: [0] workgroups, [1] entry -> first K slice in LDS, [2] -> K loop
+// done, [3] -> epilogue stores acknowledged, [4] entry -> first barrier (the first slice's
+// loads requested; [1] - [4] = their arrival + the staging pass)
+__device__ unsigned long long g_ph[16][8];
+#undef MT3_PROF_DECL
+#undef MT3_PROF_MARK
+#define MT3_PROF_DECL unsigned long long ph_t0 = 0, ph_t1 = 0, ph_t2 = 0, ph_ta = 0
+#define MT3_PROF_MARK(i)                                                                         \
+  do {                                                                                           \
+    if constexpr (BM <= 64) {                                                                    \
+      if ((i) == 4) __builtin_amdgcn_s_waitcnt(0);                                               \
+      if (threadIdx.x == 0) {                                                                    \
+        const unsigned long long t_ = wall_clock64();                                            \
+        if ((i) == 0) ph_t0 = t_;                                                                \
+        else if ((i) == 1) { if (!ph_ta) ph_ta = t_; }                                           \
+        else if ((i) == 2) { if (!ph_t1) ph_t1 = t_; }                                           \
+        else if ((i) == 3) ph_t2 = t_;                                                           \
+        else if ((i) == 4) {                                                                     \
+          atomicAdd(&g_ph[EPI][0], 1ull);                                                        \
+          atomicAdd(&g_ph[EPI][1], ph_t1 - ph_t0);                                               \
+          atomicAdd(&g_ph[EPI][2], ph_t2 - ph_t1);                                               \
+          atomicAdd(&g_ph[EPI][3], t_ - ph_t2);                                                  \
+          atomicAdd(&g_ph[EPI][4], ph_ta - ph_t0);                                               \
+        }                                                                                        \
+      }                                                                                          \
+    }                                                                                            \
+  } while (0)
 #endif
 
 namespace mt3k {
@@ -337,6 +371,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   __shared__ float ss_part[NORM ? BM * NP : 1];
   __shared__ float rs_x[NORM ? 1 : BM];            // norm == 2: row scales from the producer's partial sums
 
+  // EVERY field of the argument struct in SGPRs behind ONE scalar-memory round trip.  Left to itself the compiler sinks
+  // the s_loads into the blocks that first use a field: the decode-sized tile began with four DEPENDENT batches (shape ->
+  // tile origin -> operand pointers -> epilogue pointers), each a trip to the kernel-argument segment, before it
+  // requested its first operand byte (tools/gemm_phases_in_situ.py: 2.3-2.9 us from entry to the first slice's loads
+  // requested in situ, 1.6-2.0 alone on the chip).  The empty asm needs all of them at once; later uses are the same
+  // invariant loads and fold into these registers.
+#if !(MT3_EXP & 64)
+  asm volatile("" ::"s"(g.A), "s"(g.Wt), "s"(g.out), "s"(g.aux), "s"(g.M), "s"(g.N), "s"(g.K), "s"(g.lda), "s"(g.ldo),
+               "s"(g.seq_len), "s"(g.a_ss), "s"(g.out_ct), "s"(g.out_ss), "s"(g.out2), "s"(g.n_split), "s"(g.ld2),
+               "s"(g.A2), "s"(g.lda2), "s"(g.k_split), "s"(g.resid_src), "s"(g.n_major), "s"(gridDim.x));
+#endif
   // scalars out of the by-value argument struct (never take its address: that forces a private copy)
   const void* const gA = g.A;
   const void* const gW = g.Wt;
@@ -347,6 +392,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   void* const gOutCt = g.out_ct;
   float* const gOutSs = g.out_ss;
 
+  MT3_PROF_DECL;
   MT3_PROF_MARK(0);
   // Decode-sized tiles run beside the other row groups' attention launches, whose waves share the CU's issue arbiter
   // with this tile's four: at the default priority the latency-bound tile waits its turn behind HBM-bound waves that
@@ -367,14 +413,19 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
   const int ld_row = tid / CPR, ld_chunk = tid % CPR;
   // norm == 2: the K/16 (<= 4 * NPV) exact partial sums of squares of this thread's tile row, requested up front
   // and folded only after the operand loads have been issued (the fold must not delay them)
+  // (UNCONDITIONAL loads from always-valid addresses -- the row's partials, or with no a_ss the first bytes of the weight
+  // matrix -- at a clamped index, as in gemm_glds_kernel: under a per-thread, per-element "load or zero" condition the
+  // compiler masked each load separately and waited for the first one before it issued the operand loads: a memory
+  // round trip at the head of every norm-fused decode launch)
   float4 pv[NPV];
   const bool scale_rows = !NORM && gAss != nullptr && tid < BM;
+  const int npv = gAss ? (gK >> 6) : 1;
   if constexpr (!NORM) {
-    const int prow = m0 + tid < gM ? m0 + tid : gM - 1;
-    const float4* p4 = reinterpret_cast<const float4*>(gAss + static_cast<size_t>(prow) * (gK >> 4));
+    const int prow = m0 + (tid & (BM - 1)) < gM ? m0 + (tid & (BM - 1)) : gM - 1;
+    const float4* p4 = gAss ? reinterpret_cast<const float4*>(gAss + static_cast<size_t>(prow) * (gK >> 4))
+                            : reinterpret_cast<const float4*>(gW);
 #pragma unroll
-    for (int u = 0; u < NPV; ++u)
-      pv[u] = (scale_rows && u < (gK >> 6)) ? p4[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < NPV; ++u) pv[u] = p4[u < npv ? u : npv - 1];
   }
   // decode-sized RESID tiles (bf16): this lane's elements of the residual rows, requested before anything else
   constexpr bool kPre = (EPI == MT3_EPI_RESID || EPI == kEpiResidQ || EPI == kEpiResidS) && FM * FN <= 2;
@@ -428,7 +479,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs g) {
     if (scale_rows) {
       float t = 0.f;
 #pragma unroll
-      for (int u = 0; u < NPV; ++u) t = (((t + pv[u].x) + pv[u].y) + pv[u].z) + pv[u].w;    // fixed order per row
+      for (int u = 0; u < NPV; ++u) {
+        const float4 v = u < npv ? pv[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        t = (((t + v.x) + v.y) + v.z) + v.w;                                                // fixed order per row
+      }
       rs_x[tid] = rsqrtf(t / static_cast<float>(gK) + 1e-6f);                               // read after the K loop's barriers
     }
   }
@@ -1277,3 +1331,12 @@ extern "C" int mt3_op_gemm(int32_t dtype, const void* d_A, int32_t a_is_f32, int
   g.seq_len = seq_len;
   return mt3k::launch_gemm(dtype, g, a_is_f32 != 0, norm != 0 ? 1 : 0, epilogue, small != 0, static_cast<hipStream_t>(stream));
 }
+
+#if MT3_EXP & 32
+// experiment build only: copy the phase accumulators out (16 x 8 uint64) and clear them
+extern "C" int mt3_exp_gemm_phases(unsigned long long* h_out) {
+  if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_ph), sizeof(unsigned long long) * 16 * 8) != hipSuccess) return 1;
+  static const unsigned long long zeros[16 * 8] = {};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_ph), zeros, sizeof(zeros)) != hipSuccess;
+}
+#endif

@@ -1,7 +1,5 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-for v in 4 7 8 7 8; do
-  ( cd tools/micro && timeout 90 ./cu_split_groups $v ) 2>&1 | tee -a gpurun_out/r6_micro_cu_split_groups_b.txt | tail -2
-done
-timeout 300 python tools/attn_width_probe.py 2>&1 | tee gpurun_out/r6_attn_width_probe.txt | tail -6
-timeout 1500 python tools/ab_r6.py run 0 1 2 3 4 6 0 2>&1 | tee gpurun_out/r6_ab_decode_gemm_variants.txt | tail -12
+timeout 1200 python tools/ab_r6.py run 0 64 0 64 2>&1 | tee gpurun_out/r6_ab_kernarg_pin.txt | tail -6
+PH_STEPS=256 timeout 600 python tools/ab_r6.py phases 2>&1 | tee gpurun_out/r6_gemm_phases_in_situ_pinned.txt | grep -A5 "^1\.\|^4\." | cut -c1-330
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_engine.py tests/test_gpu_parity_r5.py -m gpu -q -x 2>&1 | tail -4

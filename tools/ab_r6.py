@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round-6 A/B builds of libmt3hip.so: `python tools/ab_r6.py build` compiles gemm.hip once per MT3_EXP value (the other
-objects come from the product build) into build/exp/libmt3hip_exp<N>.so; `python tools/ab_r6.py run [N ...]` (on the GPU
+objects come from the product build) into build/exp/libmt3hip_exp<N>.so; `python tools/ab_r6.py run [N ...]` / `phases` (on the GPU
 box) puts each in the product's place in turn, runs the f32 headline (`bench.py --no-cpu-baseline --no-extras`) and prints
 value / ms per step, then restores the product library.  Results: profiles/r6_ab_decode_gemm_variants.txt."""
 import json
@@ -15,9 +15,10 @@ from mt3_amd import build as B  # noqa: E402
 
 EXP = os.path.join(ROOT, "build", "exp")
 # MT3_EXP value -> (what, sources compiled with -DMT3_EXP=value)
-VARIANTS = {0: ("product (decode-sized GEMM tiles at s_setprio 3)", []),
+VARIANTS = {0: ("product (decode-sized GEMM tiles at s_setprio 3, kernel arguments behind one scalar round trip)", []),
+            64: ("product without the kernel-argument pin (GEMM tiles and decode attention)", ["gemm.hip", "attention.hip"]),
             2: ("decode-sized GEMM tiles at the default priority (the product of rounds 1-5)", ["gemm.hip"]),
-            8: ("product + argmax_step_kernel at s_setprio 3", ["decode_ops.hip"])}
+            32: ("product + in-situ phase accounting of the decode-sized tiles (tools/gemm_phases_in_situ.py)", ["gemm.hip"])}
 
 
 def build():
@@ -39,10 +40,14 @@ def build():
         print("built variant", n, what, flush=True)
 
 
-def run(which, bench_args):
+def run(which, bench_args, phases=False):
     keep = B.LIB + ".product"
     shutil.copy2(B.LIB, keep)
     try:
+        if phases:
+            shutil.copy2(os.path.join(EXP, "libmt3hip_exp32.so"), B.LIB)
+            subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_phases_in_situ.py")], cwd=ROOT)
+            return
         for n in which:
             shutil.copy2(keep if n == 0 else os.path.join(EXP, "libmt3hip_exp%d.so" % n), B.LIB)
             r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extras", *bench_args],
@@ -63,6 +68,8 @@ def run(which, bench_args):
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+    elif sys.argv[1] == "phases":
+        run([], [], phases=True)
     else:
         args = sys.argv[2:]
         sep = args.index("--") if "--" in args else len(args)
