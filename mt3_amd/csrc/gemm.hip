@@ -58,7 +58,9 @@
 // tile's waves do NOT raise their issue priority (the product before round 6), bit 6 = its kernel arguments are NOT
 // pinned behind one scalar round trip.  Measured and removed again
 // (profiles/r6_ab_decode_gemm_variants.txt): weight slices loaded non-temporally (-4 %), the f32 two-source fold launch in
-// K slices of 512 -- three dependent trips instead of six (+-0: the dependent trips are not what the launch waits for).
+// K slices of 512 -- three dependent trips instead of six (+-0: the dependent trips are not what the launch waits for);
+// half the WEIGHT bytes per workgroup on twice the workgroups -- fold on 32 x 16, GEGLU on 32 x 32, out-projections on
+// 32 x 16 tiles of two waves (-5 %: profiles/r6_ab_narrow_tiles.txt).
 #ifndef MT3_EXP
 #define MT3_EXP 0
 #endif
@@ -1182,6 +1184,7 @@ static int launch_tile(const GemmArgs& g, bool small, hipStream_t s) {
       if (deep) return launch_small<CT, 32, 64, 16 * KG, A_F32, NORM, EPI>(g, s);
       return launch_cfg<CT, 32, 64, 4 * KG, 2, 2, A_F32, NORM, EPI>(g, s);
     } else {
+
       if constexpr (!NORM && !A_F32 && KG == 32) {
         // the attention out-projections (K = 384 = 12 K-groups) as ONE slice as well (-1 % of the decode; the
         // same for wo, K = 1024 in 133 KB of LDS, measured slower than its two 512-slices)

@@ -40,12 +40,12 @@ def build():
         print("built variant", n, what, flush=True)
 
 
-def run(which, bench_args, phases=False):
+def run(which, bench_args, phases=0):
     keep = B.LIB + ".product"
     shutil.copy2(B.LIB, keep)
     try:
         if phases:
-            shutil.copy2(os.path.join(EXP, "libmt3hip_exp32.so"), B.LIB)
+            shutil.copy2(os.path.join(EXP, "libmt3hip_exp%d.so" % phases), B.LIB)
             subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_phases_in_situ.py")], cwd=ROOT)
             return
         for n in which:
@@ -69,7 +69,7 @@ if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
     elif sys.argv[1] == "phases":
-        run([], [], phases=True)
+        run([], [], phases=int(sys.argv[2]) if len(sys.argv) > 2 else 32)
     else:
         args = sys.argv[2:]
         sep = args.index("--") if "--" in args else len(args)
