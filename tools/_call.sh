@@ -1,3 +1,6 @@
-bash tools/gpurun.sh pmcattn
-cp gpurun_out/pmc/r6_pmc_summary.json profiles/r6_pmc_summary.json 2>/dev/null
-bash tools/gpurun.sh test smoke bench prof pmcenc
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out
+for v in 4 9 4 9; do
+  ( cd tools/micro && timeout 120 ./cu_split_groups $v ) 2>&1 | tee -a gpurun_out/r6_micro_any_order.txt | tail -3
+done
+bash tools/gpurun.sh prof

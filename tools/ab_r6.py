@@ -17,6 +17,7 @@ EXP = os.path.join(ROOT, "build", "exp")
 # MT3_EXP value -> (what, sources compiled with -DMT3_EXP=value)
 VARIANTS = {0: ("product (decode-sized GEMM tiles at s_setprio 3, kernel arguments behind one scalar round trip)", []),
             64: ("product without the kernel-argument pin (GEMM tiles and decode attention)", ["gemm.hip", "attention.hip"]),
+            66: ("neither the priority nor the pin (the kernels of round 5)", ["gemm.hip", "attention.hip"]),
             2: ("decode-sized GEMM tiles at the default priority (the product of rounds 1-5)", ["gemm.hip"]),
             32: ("product + in-situ phase accounting of the decode-sized tiles (tools/gemm_phases_in_situ.py)", ["gemm.hip"])}
 
@@ -40,10 +41,16 @@ def build():
         print("built variant", n, what, flush=True)
 
 
-def run(which, bench_args, phases=0):
+def run(which, bench_args, phases=0, ids=False):
     keep = B.LIB + ".product"
     shutil.copy2(B.LIB, keep)
     try:
+        if ids:
+            for n in which:
+                shutil.copy2(keep if n == 0 else os.path.join(EXP, "libmt3hip_exp%d.so" % n), B.LIB)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ids_hash.py")], capture_output=True, text=True, cwd=ROOT)
+                print("variant %d (%s): %s" % (n, VARIANTS.get(n, ("?",))[0], (r.stdout.strip().splitlines() or [r.stderr[-400:]])[-1]), flush=True)
+            return
         if phases:
             shutil.copy2(os.path.join(EXP, "libmt3hip_exp%d.so" % phases), B.LIB)
             subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_phases_in_situ.py")], cwd=ROOT)
@@ -68,6 +75,8 @@ def run(which, bench_args, phases=0):
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+    elif sys.argv[1] == "ids":
+        run([int(a) for a in sys.argv[2:]] or [0, 2, 64, 66], [], ids=True)
     elif sys.argv[1] == "phases":
         run([], [], phases=int(sys.argv[2]) if len(sys.argv) > 2 else 32)
     else:

@@ -66,6 +66,57 @@ __global__ __launch_bounds__(256) void k_gemm_dep(const f32x4_t* __restrict__ w,
   o[0] = acc[0] * a[0], o[1] = acc[1] * a[1], o[2] = acc[2] * a[2], o[3] = acc[3] * a[3];
 }
 
+// G (round 6): A' launched with hipExtAnyOrderLaunch -- no barrier bit between the launches of a stream, the order kept by
+// the kernels themselves: every workgroup signals a per-group counter at its end, every kernel waits (one polling lane,
+// bounded) until the counter has reached the number of workgroups launched before it.  The GEMM-like kernel reads its
+// weights BEFORE the wait.  What a launch boundary costs against a flag, if the runtime honours the flag on gfx950.
+__device__ __forceinline__ void g_wait(const int* ctr, int target, int* gave_up) {
+  if (threadIdx.x == 0) {
+    long spins = 0;
+    // bounded: ~20 ms per wait, and once 64 waits have given up nobody waits any more (a broken run ends quickly)
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > 20000 || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 64) {
+        atomicAdd(gave_up, 1);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void g_signal(int* ctr) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__global__ __launch_bounds__(192) void k_attn_like_g(const f32x4_t* __restrict__ in, float* __restrict__ sink, int* ctr, int target,
+                                                     int* gave_up) {
+  g_wait(ctr, target, gave_up);
+  const f32x4_t* src = in + static_cast<size_t>(blockIdx.x) * (512 * 1024 / 16);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < 512 * 1024 / 16; i += 192) {
+    const f32x4_t v = __builtin_nontemporal_load(src + i);
+    acc += v[0] + v[1] + v[2] + v[3];
+  }
+  if (acc == 123.456f) sink[blockIdx.x] = acc;
+  g_signal(ctr);
+}
+__global__ __launch_bounds__(256) void k_gemm_dep_g(const f32x4_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ prev,
+                                                    int slice, int* ctr, int target, int* gave_up) {
+  const f32x4_t* src = w + (static_cast<size_t>(slice) * 104 + blockIdx.x) * (64 * 1024 / 16);
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int i = threadIdx.x; i < 64 * 1024 / 16; i += 256) acc += src[i];
+  g_wait(ctr, target, gave_up);
+  const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(prev + ((blockIdx.x * 7) % 104) * 1024 + threadIdx.x * 4));
+  float* o = out + blockIdx.x * 1024 + threadIdx.x * 4;
+  o[0] = acc[0] * a[0], o[1] = acc[1] * a[1], o[2] = acc[2] * a[2], o[3] = acc[3] * a[3];
+  g_signal(ctr);
+}
+
 // F (VERDICT r5 #3b, the out-projection inside the attention epilogue): the attention-like workgroups are (row, head) pairs,
 // six per row; the LAST of a row's six to finish (a counter per row) projects the row itself -- a GEMV over the whole
 // 1.4 MB out-projection matrix (896 x 384 f32), read by every one of the 64 rows -- instead of a 22-workgroup GEMM-like
@@ -228,14 +279,15 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&out[g], 104 * 1024 * 4));
     CK(hipMemset(out[g], 0, 104 * 1024 * 4));
   }
-  const char* names[9] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
+  const char* names[10] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
                           "C two streams per group, both on all CUs",
                           "D one stream per group, work-claiming kernels that keep to 6/8 (attention) and 2/8 (dense) of the CUs",
                           "A' = A with a dependent 4 KB read in every GEMM-like launch",
                           "E0 one launch per layer and group, dense stages wait on ready counters, weights loaded AFTER the wait",
                           "E1 as E0, weights prefetched into registers BEFORE the wait",
                           "A'' = A' with the FIRST dense launch of a layer at the out-projection's size (22 workgroups, 1.4 MB)",
-                          "F  = A'' with that launch replaced by a per-row GEMV in the tail of the attention-like kernel"};
+                          "F  = A'' with that launch replaced by a per-row GEMV in the tail of the attention-like kernel",
+                           "G  = A' launched with hipExtAnyOrderLaunch, order kept by a per-group counter (weights read before the wait)"};
   int* row_cnt[G];
   for (int g = 0; g < G; ++g) CK(hipMalloc(&row_cnt[g], (kSteps + 10) * kLayers * 64 * 4));
   float* bufs[G][4];
@@ -252,10 +304,13 @@ int main(int argc, char** argv) {
   constexpr int kLaunches = (kSteps + 10) * kLayers * (1 + kDense);
   int* counters[G];
   for (int g = 0; g < G; ++g) CK(hipMalloc(&counters[g], kLaunches * 4));
-  for (int variant = 0; variant < 9; ++variant) {
+  int* gctr[G];
+  for (int g = 0; g < G; ++g) CK(hipMalloc(&gctr[g], 8));
+  for (int variant = 0; variant < 10; ++variant) {
     for (int g = 0; g < G; ++g) CK(hipMemset(row_cnt[g], 0, (kSteps + 10) * kLayers * 64 * 4));
     if (only >= 0 ? variant != only : (variant >= 1 && variant <= 3)) continue;     // B, C, D: round 4's results stand
     for (int g = 0; g < G; ++g) CK(hipMemset(counters[g], 0, kLaunches * 4));
+    for (int g = 0; g < G; ++g) CK(hipMemset(gctr[g], 0, 8));
     for (int g = 0; g < G; ++g) CK(hipMemset(flags[g], 0, (kSteps + 10) * kLayers * 8 * 4));
     hipStream_t sa[G], sd[G];
     hipEvent_t e1[G], e2[G];
@@ -268,8 +323,11 @@ int main(int argc, char** argv) {
       CK(hipEventCreateWithFlags(&e1[g], hipEventDisableTiming));
       CK(hipEventCreateWithFlags(&e2[g], hipEventDisableTiming));
     }
+    static int launched_total[G];
+    for (int g = 0; g < G; ++g) launched_total[g] = 0;
     auto run = [&](int g, int steps, int c0) {
       (void)hipSetDevice(0);
+      int& launched = launched_total[g];
       int slice = g * 3;
       int* ctr = counters[g] + c0;
       int* fl = flags[g] + 2 * c0;                   // (c0 counts 4 launches per layer; 8 flag words per fused launch)
@@ -299,6 +357,19 @@ int main(int argc, char** argv) {
             ++slice;
             for (int d = 1; d < kDense; ++d) {
               hipLaunchKernelGGL(k_gemm_dep, dim3(104), dim3(256), 0, sa[g], weights, bufs[g][d + 1], bufs[g][d], slice % 14);
+              ++slice;
+            }
+            continue;
+          }
+          if (variant == 9) {
+            const f32x4_t* kvl = kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16);
+            hipExtLaunchKernelGGL(k_attn_like_g, dim3(384), dim3(192), 0, sa[g], nullptr, nullptr, hipExtAnyOrderLaunch, kvl, sink,
+                                  gctr[g], launched, gctr[g] + 1);
+            launched += 384;
+            for (int d = 0; d < kDense; ++d) {
+              hipExtLaunchKernelGGL(k_gemm_dep_g, dim3(104), dim3(256), 0, sa[g], nullptr, nullptr, hipExtAnyOrderLaunch, weights,
+                                    bufs[g][d + 1], bufs[g][d], slice % 14, gctr[g], launched, gctr[g] + 1);
+              launched += 104;
               ++slice;
             }
             continue;
@@ -351,6 +422,14 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     long timed_out = 0;
+    if (variant == 9) {
+      for (int g = 0; g < G; ++g) {
+        int h2[2];
+        CK(hipMemcpy(h2, gctr[g], 8, hipMemcpyDeviceToHost));
+        timed_out += h2[1];
+        if (h2[0] != launched_total[g]) printf("   group %d: counter %d, launched %d\n", g, h2[0], launched_total[g]);
+      }
+    }
     if (variant == 5 || variant == 6) {
       std::vector<int> h((kSteps + 10) * kLayers * 8);
       for (int g = 0; g < G; ++g) {

@@ -10,12 +10,14 @@ root = sys.argv[1]
 files = glob.glob(os.path.join(root, "**", "*kernel_trace.csv"), recursive=True)
 if not files:
     sys.exit("no kernel_trace.csv under " + root)
-rows = []
+rows, queues = [], []
 with open(files[0]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
                      int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0),
                      int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0)) or 0)))
+        queues.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0"),
+                       int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0)))
 rows.sort()
 tot = defaultdict(lambda: [0, 0.0])
 for s, e, n, _, _ in rows:
@@ -84,3 +86,33 @@ if attn:
             print("row-group decodes: %d bursts, %.1f ms; share of wall time with k decode-attention kernels in flight: %s; "
                   "no kernel at all in flight: %.3f" % (len(bursts), span / 1e6,
                                                          {k: round(v / span, 3) for k, v in sorted(hist.items())}, idle / span))
+
+
+# ---- inter-kernel gaps per hardware queue inside the row-group decodes (round 6): end of a kernel -> start of the next one
+# on the SAME queue, by what the two kernels are (quarter-batch launches only; under the profiler's own per-launch cost)
+def kind(n):
+    if "dec_attn" in n:
+        return "attention"
+    if "argmax_step" in n:
+        return "argmax"
+    if "gemm_kernel" in n:
+        return "dense"
+    return "other"
+
+
+if attn and small and bursts:
+    byq = defaultdict(list)
+    for s, e, n, q, grid in queues:
+        if any(b0 <= s and e <= b1 for b0, b1 in bursts):
+            byq[q].append((s, e, kind(n)))
+    gaps = defaultdict(list)
+    for q, ks in byq.items():
+        ks.sort()
+        for (s0, e0, k0), (s1, e1, k1) in zip(ks, ks[1:]):
+            if s1 - e0 < 50_000 and k0 != "other" and k1 != "other":      # (a poll / refill pause is not a launch gap)
+                gaps[(k0, k1)].append((s1 - e0) / 1e3)
+    print("queues with decode work: %d" % len(byq))
+    for (k0, k1), g in sorted(gaps.items()):
+        g.sort()
+        print("gap %-9s -> %-9s: %7d boundaries, mean %.2f us, median %.2f, p90 %.2f" % (k0, k1, len(g), sum(g) / len(g),
+                                                                                         g[len(g) // 2], g[len(g) * 9 // 10]))
