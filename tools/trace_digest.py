@@ -89,7 +89,9 @@ if attn:
 
 
 # ---- inter-kernel gaps per hardware queue inside the row-group decodes (round 6): end of a kernel -> start of the next one
-# on the SAME queue, by what the two kernels are (quarter-batch launches only; under the profiler's own per-launch cost)
+# on the SAME queue, by what the two kernels are.  CAVEAT: under rocprofv3 --kernel-trace a row-group decode takes 2.6x its
+# un-profiled time and a kernel's start stamp is the end stamp of its predecessor on the queue for most boundaries (median
+# gap 0): these figures describe the profiler's serialisation, not the product's launch boundaries
 def kind(n):
     if "dec_attn" in n:
         return "attention"
