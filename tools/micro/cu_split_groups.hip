@@ -117,6 +117,57 @@ __global__ __launch_bounds__(256) void k_gemm_dep_g(const f32x4_t* __restrict__ 
   g_signal(ctr);
 }
 
+// G' : G without fences, by the guide's hand-off recipe (MI355X_MICROARCH.md, rows "handoff-flag" / "publish-large"): the
+// producer's outputs leave as write-through (sc1) stores, are drained (vmcnt 0), then ONE relaxed device-scope add per
+// workgroup; the consumer polls with a relaxed device-scope load and reads the producer's data with sc1 loads -- no
+// buffer_wbl2 / buffer_inv anywhere (G's per-workgroup release fence writes an XCD's whole L2 back).
+__device__ __forceinline__ void g2_wait(const int* ctr, int target, int* gave_up) {
+  if (threadIdx.x == 0) {
+    long spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > 20000 || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 64) {
+        atomicAdd(gave_up, 1);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void g2_signal(int* ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(192) void k_attn_like_g2(const f32x4_t* __restrict__ in, float* __restrict__ sink, int* ctr, int target,
+                                                      int* gave_up) {
+  g2_wait(ctr, target, gave_up);
+  const f32x4_t* src = in + static_cast<size_t>(blockIdx.x) * (512 * 1024 / 16);
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < 512 * 1024 / 16; i += 192) {
+    const f32x4_t v = __builtin_nontemporal_load(src + i);
+    acc += v[0] + v[1] + v[2] + v[3];
+  }
+  if (acc == 123.456f) sink[blockIdx.x] = acc;
+  g2_signal(ctr);
+}
+__global__ __launch_bounds__(256) void k_gemm_dep_g2(const f32x4_t* __restrict__ w, float* __restrict__ out, const float* __restrict__ prev,
+                                                     int slice, int* ctr, int target, int* gave_up) {
+  const f32x4_t* src = w + (static_cast<size_t>(slice) * 104 + blockIdx.x) * (64 * 1024 / 16);
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int i = threadIdx.x; i < 64 * 1024 / 16; i += 256) acc += src[i];
+  g2_wait(ctr, target, gave_up);
+  const float* pa = prev + ((blockIdx.x * 7) % 104) * 1024 + threadIdx.x * 4;
+  float a[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = __hip_atomic_load(pa + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float* o = out + blockIdx.x * 1024 + threadIdx.x * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) __hip_atomic_store(o + j, acc[j] * a[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  g2_signal(ctr);
+}
+
 // F (VERDICT r5 #3b, the out-projection inside the attention epilogue): the attention-like workgroups are (row, head) pairs,
 // six per row; the LAST of a row's six to finish (a counter per row) projects the row itself -- a GEMV over the whole
 // 1.4 MB out-projection matrix (896 x 384 f32), read by every one of the 64 rows -- instead of a 22-workgroup GEMM-like
@@ -279,7 +330,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&out[g], 104 * 1024 * 4));
     CK(hipMemset(out[g], 0, 104 * 1024 * 4));
   }
-  const char* names[10] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
+  const char* names[11] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
                           "C two streams per group, both on all CUs",
                           "D one stream per group, work-claiming kernels that keep to 6/8 (attention) and 2/8 (dense) of the CUs",
                           "A' = A with a dependent 4 KB read in every GEMM-like launch",
@@ -287,7 +338,8 @@ int main(int argc, char** argv) {
                           "E1 as E0, weights prefetched into registers BEFORE the wait",
                           "A'' = A' with the FIRST dense launch of a layer at the out-projection's size (22 workgroups, 1.4 MB)",
                           "F  = A'' with that launch replaced by a per-row GEMV in the tail of the attention-like kernel",
-                           "G  = A' launched with hipExtAnyOrderLaunch, order kept by a per-group counter (weights read before the wait)"};
+                           "G  = A' launched with hipExtAnyOrderLaunch, order kept by a per-group counter (weights read before the wait)",
+                           "G' = G without fences: write-through stores, drained, relaxed counter; sc1 loads of the producer's data"};
   int* row_cnt[G];
   for (int g = 0; g < G; ++g) CK(hipMalloc(&row_cnt[g], (kSteps + 10) * kLayers * 64 * 4));
   float* bufs[G][4];
@@ -306,7 +358,7 @@ int main(int argc, char** argv) {
   for (int g = 0; g < G; ++g) CK(hipMalloc(&counters[g], kLaunches * 4));
   int* gctr[G];
   for (int g = 0; g < G; ++g) CK(hipMalloc(&gctr[g], 8));
-  for (int variant = 0; variant < 10; ++variant) {
+  for (int variant = 0; variant < 11; ++variant) {
     for (int g = 0; g < G; ++g) CK(hipMemset(row_cnt[g], 0, (kSteps + 10) * kLayers * 64 * 4));
     if (only >= 0 ? variant != only : (variant >= 1 && variant <= 3)) continue;     // B, C, D: round 4's results stand
     for (int g = 0; g < G; ++g) CK(hipMemset(counters[g], 0, kLaunches * 4));
@@ -357,6 +409,19 @@ int main(int argc, char** argv) {
             ++slice;
             for (int d = 1; d < kDense; ++d) {
               hipLaunchKernelGGL(k_gemm_dep, dim3(104), dim3(256), 0, sa[g], weights, bufs[g][d + 1], bufs[g][d], slice % 14);
+              ++slice;
+            }
+            continue;
+          }
+          if (variant == 10) {
+            const f32x4_t* kvl = kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16);
+            hipExtLaunchKernelGGL(k_attn_like_g2, dim3(384), dim3(192), 0, sa[g], nullptr, nullptr, hipExtAnyOrderLaunch, kvl, sink,
+                                  gctr[g], launched, gctr[g] + 1);
+            launched += 384;
+            for (int d = 0; d < kDense; ++d) {
+              hipExtLaunchKernelGGL(k_gemm_dep_g2, dim3(104), dim3(256), 0, sa[g], nullptr, nullptr, hipExtAnyOrderLaunch, weights,
+                                    bufs[g][d + 1], bufs[g][d], slice % 14, gctr[g], launched, gctr[g] + 1);
+              launched += 104;
               ++slice;
             }
             continue;
@@ -422,7 +487,7 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     long timed_out = 0;
-    if (variant == 9) {
+    if (variant == 9 || variant == 10) {
       for (int g = 0; g < G; ++g) {
         int h2[2];
         CK(hipMemcpy(h2, gctr[g], 8, hipMemcpyDeviceToHost));
