@@ -121,11 +121,13 @@ __global__ __launch_bounds__(256) void k_gemm_dep_g(const f32x4_t* __restrict__ 
 // producer's outputs leave as write-through (sc1) stores, are drained (vmcnt 0), then ONE relaxed device-scope add per
 // workgroup; the consumer polls with a relaxed device-scope load and reads the producer's data with sc1 loads -- no
 // buffer_wbl2 / buffer_inv anywhere (G's per-workgroup release fence writes an XCD's whole L2 back).
+__device__ int g_poll_naps = 1;      // s_sleep 2 (~128 cycles) this many times between two polls (argv[2])
 __device__ __forceinline__ void g2_wait(const int* ctr, int target, int* gave_up) {
   if (threadIdx.x == 0) {
     long spins = 0;
+    const int naps = g_poll_naps;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
+      for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(2);
       if (++spins > 20000 || __hip_atomic_load(gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 64) {
         atomicAdd(gave_up, 1);
         break;
@@ -330,7 +332,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&out[g], 104 * 1024 * 4));
     CK(hipMemset(out[g], 0, 104 * 1024 * 4));
   }
-  const char* names[11] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
+  const char* names[13] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
                           "C two streams per group, both on all CUs",
                           "D one stream per group, work-claiming kernels that keep to 6/8 (attention) and 2/8 (dense) of the CUs",
                           "A' = A with a dependent 4 KB read in every GEMM-like launch",
@@ -339,7 +341,9 @@ int main(int argc, char** argv) {
                           "A'' = A' with the FIRST dense launch of a layer at the out-projection's size (22 workgroups, 1.4 MB)",
                           "F  = A'' with that launch replaced by a per-row GEMV in the tail of the attention-like kernel",
                            "G  = A' launched with hipExtAnyOrderLaunch, order kept by a per-group counter (weights read before the wait)",
-                           "G' = G without fences: write-through stores, drained, relaxed counter; sc1 loads of the producer's data"};
+                           "G' = G without fences: write-through stores, drained, relaxed counter; sc1 loads of the producer's data",
+                           "H  = G' with the barrier bit kept on the attention-like launches (run-ahead bounded to a layer's three dense launches)",
+                           "A'x = A' launched through hipExtLaunchKernelGGL with flags 0 (what the launch API itself costs the host)"};
   int* row_cnt[G];
   for (int g = 0; g < G; ++g) CK(hipMalloc(&row_cnt[g], (kSteps + 10) * kLayers * 64 * 4));
   float* bufs[G][4];
@@ -351,14 +355,19 @@ int main(int argc, char** argv) {
     }
     CK(hipMalloc(&flags[g], (kSteps + 10) * kLayers * 8 * 4));
   }
-  const int only = argc > 1 ? atoi(argv[1]) : -1;          // run one variant only (0..8); default: all but B, C, D
+  const int only = argc > 1 ? atoi(argv[1]) : -1;
+  if (argc > 2) {
+    const int naps = atoi(argv[2]);
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_poll_naps), &naps, sizeof(int)));
+    printf("(G' / H: %d naps of s_sleep 2 between polls)\n", naps);
+  }          // run one variant only (0..8); default: all but B, C, D
   // one claim counter per launch of variant D
   constexpr int kLaunches = (kSteps + 10) * kLayers * (1 + kDense);
   int* counters[G];
   for (int g = 0; g < G; ++g) CK(hipMalloc(&counters[g], kLaunches * 4));
   int* gctr[G];
   for (int g = 0; g < G; ++g) CK(hipMalloc(&gctr[g], 8));
-  for (int variant = 0; variant < 11; ++variant) {
+  for (int variant = 0; variant < 13; ++variant) {
     for (int g = 0; g < G; ++g) CK(hipMemset(row_cnt[g], 0, (kSteps + 10) * kLayers * 64 * 4));
     if (only >= 0 ? variant != only : (variant >= 1 && variant <= 3)) continue;     // B, C, D: round 4's results stand
     for (int g = 0; g < G; ++g) CK(hipMemset(counters[g], 0, kLaunches * 4));
@@ -377,8 +386,10 @@ int main(int argc, char** argv) {
     }
     static int launched_total[G];
     for (int g = 0; g < G; ++g) launched_total[g] = 0;
+    double host_enqueue_us = 0.0;
     auto run = [&](int g, int steps, int c0) {
       (void)hipSetDevice(0);
+      const auto t_enq = std::chrono::steady_clock::now();
       int& launched = launched_total[g];
       int slice = g * 3;
       int* ctr = counters[g] + c0;
@@ -413,10 +424,10 @@ int main(int argc, char** argv) {
             }
             continue;
           }
-          if (variant == 10) {
+          if (variant == 10 || variant == 11) {
             const f32x4_t* kvl = kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16);
-            hipExtLaunchKernelGGL(k_attn_like_g2, dim3(384), dim3(192), 0, sa[g], nullptr, nullptr, hipExtAnyOrderLaunch, kvl, sink,
-                                  gctr[g], launched, gctr[g] + 1);
+            hipExtLaunchKernelGGL(k_attn_like_g2, dim3(384), dim3(192), 0, sa[g], nullptr, nullptr,
+                                  variant == 10 ? hipExtAnyOrderLaunch : 0, kvl, sink, gctr[g], variant == 10 ? launched : 0, gctr[g] + 1);
             launched += 384;
             for (int d = 0; d < kDense; ++d) {
               hipExtLaunchKernelGGL(k_gemm_dep_g2, dim3(104), dim3(256), 0, sa[g], nullptr, nullptr, hipExtAnyOrderLaunch, weights,
@@ -435,6 +446,16 @@ int main(int argc, char** argv) {
               hipExtLaunchKernelGGL(k_gemm_dep_g, dim3(104), dim3(256), 0, sa[g], nullptr, nullptr, hipExtAnyOrderLaunch, weights,
                                     bufs[g][d + 1], bufs[g][d], slice % 14, gctr[g], launched, gctr[g] + 1);
               launched += 104;
+              ++slice;
+            }
+            continue;
+          }
+          if (variant == 12) {
+            hipExtLaunchKernelGGL(k_attn_like, dim3(384), dim3(192), 0, sa[g], nullptr, nullptr, 0,
+                                  kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16), sink);
+            for (int d = 0; d < kDense; ++d) {
+              hipExtLaunchKernelGGL(k_gemm_dep, dim3(104), dim3(256), 0, sa[g], nullptr, nullptr, 0, weights, bufs[g][d + 1],
+                                    static_cast<const float*>(bufs[g][d]), slice % 14);
               ++slice;
             }
             continue;
@@ -471,6 +492,8 @@ int main(int argc, char** argv) {
             (void)hipStreamWaitEvent(sa[g], e2[g], 0);
           }
         }
+      if (g == 0 && steps == kSteps)
+        host_enqueue_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq).count();
       (void)hipStreamSynchronize(sa[g]);
       (void)hipStreamSynchronize(sd[g]);
     };
@@ -487,7 +510,7 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     long timed_out = 0;
-    if (variant == 9 || variant == 10) {
+    if (variant >= 9) {
       for (int g = 0; g < G; ++g) {
         int h2[2];
         CK(hipMemcpy(h2, gctr[g], 8, hipMemcpyDeviceToHost));
@@ -505,6 +528,7 @@ int main(int argc, char** argv) {
     printf("%s: %.1f us per group step (%d layers of 1 attention-like + %d GEMM-like launches; four groups at once)%s\n",
            names[variant], us / kSteps, kLayers, kDense, timed_out ? "  [WAITS TIMED OUT: result void]" : "");
     if (timed_out) printf("   %ld waits gave up after ~50 ms\n", timed_out);
+    printf("   host: group 0's thread spent %.1f us per group step enqueueing\n", host_enqueue_us / kSteps);
     fflush(stdout);
     for (int g = 0; g < G; ++g) {
       (void)hipStreamDestroy(sa[g]);
