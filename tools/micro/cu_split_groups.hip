@@ -208,7 +208,10 @@ __global__ __launch_bounds__(192) void k_attn_gemv_tail(const f32x4_t* __restric
 // three dependent dense stages: wait on the ready counter (stage 0: 256 finished workgroups; stage d: 104 tiles of stage
 // d - 1), read a 4 KB slice of the producer's output, combine it with 64 KB of weights, publish.  PREFETCH: the weights
 // of stage 0 are requested BEFORE the attention phase and those of stage d + 1 before the wait for stage d's tiles.
-template <bool PREFETCH>
+// NOFENCE (round 6, after G'): the same hand-offs by the guide's recipe -- write-through (sc1) stores of a stage's output,
+// drained, one relaxed device-scope add; relaxed sc1 polls and sc1 loads of the producer's output; no release / acquire
+// fence (buffer_wbl2 / buffer_inv sc1 act on an XCD's whole L2, which every other group is using)
+template <bool PREFETCH, bool NOFENCE = false>
 __global__ __launch_bounds__(256) void k_layer_fused(const f32x4_t* __restrict__ kv, float* __restrict__ sink,
                                                      const f32x4_t* __restrict__ w, float* __restrict__ b0, float* __restrict__ b1,
                                                      float* __restrict__ b2, float* __restrict__ b3, int slice, int* flags) {
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void k_layer_fused(const f32x4_t* __restrict__
   if (acc == 123.456f) sink[blockIdx.x] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (!NOFENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __hip_atomic_fetch_add(flags, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (!dense) return;
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(256) void k_layer_fused(const f32x4_t* __restrict__
           break;
         }
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (!NOFENCE) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
     if (!PREFETCH) load_weights(d);
@@ -257,13 +260,23 @@ __global__ __launch_bounds__(256) void k_layer_fused(const f32x4_t* __restrict__
     for (int i = 0; i < 16; ++i) a4 += wr[i];
     const float* prev = d == 0 ? b0 : d == 1 ? b1 : b2;
     float* out = d == 0 ? b1 : d == 1 ? b2 : b3;
-    const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(prev + ((blockIdx.x * 7) % 104) * 1024 + threadIdx.x * 4));
+    const float* pa = prev + ((blockIdx.x * 7) % 104) * 1024 + threadIdx.x * 4;
     float* o = out + blockIdx.x * 1024 + threadIdx.x * 4;
-    o[0] = a4[0] * a[0], o[1] = a4[1] * a[1], o[2] = a4[2] * a[2], o[3] = a4[3] * a[3];
+    if constexpr (NOFENCE) {
+      float a[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = __hip_atomic_load(pa + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) __hip_atomic_store(o + j, a4[j] * a[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const f32x4_t a = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(pa));
+      o[0] = a4[0] * a[0], o[1] = a4[1] * a[1], o[2] = a4[2] * a[2], o[3] = a4[3] * a[3];
+    }
     if (PREFETCH && d < 2) load_weights(d + 1);          // in flight while this stage is published and the next one awaited
+    if (NOFENCE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      if (!NOFENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __hip_atomic_fetch_add(flags + 1 + d, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
@@ -332,7 +345,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&out[g], 104 * 1024 * 4));
     CK(hipMemset(out[g], 0, 104 * 1024 * 4));
   }
-  const char* names[13] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
+  const char* names[15] = {"A one stream per group, all CUs", "B attention on 6/8 of the CUs, dense launches on the other 2/8",
                           "C two streams per group, both on all CUs",
                           "D one stream per group, work-claiming kernels that keep to 6/8 (attention) and 2/8 (dense) of the CUs",
                           "A' = A with a dependent 4 KB read in every GEMM-like launch",
@@ -343,7 +356,8 @@ int main(int argc, char** argv) {
                            "G  = A' launched with hipExtAnyOrderLaunch, order kept by a per-group counter (weights read before the wait)",
                            "G' = G without fences: write-through stores, drained, relaxed counter; sc1 loads of the producer's data",
                            "H  = G' with the barrier bit kept on the attention-like launches (run-ahead bounded to a layer's three dense launches)",
-                           "A'x = A' launched through hipExtLaunchKernelGGL with flags 0 (what the launch API itself costs the host)"};
+                           "A'x = A' launched through hipExtLaunchKernelGGL with flags 0 (what the launch API itself costs the host)",
+                           "E0' = E0 without fences (sc1 stores drained + relaxed counter, sc1 loads)", "E1' = E1 without fences"};
   int* row_cnt[G];
   for (int g = 0; g < G; ++g) CK(hipMalloc(&row_cnt[g], (kSteps + 10) * kLayers * 64 * 4));
   float* bufs[G][4];
@@ -367,7 +381,7 @@ int main(int argc, char** argv) {
   for (int g = 0; g < G; ++g) CK(hipMalloc(&counters[g], kLaunches * 4));
   int* gctr[G];
   for (int g = 0; g < G; ++g) CK(hipMalloc(&gctr[g], 8));
-  for (int variant = 0; variant < 13; ++variant) {
+  for (int variant = 0; variant < 15; ++variant) {
     for (int g = 0; g < G; ++g) CK(hipMemset(row_cnt[g], 0, (kSteps + 10) * kLayers * 64 * 4));
     if (only >= 0 ? variant != only : (variant >= 1 && variant <= 3)) continue;     // B, C, D: round 4's results stand
     for (int g = 0; g < G; ++g) CK(hipMemset(counters[g], 0, kLaunches * 4));
@@ -396,6 +410,18 @@ int main(int argc, char** argv) {
       int* fl = flags[g] + 2 * c0;                   // (c0 counts 4 launches per layer; 8 flag words per fused launch)
       for (int t = 0; t < steps; ++t)
         for (int l = 0; l < kLayers; ++l) {
+          if (variant == 13 || variant == 14) {
+            const f32x4_t* kvl = kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16);
+            if (variant == 13)
+              hipLaunchKernelGGL((k_layer_fused<false, true>), dim3(256), dim3(256), 0, sa[g], kvl, sink, weights, bufs[g][0],
+                                 bufs[g][1], bufs[g][2], bufs[g][3], slice % 14, fl);
+            else
+              hipLaunchKernelGGL((k_layer_fused<true, true>), dim3(256), dim3(256), 0, sa[g], kvl, sink, weights, bufs[g][0],
+                                 bufs[g][1], bufs[g][2], bufs[g][3], slice % 14, fl);
+            fl += 8;
+            slice += 3;
+            continue;
+          }
           if (variant == 5 || variant == 6) {
             const f32x4_t* kvl = kv[g] + static_cast<size_t>(l) * 384 * (512 * 1024 / 16);
             if (variant == 5)
@@ -518,7 +544,7 @@ int main(int argc, char** argv) {
         if (h2[0] != launched_total[g]) printf("   group %d: counter %d, launched %d\n", g, h2[0], launched_total[g]);
       }
     }
-    if (variant == 5 || variant == 6) {
+    if (variant == 5 || variant == 6 || variant == 13 || variant == 14) {
       std::vector<int> h((kSteps + 10) * kLayers * 8);
       for (int g = 0; g < G; ++g) {
         CK(hipMemcpy(h.data(), flags[g], h.size() * 4, hipMemcpyDeviceToHost));
