@@ -1350,6 +1350,8 @@ int mt3_engine_encode(mt3_engine* e, const float* d_inputs, int32_t batch, float
 // profiles/r4_bench_driver_like.json eos_schedule); bf16 two groups 212.3 against 220.0 on one stream.
 static int row_groups_for(const mt3_engine_config& c, int batch, bool early_exit = false) {
   const bool f32 = c.compute_dtype != MT3_BF16;
+  // (round 6, with the dense tiles' priority in place: four groups under early exit from 256 f32 rows on -- 368-372 ms per
+  // EOS-schedule decode against 362-367 with two: profiles/r6_ab_priorities_and_kernarg_pin.txt, block 4; the rule stays)
   if (batch >= (f32 && !early_exit ? 256 : 512)) return 4;
   return batch >= 128 ? 2 : 1;
 }

@@ -77,6 +77,17 @@ if __name__ == "__main__":
         build()
     elif sys.argv[1] == "ids":
         run([int(a) for a in sys.argv[2:]] or [0, 2, 64, 66], [], ids=True)
+    elif sys.argv[1] == "eos":
+        keep = B.LIB + ".product"
+        shutil.copy2(B.LIB, keep)
+        try:
+            for n in [int(a) for a in sys.argv[2:]]:
+                shutil.copy2(keep if n == 0 else os.path.join(EXP, "libmt3hip_exp%d.so" % n), B.LIB)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "eos_profile.py"), "float32", "4"], capture_output=True, text=True, cwd=ROOT)
+                print("variant %d (%s):\n%s" % (n, VARIANTS.get(n, ("?",))[0], "\n".join(r.stdout.strip().splitlines()[-3:]) or r.stderr[-400:]), flush=True)
+        finally:
+            shutil.copy2(keep, B.LIB)
+            os.remove(keep)
     elif sys.argv[1] == "phases":
         run([], [], phases=int(sys.argv[2]) if len(sys.argv) > 2 else 32)
     else:
